@@ -1,0 +1,22 @@
+"""pytest configuration: markers + repo-root import path.
+
+`-m "not gpu"` (runs in the GPU-less build container): oracle vs golden vectors, host logic,
+C-ABI symbol checks, gloo world_size-2 tests.  `-m gpu`: parity of the HIP path vs the oracle.
+"""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return os.path.join(ROOT, "tests", "golden")
