@@ -1,0 +1,58 @@
+"""ctypes binding of include/palu_hip.h.  No torch types cross this boundary: tensors are passed
+as (data_ptr, strides, sizes) and the current HIP stream handle.
+
+There is deliberately NO fallback: if libpalu_hip.so is missing the import raises, so a GPU run
+can never silently pass on a PyTorch/CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpalu_hip.so")
+
+
+class PaluError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -m palu_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback.")
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+vp, i64, i32, f32, sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); lists every symbol declared in include/palu_hip.h
+# (tests/test_cabi.py cross-checks this table against the header and the .so exports)
+SIGNATURES = {
+    "palu_last_error": (C.c_char_p, []),
+    "palu_version": (i32, []),
+    "palu_rope_inv_freq_host": (i32, [f32, i32, C.POINTER(C.c_float)]),
+    "palu_abx_bfrag_bytes": (sz, [i32, i32, i32]),
+    "palu_abx_prepare_b": (i32, [vp, i64, i64, i64, i32, i32, i32, i32, vp, vp]),
+    "palu_abx_rope_f16": (i32, [vp, i64, i64, vp, vp, i64, i64, vp, i64, i32, i32, i32, i32, i32, vp, i32, vp]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def check(code: int, what: str = ""):
+    if code != 0:
+        msg = lib.palu_last_error().decode("utf-8", "replace")
+        if code == -1:
+            raise ValueError(f"{what}: {msg}")
+        raise PaluError(f"{what}: {msg} (code {code})")
+
+
+def current_stream() -> int:
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,49 @@
+// Shared device/host helpers for the Palu decode-path HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/palu_hip.h"
+
+typedef _Float16 h16;
+typedef __attribute__((ext_vector_type(2))) _Float16 h16x2;
+typedef __attribute__((ext_vector_type(4))) _Float16 h16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 h16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#define PALU_WAVE 64
+
+// Set by every entry point on failure; read with palu_last_error().
+void palu_set_error(const char* fmt, ...);
+
+#define PALU_REQUIRE(cond, code, ...)        \
+  do {                                       \
+    if (!(cond)) {                           \
+      palu_set_error(__VA_ARGS__);           \
+      return (code);                         \
+    }                                        \
+  } while (0)
+
+#define PALU_LAUNCH_CHECK()                                             \
+  do {                                                                  \
+    hipError_t e_ = hipGetLastError();                                  \
+    if (e_ != hipSuccess) {                                             \
+      palu_set_error("HIP launch failed: %s", hipGetErrorString(e_));   \
+      return PALU_ERR_LAUNCH;                                           \
+    }                                                                   \
+  } while (0)
+
+int palu_num_cus();   // cached hipDeviceProp multiProcessorCount of the current device
+
+static __device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+static __device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

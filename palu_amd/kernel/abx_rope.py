@@ -1,0 +1,86 @@
+"""`abx(a, b, x)` -- drop-in for the reference's `kernel.abx_rope.abx` (kernel/abx_rope.py:114-150,
+imported as `recompute_k_gemv` at kernel/palu_attention.py:13 and called at :219).
+
+Same signature, shapes and conventions: a [H,1,D], b [H,R,D], x [G,L,R] fp16 on one device ->
+[H,1,L] fp16 freshly allocated; no 1/sqrt(D); RoPE theta 1e4; key position = row index of x.
+Extensions (keyword-only): `theta`, `pos_offset`, `out`.  Arbitrary L (masked tail), arbitrary
+H/G, strided a/b; x rows must be contiguous (else one contiguous copy is made, like the cat in
+HF's cache did).  Runs on the current stream, allocation only through torch's caching allocator:
+safe under torch.cuda.graph capture once the B fragments are cached (first call outside capture).
+"""
+from __future__ import annotations
+
+import weakref
+
+import torch
+
+from .. import _lib
+
+_inv_freq_cache = {}
+_bfrag_cache = {}
+
+
+def rope_inv_freq(device, head_dim: int = 128, theta: float = 10000.0) -> torch.Tensor:
+    """fp32 table 1/theta^(2i/D), computed with the same torch expression as
+    kernel/pytorch_reference.py:4 so the angles are bit-identical to the oracle's."""
+    key = (str(device), head_dim, float(theta))
+    t = _inv_freq_cache.get(key)
+    if t is None:
+        t = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+        t = t.to(device)
+        _inv_freq_cache[key] = t
+    return t
+
+
+def prepare_b(b: torch.Tensor, num_groups: int) -> torch.Tensor:
+    """Lay the weight B [H,R,D] out as MFMA A-operand fragments (palu_abx_prepare_b).  Cached per
+    tensor object + version, because B is a weight (nn.Parameter at kernel/palu_attention.py:114)."""
+    key = id(b)
+    hit = _bfrag_cache.get(key)
+    if hit is not None:
+        ref, ver, G, frag = hit
+        if ref() is b and ver == b._version and G == num_groups:
+            return frag
+    H, R, D = b.shape
+    nbytes = _lib.lib.palu_abx_bfrag_bytes(H, num_groups, R)
+    if nbytes == 0:
+        raise ValueError(f"abx: unsupported shape H={H} G={num_groups} R={R} (need H%G==0, R%8==0)")
+    frag = torch.empty(nbytes, dtype=torch.uint8, device=b.device)
+    _lib.check(_lib.lib.palu_abx_prepare_b(b.data_ptr(), b.stride(0), b.stride(1), b.stride(2),
+                                           H, num_groups, R, D, frag.data_ptr(), _lib.current_stream()),
+               "palu_abx_prepare_b")
+    if len(_bfrag_cache) > 256:
+        for k in [k for k, v in _bfrag_cache.items() if v[0]() is None]:
+            del _bfrag_cache[k]
+    _bfrag_cache[key] = (weakref.ref(b), b._version, num_groups, frag)
+    return frag
+
+
+def abx(a: torch.Tensor, b: torch.Tensor, x: torch.Tensor, *, theta: float = 10000.0,
+        pos_offset: int = 0, out: torch.Tensor | None = None) -> torch.Tensor:
+    assert a.dim() == 3
+    assert b.dim() == 3
+    assert x.dim() == 3
+    if not (a.is_cuda and b.is_cuda and x.is_cuda):
+        raise RuntimeError("abx: tensors must live on a ROCm device (no CPU fallback)")
+    if not (a.dtype == b.dtype == x.dtype == torch.float16):
+        raise TypeError("abx: fp16 only (kernel/abx_rope.py:170 casts to float16)")
+    H, one, D = a.shape
+    Hb, R, Db = b.shape
+    G, L, Rx = x.shape
+    if one != 1 or Hb != H or Db != D or Rx != R or H % G != 0:
+        raise ValueError(f"abx: inconsistent shapes a{tuple(a.shape)} b{tuple(b.shape)} x{tuple(x.shape)}")
+    if x.stride(2) != 1 or x.stride(1) % 8 or x.stride(0) % 8 or x.data_ptr() % 16:
+        x = x.contiguous()
+    frag = prepare_b(b, G)
+    if out is None:
+        out = torch.empty((H, 1, L), dtype=x.dtype, device=x.device)
+    else:
+        assert out.shape == (H, 1, L) and out.dtype == torch.float16 and out.stride(2) == 1
+    inv = rope_inv_freq(x.device, D, theta)
+    _lib.check(_lib.lib.palu_abx_rope_f16(a.data_ptr(), a.stride(0), a.stride(2), frag.data_ptr(),
+                                          x.data_ptr(), x.stride(0), x.stride(1),
+                                          out.data_ptr(), out.stride(0), H, G, L, R, D,
+                                          inv.data_ptr(), int(pos_offset), _lib.current_stream()),
+               "palu_abx_rope_f16")
+    return out

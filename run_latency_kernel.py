@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Kernel micro-benchmark for the fused abx_rope score kernel -- same CLI as the reference's
+run_latency_kernel.py (:5-13) / kernel/abx_rope.py::run_benchmark (:173-228), without Triton:
+warm-up 25, 100 timed reps, median/p20/p80 in microseconds (abx_rope.py:198-223), randn fp16
+inputs (:200-204).  Providers: `WX` (uncompressed q.K^T, torch.matmul), `ours` (HIP abx).
+Adds achieved HBM GB/s and MFMA TFLOP/s from the algorithmic bytes/flops of SURVEY.md 8(d).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+
+import torch
+
+
+def do_bench(fn, warmup=25, rep=100, flush_mb=0):
+    """hipEvent timing of `fn` on the current stream; returns (median, p20, p80) in us."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    flush = torch.empty(flush_mb * 1024 * 1024, dtype=torch.uint8, device="cuda") if flush_mb else None
+    times = []
+    for _ in range(rep):
+        if flush is not None:
+            flush.zero_()                     # evict L2 / Infinity Cache between reps
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        fn()
+        e.record()
+        e.synchronize()
+        times.append(s.elapsed_time(e) * 1e3)
+    t = torch.tensor(times)
+    return t.median().item(), t.quantile(0.2).item(), t.quantile(0.8).item()
+
+
+def abx_algorithmic(H, G, L, R, D=128):
+    nbytes = 2 * G * L * R + 2 * H * R * D + 2 * H * D + 2 * H * L
+    flops = 2 * H * L * R * D + 5 * H * L * D
+    return nbytes, flops
+
+
+def main():
+    ap = argparse.ArgumentParser(description="abx_rope kernel latency (MI355X)")
+    ap.add_argument("--total_rank", type=int, default=2048)
+    ap.add_argument("--num_heads", type=int, default=32)
+    ap.add_argument("--head_dim", type=int, default=128)
+    ap.add_argument("--group_size", type=int, default=4)
+    ap.add_argument("--target_seq_lens", nargs="+", type=int, default=[4096, 16384, 65536, 262144])
+    ap.add_argument("--flush_mb", type=int, default=0, help="write this many MiB between reps to defeat the 256 MiB Infinity Cache")
+    ap.add_argument("--json", action="store_true")
+    args = ap.parse_args()
+
+    from palu_amd.kernel.abx_rope import abx
+    torch.manual_seed(0)
+    H, D = args.num_heads, args.head_dim
+    G = H // args.group_size
+    R = args.total_rank // G
+    dev, dt = "cuda", torch.float16
+    print(f"Total Rank: {args.total_rank}  Heads: {H}  Head dim: {D}  Group size: {args.group_size}  "
+          f"Groups: {G}  Rank per group: {R}")
+    rows = []
+    for L in args.target_seq_lens:
+        A = torch.randn(H, 1, D, dtype=dt, device=dev)
+        B = torch.randn(H, R, D, dtype=dt, device=dev)
+        X = torch.randn(G, L, R, dtype=dt, device=dev)
+        org_A = torch.randn(H, 1, D, dtype=dt, device=dev)
+        org_X = torch.randn(H, L, D, dtype=dt, device=dev)
+        abx(A, B, X)                                                    # builds the B fragments once
+        ours = do_bench(lambda: abx(A, B, X), flush_mb=args.flush_mb)
+        wx = do_bench(lambda: torch.matmul(org_A, org_X.transpose(-1, -2)), flush_mb=args.flush_mb)
+        nbytes, flops = abx_algorithmic(H, G, L, R, D)
+        row = {"seq_len": L, "ours_us": ours[0], "ours_p20": ours[1], "ours_p80": ours[2], "WX_us": wx[0],
+               "hbm_GBps": nbytes / ours[0] * 1e-3, "hbm_frac": nbytes / ours[0] * 1e-3 / 8000.0,
+               "mfma_TFLOPs": flops / ours[0] * 1e-6, "mfma_frac": flops / ours[0] * 1e-6 / 2500.0}
+        rows.append(row)
+        print(f"L={L:7d}  ours {ours[0]:9.1f} us (p20 {ours[1]:.1f}, p80 {ours[2]:.1f})   WX {wx[0]:9.1f} us   "
+              f"{row['hbm_GBps']:7.0f} GB/s ({100 * row['hbm_frac']:.1f}% of 8 TB/s)   "
+              f"{row['mfma_TFLOPs']:6.0f} TF ({100 * row['mfma_frac']:.1f}% of 2.5 PF)")
+        del X, org_X
+    if args.json:
+        print(json.dumps(rows))
+
+
+if __name__ == "__main__":
+    main()

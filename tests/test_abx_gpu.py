@@ -1,0 +1,151 @@
+"""GPU parity of the HIP abx_rope kernel (through the C ABI) against the CPU oracle and the golden
+vectors generated from the reference.  Criteria: SURVEY.md section 8(c) P1/P2."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle
+from tests.golden import inputs as gi
+
+
+def _abx():
+    from palu_amd.kernel.abx_rope import abx
+    return abx
+
+
+def _check(got, a, b, x, ref16=None, tol=1e-3):
+    """P2: normalised max error vs the fp16 oracle <= 1e-3 and error vs fp64 no worse than 1.5x
+    the oracle's own error vs fp64."""
+    exact = oracle.abx_scores_f64(a, b, x)
+    if ref16 is None:
+        ref16 = oracle.abx_scores(a, b, x)
+    scale = exact.abs().max().item()
+    got = got.detach().cpu()
+    assert got.shape == ref16.shape and got.dtype == torch.float16
+    assert torch.isfinite(got.float()).all()
+    err_vs_oracle = (got.double() - ref16.double()).abs().max().item() / scale
+    err_mine = (got.double() - exact).abs().max().item() / scale
+    err_oracle = (ref16.double() - exact).abs().max().item() / scale
+    assert err_vs_oracle <= tol, (err_vs_oracle, err_mine, err_oracle)
+    assert err_mine <= max(1.5 * err_oracle, 2.0 ** -10), (err_mine, err_oracle)
+    return err_mine, err_oracle
+
+
+@pytest.mark.parametrize("case", gi.ABX_CASES, ids=[c[0] for c in gi.ABX_CASES])
+def test_abx_golden(golden_dir, case):
+    tag, seed, H, D, gs, R, L, regime = case
+    g = np.load(os.path.join(golden_dir, "g1_abx.npz"))
+    a, b, x = gi.abx_inputs(seed, H, D, gs, R, L, regime)
+    assert gi.digest(a, b, x) == str(g[tag + "/digest"])
+    got = _abx()(a.cuda(), b.cuda(), x.cuda())
+    _check(got, a, b, x, ref16=torch.from_numpy(g[tag + "/out"]))
+
+
+@pytest.mark.parametrize("H,gs,R,L", [
+    (32, 4, 128, 1), (32, 4, 128, 31), (32, 4, 128, 127), (32, 4, 128, 128), (32, 4, 128, 129),
+    (32, 4, 128, 4096 + 65), (32, 4, 64, 3000), (32, 4, 32, 5000), (32, 4, 96, 300),
+    (32, 4, 256, 513), (16, 8, 128, 700), (12, 3, 64, 257), (6, 6, 32, 130), (4, 1, 128, 200),
+    (8, 2, 160, 333),
+])
+def test_abx_shapes(H, gs, R, L):
+    rng = np.random.default_rng(H * 1000 + R + L)
+    G = H // gs
+    a = torch.from_numpy(rng.standard_normal((H, 1, 128)).astype(np.float16))
+    b = torch.from_numpy((rng.standard_normal((H, R, 128)) / np.sqrt(R)).astype(np.float16))
+    x = torch.from_numpy(rng.standard_normal((G, L, R)).astype(np.float16))
+    got = _abx()(a.cuda(), b.cuda(), x.cuda())
+    _check(got, a, b, x)
+
+
+def test_abx_strided_inputs_and_cache_view():
+    """a from a transposed view (palu_attention.py:170,216), b non-contiguous, x a [:, :L] view of
+    a pre-allocated cache (stride_g = Lmax*R)."""
+    rng = np.random.default_rng(5)
+    H, G, R, L, Lmax = 32, 8, 128, 777, 1024
+    q = torch.from_numpy(rng.standard_normal((1, 1, H, 128)).astype(np.float16)).cuda()
+    a = q.transpose(1, 2).squeeze(0)                       # [H,1,D] view
+    bfull = torch.from_numpy((rng.standard_normal((H, R, 256)) / 11.3).astype(np.float16)).cuda()
+    b = bfull[:, :, ::2]                                    # stride_d = 2
+    cache = torch.from_numpy(rng.standard_normal((G, Lmax, R)).astype(np.float16)).cuda()
+    x = cache[:, :L]
+    got = _abx()(a, b, x)
+    _check(got, a.cpu().contiguous(), b.cpu().contiguous(), x.cpu().contiguous())
+
+
+def test_abx_pos_offset_equals_shifted_rows():
+    rng = np.random.default_rng(6)
+    H, G, R, L = 32, 8, 64, 384
+    a = torch.from_numpy(rng.standard_normal((H, 1, 128)).astype(np.float16)).cuda()
+    b = torch.from_numpy((rng.standard_normal((H, R, 128)) / 8).astype(np.float16)).cuda()
+    x = torch.from_numpy(rng.standard_normal((G, L, R)).astype(np.float16)).cuda()
+    full = _abx()(a, b, x)
+    part = _abx()(a, b, x[:, 100:].contiguous(), pos_offset=100)
+    assert (full[:, :, 100:].float() - part.float()).abs().max().item() <= 2e-3 * full.float().abs().max().item()
+
+
+def test_abx_long_context_positions():
+    """RoPE angles at positions up to 64k must follow the oracle's fp32-rounded l*inv_freq
+    (pytorch_reference.py:5-6): compare a window at the end of a 65,600-row cache."""
+    rng = np.random.default_rng(7)
+    H, G, R = 32, 8, 32
+    L = 65600
+    a = torch.from_numpy(rng.standard_normal((H, 1, 128)).astype(np.float16))
+    b = torch.from_numpy((rng.standard_normal((H, R, 128)) / np.sqrt(R)).astype(np.float16))
+    x = torch.from_numpy(rng.standard_normal((G, L, R)).astype(np.float16))
+    got = _abx()(a.cuda(), b.cuda(), x.cuda()).cpu()
+    ref = oracle.abx_scores(a, b, x)
+    exact = oracle.abx_scores_f64(a, b, x)
+    scale = exact.abs().max().item()
+    assert (got.double() - ref.double()).abs().max().item() / scale <= 1e-3
+    e_mine = (got.double() - exact).abs().max().item() / scale
+    e_ref = (ref.double() - exact).abs().max().item() / scale
+    assert e_mine <= max(1.5 * e_ref, 2.0 ** -10), (e_mine, e_ref)
+
+
+def test_abx_full_size_c2_properties():
+    """BASELINE config 2 shape (H=32, R=128, L=65536): size-independent properties.
+    (1) linearity in a; (2) tile independence: scores of rows [s, e) computed on the slice with
+    pos_offset equal the full result; (3) oracle check on a strided sample of heads' groups."""
+    torch.manual_seed(0)
+    H, G, R, L = 32, 8, 128, 65536
+    dev = "cuda"
+    a1 = torch.randn(H, 1, 128, dtype=torch.float16, device=dev)
+    a2 = torch.randn(H, 1, 128, dtype=torch.float16, device=dev)
+    b = (torch.randn(H, R, 128, device=dev) / R ** 0.5).half()
+    x = torch.randn(G, L, R, dtype=torch.float16, device=dev)
+    abx = _abx()
+    o1, o2, o12 = abx(a1, b, x), abx(a2, b, x), abx((a1.float() * 0.5 + a2.float() * 0.25).half(), b, x)
+    lin = o1.float() * 0.5 + o2.float() * 0.25
+    assert (lin - o12.float()).abs().max().item() <= 4e-3 * lin.abs().max().item()
+    s, e = 40000, 41000
+    sl = abx(a1, b, x[:, s:e].contiguous(), pos_offset=s)
+    assert (sl.float() - o1[:, :, s:e].float()).abs().max().item() <= 2e-3 * o1.float().abs().max().item()
+    # oracle on one group (4 heads), all 65536 positions
+    g = 5
+    ref = oracle.abx_scores(a1[4 * g:4 * g + 4].cpu(), b[4 * g:4 * g + 4].cpu(), x[g:g + 1].cpu())
+    exact = oracle.abx_scores_f64(a1[4 * g:4 * g + 4].cpu(), b[4 * g:4 * g + 4].cpu(), x[g:g + 1].cpu())
+    got = o1[4 * g:4 * g + 4].cpu()
+    scale = exact.abs().max().item()
+    assert (got.double() - ref.double()).abs().max().item() / scale <= 1e-3
+    assert (got.double() - exact).abs().max().item() <= 1.5 * (ref.double() - exact).abs().max().item() + 1e-3 * scale / 4
+
+
+def test_abx_errors():
+    abx = _abx()
+    a = torch.zeros(32, 1, 128, dtype=torch.float16, device="cuda")
+    b = torch.zeros(32, 128, 128, dtype=torch.float16, device="cuda")
+    x = torch.zeros(8, 64, 128, dtype=torch.float16, device="cuda")
+    with pytest.raises(AssertionError):
+        abx(a[:, 0], b, x)                                   # non-3-D (abx_rope.py:116-118)
+    with pytest.raises(TypeError):
+        abx(a.float(), b.float(), x.float())
+    with pytest.raises(ValueError):
+        abx(a, b, x[:, :, :64])
+    with pytest.raises(RuntimeError):
+        abx(a.cpu(), b.cpu(), x.cpu())
+    out = abx(a, b, x[:, :0])
+    assert out.shape == (32, 1, 0)
