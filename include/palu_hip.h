@@ -58,6 +58,10 @@ int palu_rope_inv_freq_host(float theta, int head_dim, float* out_host);
  * x rows must be 16-byte aligned (sx_g % 8 == 0, sx_l % 8 == 0, innermost stride 1).
  */
 size_t palu_abx_bfrag_bytes(int H, int G, int R);
+/* Numerics switch of the R in {32,64,128} fast path (process-wide, returns the previous value):
+ * 1 (default) folds the query into the B fragments once per launch -- one extra fp16 operand
+ * rounding, same size as the oracle's own rounding of K (abx_rope.py:164); 0 keeps q in fp32. */
+int palu_abx_set_fold(int enable);
 int palu_abx_prepare_b(const void* b, int64_t sb_h, int64_t sb_r, int64_t sb_d,
                        int H, int G, int R, int D, void* bfrag, palu_stream_t stream);
 int palu_abx_rope_f16(const void* a, int64_t sa_h, int64_t sa_d,

@@ -35,6 +35,7 @@ SIGNATURES = {
     "palu_version": (i32, []),
     "palu_rope_inv_freq_host": (i32, [f32, i32, C.POINTER(C.c_float)]),
     "palu_abx_bfrag_bytes": (sz, [i32, i32, i32]),
+    "palu_abx_set_fold": (i32, [i32]),
     "palu_abx_prepare_b": (i32, [vp, i64, i64, i64, i32, i32, i32, i32, vp, vp]),
     "palu_abx_rope_f16": (i32, [vp, i64, i64, vp, vp, i64, i64, vp, i64, i32, i32, i32, i32, i32, vp, i32, vp]),
 }

@@ -23,6 +23,8 @@
 //     pytorch_reference.py:5-6).  cos/sin of the exact product l*inv_freq are carried by a
 //     rotation recurrence (+32 positions per step) and corrected to the fp32-rounded angle by a
 //     second-order expansion in the (exactly computed) rounding residual.
+#include <stdlib.h>
+
 #include "palu_common.h"
 
 namespace {
@@ -30,6 +32,9 @@ namespace {
 constexpr int TL = 128;        // rows (cache positions) per tile
 constexpr int NTHREADS = 512;  // 8 waves
 constexpr int HEAD_DIM = 128;
+#ifndef PALU_ABX_PRIO
+#define PALU_ABX_PRIO 1
+#endif
 
 struct AbxParams {
   const h16* a;
@@ -44,6 +49,9 @@ struct AbxParams {
   int nch;       // workgroups per (group, head-block)
   int nt_total;  // number of 128-row tiles covering L
   int nkc;       // 128-column chunks of R (chunked kernel only)
+  unsigned long long* dbg;  // optional per-wave cycle stamps (timing build only)
+  unsigned out_bytes;       // extent of `out` for the bounds-checked buffer store
+  int prio_mode;            // 0 none, 1 static (waves 4-7), 2 alternating per half tile
 };
 
 // heads per workgroup = 2*NMB; each MFMA M-block carries 2 heads x 8 pairs x {i, i+64}
@@ -96,10 +104,32 @@ struct LdsGeom {
   static __device__ __forceinline__ int swz(int row, int c) { return c ^ ((row >> SH) & MASK); }
 };
 
-constexpr int abx_smem_bytes(int nks) { return 2 * TL * 32 * nks + 2 * 8 * 4 * TL * (int)sizeof(float); }
+
+// sin/cos of the EXACT product l*f (both fp32 values, product exact in fp64): two-term Cody-Waite
+// reduction in fp64 (|n| < 2^24 here), fp32 minimax polynomials on [-pi/4, pi/4] (abs err ~1e-7).
+static __device__ __forceinline__ void sincos_exact_product(float l, float f, float* s, float* c) {
+  const double x = (double)l * (double)f;
+  const double nd = __builtin_rint(x * 0.6366197723675814);
+  double rd = __builtin_fma(-nd, 1.5707963267948966, x);
+  rd = __builtin_fma(-nd, 6.123233995736766e-17, rd);
+  const float r = (float)rd;
+  const float r2 = r * r;
+  float sp = fmaf(r2, fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f);
+  sp = fmaf(r * r2, sp, r);
+  float cp = fmaf(r2, fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f);
+  cp = fmaf(r2 * r2, cp, fmaf(-0.5f, r2, 1.0f));
+  const int q = (int)(long long)nd & 3;
+  const float ss = (q & 1) ? cp : sp;
+  const float cc = (q & 1) ? sp : cp;
+  *s = (q & 2) ? -ss : ss;
+  *c = ((q + 1) & 2) ? -cc : cc;
+}
+
+constexpr int abx_smem_fast(int nks) { return 3 * TL * 32 * nks + 3 * 8 * 4 * TL * (int)sizeof(float); }
+constexpr int abx_smem_bytes(int nks, int nred) { return 2 * TL * 32 * nks + nred * 8 * 4 * TL * (int)sizeof(float); }
 
 template <int NKS, int NMB, bool CHUNKED>
-__global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
+__global__ __launch_bounds__(NTHREADS, 2) void abx_rope_generic_kernel(AbxParams p) {
   using Geo = LdsGeom<NKS>;
   constexpr int HPW = 2 * NMB;
   constexpr int NACC = CHUNKED ? 4 : 1;
@@ -258,8 +288,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
     float* rdst = red + (size_t)(tt & 1) * (8 * 4 * TL) + (size_t)w * (4 * TL) + blk * 32 + n;
 #pragma unroll
     for (int s = 0; s < HPW; ++s) {
-      float v = part[s] + __shfl_xor(part[s], 32, 64);
-      if (hi == 0) rdst[s * TL] = v;
+      // lanes n and n+32 hold complementary pairs: swap halves in-register (no LDS round trip);
+      // both halves then hold the same sum and write the same word (benign duplicate store).
+      unsigned pv = __float_as_uint(part[s]);
+      auto sw = __builtin_amdgcn_permlane32_swap(pv, pv, false, false);
+      rdst[s * TL] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
   };
 
@@ -311,23 +344,335 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
   reduce_store(ntile - 1);
 }
 
-template <int NKS, int NMB, bool CHUNKED>
-int launch_abx(const AbxParams& p, int nwg, hipStream_t stream) {
-  auto kern = abx_rope_kernel<NKS, NMB, CHUNKED>;
-  constexpr int smem = abx_smem_bytes(NKS);
-  static bool attr_done = false;
-  if (!attr_done) {
+
+// ---------------------------------------------------------------------------------------------
+// Fast path: R in {32, 64, 128} (NKS = R/16 k-steps), B fragments register-resident.
+//
+// FOLD: the query is folded into the B fragments once per launch (in registers):
+//   P[r,i] = q_i B[r,i] + q_{i+64} B[r,i+64],  Q[r,i] = q_{i+64} B[r,i] - q_i B[r,i+64]
+// so that the MFMA directly produces U = x.P and V = x.Q and the score is sum_i cos*U + sin*V
+// (2 FMAs per pair and head instead of 6).  P and Q are rounded to fp16 (MFMA operands): one
+// extra operand rounding, the same size as the oracle's own fp16 rounding of K (abx_rope.py:164).
+//
+// Software pipeline: the MFMAs of block b+1 and the RoPE/reduction epilogue of block b are
+// independent instruction streams in one basic block (two accumulator sets), so the matrix pipe
+// and the VALU overlap inside a wave as well as across the two waves of a SIMD.
+template <int NKS, int NMB, bool FOLD, bool TIMING = false>
+__global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
+  using Geo = LdsGeom<NKS>;
+  constexpr int HPW = 2 * NMB;
+  constexpr int NRING = 3;                // X tiles resident in LDS
+  constexpr int RED_STRIDE = 8 * 4 * TL;  // floats per red buffer: [8 waves][4 slots][TL]
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem + NRING * Geo::TILE_BYTES);  // [3][8][4][TL]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 31, hi = lane >> 5;
+  int stamp_i = 0;
+  auto stamp = [&]() {
+    if (TIMING) {
+      unsigned long long t = __builtin_readcyclecounter();
+      if (lane == 0 && stamp_i < 64) p.dbg[((size_t)blockIdx.x * 8 + w) * 64 + stamp_i] = t;
+      ++stamp_i;
+    }
+  };
+  stamp();
+
+  const int ngb = p.G * p.HB;
+  const int gb = blockIdx.x % ngb;
+  const int cidx = blockIdx.x / ngb;
+  const int g = gb / p.HB, hb = gb % p.HB;
+
+  const int base = p.nt_total / p.nch, rem = p.nt_total % p.nch;
+  const int tile0 = cidx * base + min(cidx, rem);
+  const int ntile = base + (cidx < rem ? 1 : 0);
+  if (ntile <= 0) return;
+
+  const h16* xg = p.x + (int64_t)g * p.sx_g;
+
+  // ---- staging by LDS-DMA (global_load_lds_dwordx4): wave w, piece k fills the 64 consecutive 16-byte
+  //      LDS slots [512k + 64w, +64) of a tile; the XOR swizzle is applied to the per-lane SOURCE
+  //      address (the DMA destination is lane-linear).  Hidden from the compiler (inline asm), so the
+  //      completion wait is ours: s_waitcnt vmcnt(0) before the barrier that publishes the tile.
+  auto dma_tile = [&](int tt, int slot) {
+    const int row0 = (tile0 + tt) * TL;
+#pragma unroll
+    for (int k = 0; k < Geo::SPT; ++k) {
+      const int s = tid + NTHREADS * k;
+      const int row = s / Geo::CPR, pp = s % Geo::CPR;
+      const int l = min(row0 + row, p.L - 1);
+      const h16* src = xg + (int64_t)l * p.sx_l + Geo::swz(row, pp) * 8;
+      const unsigned dst = (unsigned)(slot * Geo::TILE_BYTES + (NTHREADS * k + 64 * w) * 16);
+      unsigned keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %2\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %1, off\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(src), "s"(dst)
+          : "memory");
+    }
+  };
+  auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+  dma_tile(0, 0);
+  dma_tile(min(1, ntile - 1), 1);
+
+  // ---- B fragments (issued early; consumed by the fold / first MFMA)
+  const u32x4* bf_base = p.bfrag + ((int64_t)(gb * 8 + w) * NMB) * NKS * 64 + lane;
+  h16x8 bf[NMB][NKS];
+#pragma unroll
+  for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      u32x4 v = bf_base[(int64_t)(mb * NKS + ks) * 64];
+      bf[mb][ks] = *reinterpret_cast<h16x8*>(&v);
+    }
+
+  stamp();  // 1: B loads issued
+  // ---- RoPE state of this lane (C layout: position n, pairs i = 8w + 2j + hi), started one block
+  //      early because the pipeline runs one (discarded) epilogue before the first real block.
+  float fr[4], rc[4], rs[4], cs[4], sn[4];
+  float lf = (float)(p.pos0 + tile0 * TL + n - 32);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    fr[j] = p.inv_freq[8 * w + 2 * j + hi];
+    sincos_exact_product(lf, fr[j], &sn[j], &cs[j]);
+    sincos_exact_product(32.0f, fr[j], &rs[j], &rc[j]);
+  }
+
+  stamp();  // 2: rope init done
+  // ---- query: either folded into the fragments (FOLD) or kept per (pair, head) for the epilogue
+  float q1[FOLD ? 1 : HPW][4], q2[FOLD ? 1 : HPW][4];
+  if (FOLD) {
+    // A-fragment lane = row m of the M-block: u = m&1, t = (m>>1)&1, pair = m>>2.
+    //   row u=0 (B[:,i])    <- P = q_i B[:,i] + q_{i+64} B[:,i+64]
+    //   row u=1 (B[:,i+64]) <- Q = q_{i+64} B[:,i] - q_i B[:,i+64]
+    // i.e. new = c_own*own + q_{i+64}*partner with c_own = +/-q_i; partner row = lane^1 (DPP).
+    // v_dot2_f32_f16: both products exact in fp32, one rounding to fp16 at the end.
+    const int m = lane & 31;
+    const int u = m & 1, t = (m >> 1) & 1, pair = m >> 2;
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+      int hloc = hb * HPW + 2 * mb + t;
+      bool valid = hloc < p.gs;
+      int h = g * p.gs + (valid ? hloc : 0);
+      int i = 8 * w + pair;
+      h16 qi = valid ? p.a[h * p.sa_h + i * p.sa_d] : (h16)0.f;
+      h16 qj = valid ? p.a[h * p.sa_h + (i + 64) * p.sa_d] : (h16)0.f;
+      h16x2 coef;
+      coef[0] = u ? -qi : qi;
+      coef[1] = qj;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        u32x4 own = __builtin_bit_cast(u32x4, bf[mb][ks]);
+        u32x4 res;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          unsigned ow = own[e];
+          unsigned par = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ow, 0xB1, 0xF, 0xF, false);  // lane^1
+          unsigned lo2 = __builtin_amdgcn_perm(par, ow, 0x05040100u);  // (own.lo, par.lo)
+          unsigned hi2 = __builtin_amdgcn_perm(par, ow, 0x07060302u);  // (own.hi, par.hi)
+          float r0 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, lo2), coef, 0.f, false);
+          float r1 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, hi2), coef, 0.f, false);
+          h16x2 r2;
+          r2[0] = (h16)r0;
+          r2[1] = (h16)r1;
+          res[e] = __builtin_bit_cast(unsigned, r2);
+        }
+        bf[mb][ks] = __builtin_bit_cast(h16x8, res);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < HPW; ++s) {
+      int hloc = hb * HPW + s;
+      bool valid = hloc < p.gs;
+      int h = g * p.gs + (valid ? hloc : 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int i = 8 * w + 2 * j + hi;
+        float v1 = (float)p.a[h * p.sa_h + i * p.sa_d];
+        float v2 = (float)p.a[h * p.sa_h + (i + 64) * p.sa_d];
+        q1[s][j] = valid ? v1 : 0.f;
+        q2[s][j] = valid ? v2 : 0.f;
+      }
+    }
+  }
+
+  // scores leave through a buffer store: invalid (row >= L, padded head, pipeline warm-up) lanes get an
+  // out-of-range offset that the hardware drops, so the store needs no branch inside the MFMA stream
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+
+  auto reduce_store = [&](int tt) {
+    const int slot = tid >> 7, pos = tid & 127;
+    const float* r = red + (size_t)((tt + 3) % 3) * RED_STRIDE + (slot & 3) * TL + pos;
+    float s = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 8; ++ww) s += r[ww * 4 * TL];
+    const int l = (tile0 + tt) * TL + pos;
+    const int hloc = hb * HPW + slot;
+    const bool ok = tt >= 0 && slot < HPW && l < p.L && hloc < p.gs;
+    const unsigned off = ok ? (unsigned)(((int64_t)(g * p.gs + hloc) * p.so_h + l) * 2) : 0xFFFFFFF0u;
+    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (h16)s), orsrc, off, 0, 0);
+  };
+
+  // X fragments are prefetched XD k-steps ahead through a ring of XD registers-sets: the fragment of
+  // k-step ks lives in xf[ks % XD] and is refilled with the fragment XD k-steps later (possibly of the
+  // next block) right after its MFMAs have issued -> LDS latency never sits in front of an MFMA.
+  constexpr int XD = NKS < 4 ? NKS : 4;
+  h16x8 xf[XD];
+  auto read_frag = [&](const char* xs, int blk, int ks) {
+    const int row = blk * 32 + n;
+    return *reinterpret_cast<const h16x8*>(xs + row * Geo::RB + Geo::swz(row, 2 * ks + hi) * 16);
+  };
+  auto load_xf = [&](const char* xs, int blk) {
+#pragma unroll
+    for (int ks = 0; ks < XD; ++ks) xf[ks] = read_frag(xs, blk, ks);
+  };
+  // MFMAs of one 32-row block (this tile `xs`, block `blk`); (nxs, nblk) = the block that follows
+  auto mfma_block = [&](f32x16 (&ac)[NMB], const char* xs, int blk, const char* nxs, int nblk) {
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) ac[mb][e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb)
+        ac[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[mb][ks], xf[ks % XD], ac[mb], 0, 0, 0);
+      xf[ks % XD] = (ks + XD < NKS) ? read_frag(xs, blk, ks + XD) : read_frag(nxs, nblk, ks + XD - NKS);
+    }
+  };
+
+  auto epilogue = [&](int tt, int blk, const f32x16 (&ac)[NMB]) {
+    float part[HPW];
+#pragma unroll
+    for (int s = 0; s < HPW; ++s) part[s] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // cos/sin at the oracle's fp32-rounded angle ang = fl(l*f): exact angle = ang + lo, |lo| <= ulp(ang)/2
+      // (first order in lo; the dropped term lo^2/2 is < 3.1e-5 for positions < 2^18)
+      float ang = lf * fr[j];
+      float lo = fmaf(lf, fr[j], -ang);
+      float cc = fmaf(lo, sn[j], cs[j]);
+      float ss = fmaf(-lo, cs[j], sn[j]);
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          float k1 = ac[mb][4 * j + 2 * t], k2 = ac[mb][4 * j + 2 * t + 1];
+          int s = 2 * mb + t;
+          if (FOLD) {
+            part[s] = fmaf(cc, k1, fmaf(ss, k2, part[s]));
+          } else {
+            float t1 = fmaf(q2[s][j], k2, q1[s][j] * k1);
+            float t2 = fmaf(-q1[s][j], k2, q2[s][j] * k1);
+            part[s] = fmaf(cc, t1, fmaf(ss, t2, part[s]));
+          }
+        }
+      float c2 = fmaf(-sn[j], rs[j], cs[j] * rc[j]);  // advance the exact-angle state by 32 positions
+      float s2 = fmaf(cs[j], rs[j], sn[j] * rc[j]);
+      cs[j] = c2;
+      sn[j] = s2;
+    }
+    lf += 32.0f;
+    float* rdst = red + (size_t)((tt + 3) % 3) * RED_STRIDE + (size_t)w * (4 * TL) + blk * 32 + n;
+#pragma unroll
+    for (int s = 0; s < HPW; ++s) {
+      // lanes n and n+32 hold complementary pairs: swap halves in-register; both halves then hold
+      // the same sum and write the same word (benign duplicate store, keeps the block branch-free)
+      unsigned pv = __float_as_uint(part[s]);
+      auto sw = __builtin_amdgcn_permlane32_swap(pv, pv, false, false);
+      rdst[s * TL] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+  };
+
+  f32x16 accA[NMB], accB[NMB];
+#pragma unroll
+  for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accB[mb][e] = 0.f;
+
+  stamp();  // 3: fold done
+
+  // the second-dispatched half of the workgroup loses issue arbitration on every segment
+  // (priority, then age): give it static priority so both waves of a SIMD finish together
+  const bool young = w >= 4;
+  if (p.prio_mode == 1 && young) __builtin_amdgcn_s_setprio(1);
+
+  dma_wait();
+  stamp();  // 4: first tiles landed
+  __syncthreads();
+  load_xf(smem, 0);
+
+  for (int tt = 0; tt < ntile; ++tt) {
+    stamp();  // 5+2*tt: arrive at barrier
+    if (tt > 0) {
+      dma_wait();  // this wave's pieces of tile tt+1 have landed -> published by the barrier
+      __syncthreads();
+    }
+    stamp();  // 6+2*tt: leave barrier
+    if (p.prio_mode == 2 && young) __builtin_amdgcn_s_setprio(1);  // young half leads the first half tile
+    // one straight-line region per tile: MFMAs of block b+1, RoPE epilogue of block b, staging of tile
+    // tt+2 into the ring, prefetch of tile tt+3, cross-wave reduction + store of tile tt-2
+    const char* xs = smem + (tt % NRING) * Geo::TILE_BYTES;
+    const char* xn = smem + ((tt + 1) % NRING) * Geo::TILE_BYTES;
+    mfma_block(accA, xs, 0, xs, 1);
+    dma_tile(min(tt + 2, ntile - 1), (tt + 2) % NRING);
+    epilogue(tt - 1, 3, accB);  // tt == 0: discarded (writes a slot that is rewritten before use)
+    __builtin_amdgcn_sched_barrier(0);  // keep each {MFMA block b+1, epilogue b} pair its own scheduling region
+    mfma_block(accB, xs, 1, xs, 2);
+    reduce_store(tt - 2);
+    epilogue(tt, 0, accA);
+    __builtin_amdgcn_sched_barrier(0);
+    if (p.prio_mode == 2 && young) __builtin_amdgcn_s_setprio(0);  // ... the old half catches up in the second
+    mfma_block(accA, xs, 2, xs, 3);
+    epilogue(tt, 1, accB);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block(accB, xs, 3, xn, 0);  // prefetches block 0 of the next tile (staged one barrier ago)
+    epilogue(tt, 2, accA);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  epilogue(ntile - 1, 3, accB);
+  stamp();
+  dma_wait();
+  __syncthreads();
+  reduce_store(ntile - 2);
+  reduce_store(ntile - 1);
+  stamp();
+}
+
+template <typename K>
+int launch_kernel(K kern, int smem, bool* attr_done, const AbxParams& p, int nwg, hipStream_t stream) {
+  if (!*attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) {
       palu_set_error("hipFuncSetAttribute(%d B LDS) failed: %s", smem, hipGetErrorString(e));
       return PALU_ERR_LAUNCH;
     }
-    attr_done = true;
+    *attr_done = true;
   }
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), smem, stream, p);
   PALU_LAUNCH_CHECK();
   return PALU_OK;
+}
+
+template <int NKS, int NMB, bool FOLD>
+int launch_abx_fast(const AbxParams& p, int nwg, hipStream_t stream) {
+  static bool attr_done = false;
+  return launch_kernel(abx_rope_kernel<NKS, NMB, FOLD>, abx_smem_fast(NKS), &attr_done, p, nwg, stream);
+}
+
+template <int NMB>
+int launch_abx_generic(const AbxParams& p, int nwg, hipStream_t stream) {
+  static bool attr_done = false;
+  return launch_kernel(abx_rope_generic_kernel<8, NMB, true>, abx_smem_bytes(8, 2), &attr_done, p, nwg, stream);
 }
 
 struct AbxPlan {
@@ -348,6 +693,17 @@ bool abx_plan(int H, int G, int R, AbxPlan* pl) {
 }
 
 }  // namespace
+
+static int g_abx_fold = 1;
+static int abx_prio_mode() {
+  static int m = -1;
+  if (m < 0) {
+    const char* e = getenv("PALU_ABX_PRIO_MODE");
+    m = e ? atoi(e) : 2;
+  }
+  return m;
+}
+extern "C" int palu_abx_set_fold(int enable) { int o = g_abx_fold; g_abx_fold = enable ? 1 : 0; return o; }
 
 extern "C" size_t palu_abx_bfrag_bytes(int H, int G, int R) {
   AbxPlan pl;
@@ -394,6 +750,13 @@ extern "C" int palu_abx_rope_f16(const void* a, int64_t sa_h, int64_t sa_d, cons
   p.H = H; p.G = G; p.gs = pl.gs; p.HB = pl.hb; p.L = L; p.R = R; p.pos0 = pos0;
   p.nt_total = (L + TL - 1) / TL;
   p.nkc = pl.nkc;
+  p.dbg = nullptr;
+  p.prio_mode = abx_prio_mode();
+  {
+    int64_t ob = ((int64_t)(H - 1) * so_h + L) * 2;
+    PALU_REQUIRE(ob > 0 && ob < 0xFFFFFFF0ll, PALU_ERR_UNSUPPORTED, "abx: out extent must be < 4 GiB");
+    p.out_bytes = (unsigned)ob;
+  }
   int ngb = G * pl.hb;
   int target = palu_num_cus();               // one 8-wave workgroup per CU
   int nch = target / ngb;
@@ -402,12 +765,47 @@ extern "C" int palu_abx_rope_f16(const void* a, int64_t sa_h, int64_t sa_d, cons
   p.nch = nch;
   int nwg = nch * ngb;
   hipStream_t s = (hipStream_t)stream;
-  if (pl.chunked) {
-    return pl.nmb == 2 ? launch_abx<8, 2, true>(p, nwg, s) : launch_abx<8, 1, true>(p, nwg, s);
-  }
+  const bool fold = g_abx_fold != 0;
+  if (pl.chunked) return pl.nmb == 2 ? launch_abx_generic<2>(p, nwg, s) : launch_abx_generic<1>(p, nwg, s);
+#define PALU_ABX_DISPATCH(NKS)                                                                       \
+  (fold ? (pl.nmb == 2 ? launch_abx_fast<NKS, 2, true>(p, nwg, s) : launch_abx_fast<NKS, 1, true>(p, nwg, s)) \
+        : (pl.nmb == 2 ? launch_abx_fast<NKS, 2, false>(p, nwg, s) : launch_abx_fast<NKS, 1, false>(p, nwg, s)))
   switch (R) {
-    case 32: return pl.nmb == 2 ? launch_abx<2, 2, false>(p, nwg, s) : launch_abx<2, 1, false>(p, nwg, s);
-    case 64: return pl.nmb == 2 ? launch_abx<4, 2, false>(p, nwg, s) : launch_abx<4, 1, false>(p, nwg, s);
-    default: return pl.nmb == 2 ? launch_abx<8, 2, false>(p, nwg, s) : launch_abx<8, 1, false>(p, nwg, s);
+    case 32: return PALU_ABX_DISPATCH(2);
+    case 64: return PALU_ABX_DISPATCH(4);
+    default: return PALU_ABX_DISPATCH(8);
   }
+#undef PALU_ABX_DISPATCH
+}
+
+// Debug/profiling entry (not part of the stable ABI): C2-class shapes only (R = 128, gs >= 3).
+// dbg: [nwg][8 waves][64] cycle stamps (s_memtime), see the stamp() calls in abx_rope_kernel.
+extern "C" int palu_abx_rope_f16_timed(const void* a, int64_t sa_h, int64_t sa_d, const void* bfrag, const void* x,
+                                       int64_t sx_g, int64_t sx_l, void* out, int64_t so_h, int H, int G, int L,
+                                       int R, const float* inv_freq, int pos0, unsigned long long* dbg,
+                                       int* nwg_out, palu_stream_t stream) {
+  AbxPlan pl;
+  PALU_REQUIRE(abx_plan(H, G, R, &pl) && R == 128 && pl.nmb == 2 && L > 0 && dbg, PALU_ERR_UNSUPPORTED,
+               "abx timed: needs R=128, gs>=3");
+  AbxParams p;
+  p.a = (const h16*)a; p.sa_h = sa_h; p.sa_d = sa_d;
+  p.bfrag = (const u32x4*)bfrag;
+  p.x = (const h16*)x; p.sx_g = sx_g; p.sx_l = sx_l;
+  p.out = (h16*)out; p.so_h = so_h;
+  p.inv_freq = inv_freq;
+  p.H = H; p.G = G; p.gs = pl.gs; p.HB = pl.hb; p.L = L; p.R = R; p.pos0 = pos0;
+  p.nt_total = (L + TL - 1) / TL;
+  p.nkc = 1;
+  p.dbg = dbg;
+  p.prio_mode = abx_prio_mode();
+  p.out_bytes = (unsigned)(((int64_t)(H - 1) * so_h + L) * 2);
+  int ngb = G * pl.hb;
+  int nch = palu_num_cus() / ngb;
+  if (nch < 1) nch = 1;
+  if (nch > p.nt_total) nch = p.nt_total;
+  p.nch = nch;
+  int nwg = nch * ngb;
+  if (nwg_out) *nwg_out = nwg;
+  static bool attr_done = false;
+  return launch_kernel(abx_rope_kernel<8, 2, true, true>, abx_smem_fast(8), &attr_done, p, nwg, (hipStream_t)stream);
 }

@@ -32,6 +32,12 @@ def rope_inv_freq(device, head_dim: int = 128, theta: float = 10000.0) -> torch.
     return t
 
 
+def set_fold(enable: bool) -> bool:
+    """Numerics switch of the fast path (palu_abx_set_fold): True (default) folds q into the B
+    fragments (one extra fp16 operand rounding, fewer VALU ops); False keeps q in fp32."""
+    return bool(_lib.lib.palu_abx_set_fold(1 if enable else 0))
+
+
 def prepare_b(b: torch.Tensor, num_groups: int) -> torch.Tensor:
     """Lay the weight B [H,R,D] out as MFMA A-operand fragments (palu_abx_prepare_b).  Cached per
     tensor object + version, because B is a weight (nn.Parameter at kernel/palu_attention.py:114)."""

@@ -14,12 +14,16 @@ import torch
 
 
 def do_bench(fn, warmup=25, rep=100, flush_mb=0):
-    """hipEvent timing of `fn` on the current stream; returns (median, p20, p80) in us."""
+    """hipEvent timing of `fn` on the current stream; returns (median, p20, p80) in us.
+
+    Like triton.testing.do_bench (kernel/abx_rope.py:198-223) each rep is bracketed by its own event
+    pair; the reps are enqueued back to back (no host sync in between) so that the events measure
+    device time, not the Python launch latency of an idle stream."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
     flush = torch.empty(flush_mb * 1024 * 1024, dtype=torch.uint8, device="cuda") if flush_mb else None
-    times = []
+    evs = []
     for _ in range(rep):
         if flush is not None:
             flush.zero_()                     # evict L2 / Infinity Cache between reps
@@ -27,10 +31,24 @@ def do_bench(fn, warmup=25, rep=100, flush_mb=0):
         s.record()
         fn()
         e.record()
-        e.synchronize()
-        times.append(s.elapsed_time(e) * 1e3)
-    t = torch.tensor(times)
+        evs.append((s, e))
+    torch.cuda.synchronize()
+    t = torch.tensor([s.elapsed_time(e) * 1e3 for s, e in evs])
     return t.median().item(), t.quantile(0.2).item(), t.quantile(0.8).item()
+
+
+def do_bench_total(fn, warmup=25, rep=100):
+    """One event pair around `rep` back-to-back calls (run_latency_attention.py:97-106 style): us/call."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(rep):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e3 / rep
 
 
 def abx_algorithmic(H, G, L, R, D=128):
@@ -47,10 +65,12 @@ def main():
     ap.add_argument("--group_size", type=int, default=4)
     ap.add_argument("--target_seq_lens", nargs="+", type=int, default=[4096, 16384, 65536, 262144])
     ap.add_argument("--flush_mb", type=int, default=0, help="write this many MiB between reps to defeat the 256 MiB Infinity Cache")
+    ap.add_argument("--no_fold", action="store_true", help="keep q in fp32 instead of folding it into B (slower, exact)")
     ap.add_argument("--json", action="store_true")
     args = ap.parse_args()
 
-    from palu_amd.kernel.abx_rope import abx
+    from palu_amd.kernel.abx_rope import abx, set_fold
+    set_fold(not args.no_fold)
     torch.manual_seed(0)
     H, D = args.num_heads, args.head_dim
     G = H // args.group_size
@@ -66,14 +86,17 @@ def main():
         org_A = torch.randn(H, 1, D, dtype=dt, device=dev)
         org_X = torch.randn(H, L, D, dtype=dt, device=dev)
         abx(A, B, X)                                                    # builds the B fragments once
-        ours = do_bench(lambda: abx(A, B, X), flush_mb=args.flush_mb)
+        out_buf = torch.empty(H, 1, L, dtype=dt, device=dev)
+        ours = do_bench(lambda: abx(A, B, X, out=out_buf), flush_mb=args.flush_mb)
+        ours_total = do_bench_total(lambda: abx(A, B, X, out=out_buf))
         wx = do_bench(lambda: torch.matmul(org_A, org_X.transpose(-1, -2)), flush_mb=args.flush_mb)
         nbytes, flops = abx_algorithmic(H, G, L, R, D)
         row = {"seq_len": L, "ours_us": ours[0], "ours_p20": ours[1], "ours_p80": ours[2], "WX_us": wx[0],
                "hbm_GBps": nbytes / ours[0] * 1e-3, "hbm_frac": nbytes / ours[0] * 1e-3 / 8000.0,
                "mfma_TFLOPs": flops / ours[0] * 1e-6, "mfma_frac": flops / ours[0] * 1e-6 / 2500.0}
         rows.append(row)
-        print(f"L={L:7d}  ours {ours[0]:9.1f} us (p20 {ours[1]:.1f}, p80 {ours[2]:.1f})   WX {wx[0]:9.1f} us   "
+        row["ours_back_to_back_us"] = ours_total
+        print(f"L={L:7d}  ours {ours[0]:9.1f} us (p20 {ours[1]:.1f}, p80 {ours[2]:.1f}; {ours_total:.1f} us/call back-to-back)   WX {wx[0]:9.1f} us   "
               f"{row['hbm_GBps']:7.0f} GB/s ({100 * row['hbm_frac']:.1f}% of 8 TB/s)   "
               f"{row['mfma_TFLOPs']:6.0f} TF ({100 * row['mfma_frac']:.1f}% of 2.5 PF)")
         del X, org_X
