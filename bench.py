@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Headline benchmark: one low-rank-KV attention decode step on MI355X (BASELINE.json configs[1]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Workload ("step" = one pass of the hot path over one token): Llama-2-7B attention geometry as built by
+the reference harness (run_latency_attention.py:40-55: hidden 4096, 32 heads x 128, theta 1e4), Palu
+rank_k=1024, rank_v=3072, group_size=4 (G=8 latent groups), fp16 latent KV cache of prompt_len=65536
+positions, batch 1; synthetic randn latents / token and random-init weights (no checkpoints offline),
+all resident in HBM before the timed region.  One step = qkv GEMV + q-RoPE + in-place cache append ->
+fused reconstruct-K/RoPE/q.K^T (abx) -> softmax + latent P.V -> o_proj GEMV, i.e. the decode branch of
+kernel/palu_attention.py:147-263 through the C ABI (palu_decode_step_f16).
+
+N > 1: head-group parallel (strong scaling of the same step): rank r owns G/N groups, one RCCL
+all-gather of the [H/N*Rv] fp16 context slice per step, replicated o_proj.
+
+Prints ONE JSON line (rank 0).  `value` = decode-step microseconds (lower is better); `roofline` is the
+dominant kernel of the step by measured time, `roofline_abx` the fused score kernel the north star
+targets (both HBM fraction from algorithmic bytes and MFMA fraction from algorithmic flops);
+`cpu_baseline` = the CPU oracle (a port of the reference's PyTorch path) timed on this host's cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
+MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16 MFMA (no sparsity)
+
+H, D, GS, HIDDEN = 32, 128, 4, 4096
+G = H // GS
+
+
+def algorithmic(rank_k, rank_v, L):
+    """SURVEY.md 8(d) per-launch algorithmic bytes / flops (L = cached positions incl. the new token)."""
+    Rk, Rv = rank_k // G, rank_v // G
+    abx_b = 2 * G * L * Rk + 2 * H * Rk * D + 2 * H * D + 2 * H * L
+    abx_f = 2 * H * L * Rk * D + 5 * H * L * D
+    pv_b = 2 * G * L * Rv + 2 * H * L + 2 * H * Rv
+    pv_f = 2 * H * L * Rv
+    qkv_b = 2 * HIDDEN * (H * D + rank_k + rank_v) + 2 * HIDDEN
+    o_b = 2 * HIDDEN * H * Rv + 2 * H * Rv
+    return {"abx": (abx_b, abx_f), "softmax_pv": (pv_b, pv_f), "qkv": (qkv_b, 2 * HIDDEN * (H * D + rank_k + rank_v)),
+            "o_proj": (o_b, 2 * HIDDEN * H * Rv), "step": (abx_b + pv_b + qkv_b + o_b, abx_f + pv_f)}
+
+
+def time_loop(fn, steps, warmup, sync):
+    for _ in range(warmup):
+        fn()
+    sync()
+    t0 = time.perf_counter()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(steps):
+        fn()
+    ev1.record()
+    sync()
+    wall = (time.perf_counter() - t0) * 1e3
+    return wall, ev0.elapsed_time(ev1)      # (host wall between the two syncs, device event time), ms over `steps`
+
+
+def cpu_baseline(rank_k, rank_v, L, reps=1):
+    """The CPU oracle's decode step (port of the reference's PyTorch path) at the SAME shapes on this host."""
+    import oracle
+    torch.manual_seed(0)
+    Rk, Rv = rank_k // G, rank_v // G
+    w = {"wq": torch.randn(H * D, HIDDEN).mul_(1 / 64).half(), "vt_k": torch.randn(rank_k, HIDDEN).mul_(1 / 64).half(),
+         "vt_v": torch.randn(rank_v, HIDDEN).mul_(1 / 64).half(), "b": torch.randn(H, Rk, D).mul_(Rk ** -0.5).half(),
+         "wo": torch.randn(HIDDEN, H * Rv).mul_(0.01).half()}
+    k = torch.randn(G, L - 1, Rk).half()
+    v = torch.randn(G, L - 1, Rv).half()
+    tok = torch.randn(HIDDEN).half()
+    times = []
+    with torch.no_grad():
+        for i in range(reps + 1):
+            t0 = time.perf_counter()
+            oracle.decode_step(tok, L - 1, w, k, v)
+            times.append(time.perf_counter() - t0)
+    return min(times[1:]) * 1e6
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=25)
+    ap.add_argument("--rank_k", type=int, default=1024)
+    ap.add_argument("--rank_v", type=int, default=3072)
+    ap.add_argument("--prompt_len", type=int, default=65536)
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--cpu_sample_len", type=int, default=0, help="positions used for the CPU baseline (0 = full)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from palu_amd import _lib
+    from palu_amd.kernel import head_parallel as hp
+    from palu_amd.kernel.abx_rope import prepare_b, rope_inv_freq
+
+    rank_k, rank_v, Lp = args.rank_k, args.rank_v, args.prompt_len
+    Rk, Rv = rank_k // G, rank_v // G
+    L = Lp + 1
+    cap = (Lp + 64 + 63) // 64 * 64
+    torch.manual_seed(1234)
+    plan = hp.make_plan(world, rank, H, G, D, Rk, Rv)
+    full = {"wq": (torch.randn(H * D, HIDDEN, device=dev) / 64).half(),
+            "vt_k": (torch.randn(rank_k, HIDDEN, device=dev) / 64).half(),
+            "vt_v": (torch.randn(rank_v, HIDDEN, device=dev) / 64).half(),
+            "b": (torch.randn(H, Rk, D, device=dev) * Rk ** -0.5).half(),
+            "wo": (torch.randn(HIDDEN, H * Rv, device=dev) * 0.01).half()}
+    w = {k: v.contiguous() for k, v in hp.shard_weights(plan, full).items()}
+    del full
+    Gl = plan.groups_local
+    k_cache = torch.randn(Gl, cap, Rk, device=dev, dtype=torch.float16)       # run_latency_attention.py:62-63
+    v_cache = torch.randn(Gl, cap, Rv, device=dev, dtype=torch.float16)
+    hidden = torch.randn(HIDDEN, device=dev, dtype=torch.float16)             # :70
+    dec = hp.HeadParallelDecoder(plan, w, k_cache, v_cache, HIDDEN)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step():
+        dec.step(hidden, Lp, Lp)
+
+    sync()
+    ms, ev_ms = time_loop(step, args.steps, args.warmup, sync)
+    t = torch.tensor([ms], device=dev)
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ms = float(t.item())
+    us_step = ms * 1e3 / args.steps
+
+    rec = None
+    if rank == 0:
+        alg = algorithmic(rank_k, rank_v, L)
+        kern = {}
+        if world == 1:
+            # per-kernel durations, each kernel in its own back-to-back loop between HIP events on the
+            # stream the kernels are launched on (torch's current stream)
+            lib, s = _lib.lib, _lib.current_stream
+            Hl = H
+            inv = dec.inv
+
+            def k_qkv():
+                _lib.check(lib.palu_decode_qkv_f16(w["wq"].data_ptr(), w["wq"].stride(0), w["vt_k"].data_ptr(),
+                                                   w["vt_k"].stride(0), w["vt_v"].data_ptr(), w["vt_v"].stride(0),
+                                                   hidden.data_ptr(), dec.q.data_ptr(), k_cache.data_ptr(),
+                                                   k_cache.stride(0), k_cache.stride(1), v_cache.data_ptr(),
+                                                   v_cache.stride(0), v_cache.stride(1), inv.data_ptr(), Hl, D, HIDDEN,
+                                                   G, Rk, Rv, Lp, Lp, s()), "qkv")
+
+            def k_abx():
+                _lib.check(lib.palu_abx_rope_f16(dec.q.data_ptr(), D, 1, dec.frag.data_ptr(), k_cache.data_ptr(),
+                                                 k_cache.stride(0), k_cache.stride(1), dec.scores.data_ptr(),
+                                                 dec.scores.stride(0), Hl, G, L, Rk, D, inv.data_ptr(), 0, s()), "abx")
+
+            def k_pv():
+                _lib.check(lib.palu_softmax_pv_f16(dec.scores.data_ptr(), dec.scores.stride(0), 0, v_cache.data_ptr(),
+                                                   v_cache.stride(0), v_cache.stride(1), dec.ctx.data_ptr(), 0, 0,
+                                                   dec.pvws.data_ptr(), Hl, G, L, Rv, math.sqrt(D), s()), "pv")
+
+            def k_o():
+                _lib.check(lib.palu_gemv_f16(w["wo"].data_ptr(), w["wo"].stride(0), dec.ctx.data_ptr(),
+                                             dec.out.data_ptr(), HIDDEN, H * Rv, s()), "o")
+            n = max(20, min(args.steps, 200))
+            for name, fn in (("qkv", k_qkv), ("abx", k_abx), ("softmax_pv", k_pv), ("o_proj", k_o)):
+                _, kms = time_loop(fn, n, 10, torch.cuda.synchronize)
+                us = kms * 1e3 / n
+                b, f = alg[name]
+                kern[name] = {"us": round(us, 2), "algorithmic_bytes": b, "hbm_GBps": round(b / us * 1e-3, 1),
+                              "hbm_frac": round(b / us * 1e-3 / HBM_PEAK_GBPS, 4),
+                              "tflops": round(f / us * 1e-6, 1)}
+        step_b, _ = alg["step"]
+        rec = {
+            "metric": "decode-step us + achieved HBM GB/s, rank_k=%d prompt_len=%dk (Llama-2-7B attention geometry "
+                      "as built by run_latency_attention.py)" % (rank_k, Lp // 1024),
+            "value": round(us_step, 2), "unit": "us", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(us_step * 1e-3, 5), "higher_is_better": False,
+            "scaling": "strong" if world > 1 else "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "Palu low-rank KV attention decode step (kernel/palu_attention.py decode branch): "
+                                   "H=32 D=128 hidden=4096 gs=4 G=8 rank_k=%d rank_v=%d prompt_len=%d fp16 latents batch=1"
+                                   % (rank_k, rank_v, Lp),
+                       "parallelism": "head-group x%d + RCCL all-gather" % world if world > 1 else "single GPU",
+                       "kernels_per_step": 5 if world == 1 else 6},
+            "step_algorithmic_bytes": step_b,
+            "step_hbm_GBps": round(step_b / us_step * 1e-3, 1),
+            "step_hbm_frac": round(step_b / us_step * 1e-3 / HBM_PEAK_GBPS, 4),
+        }
+        if kern:
+            dom = max(("abx", "softmax_pv"), key=lambda k_: kern[k_]["us"])
+            b, f = alg[dom]
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "traffic.json")        # PMC-derived HBM bytes per launch (committed)
+            if os.path.exists(tf):
+                traffic = json.load(open(tf)).get(dom)
+            rec["kernels"] = kern
+            rec["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["hbm_GBps"], "peak": HBM_PEAK_GBPS,
+                               "unit": "GB/s", "frac": kern[dom]["hbm_frac"], "traffic": traffic}
+            ab, af = alg["abx"]
+            rec["roofline_abx"] = {"kernel": "abx_rope", "bound": "mfma", "achieved": kern["abx"]["tflops"],
+                                   "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": round(kern["abx"]["tflops"] / MFMA_PEAK_TFLOPS, 4),
+                                   "hbm_achieved_GBps": kern["abx"]["hbm_GBps"], "hbm_frac": kern["abx"]["hbm_frac"],
+                                   "traffic": None if traffic is None else json.load(open(tf)).get("abx"),
+                                   "note": "arithmetic intensity gs*D=512 flop/B > ridge: MFMA-bound (SURVEY F4)"}
+        if world == 1 and not args.no_cpu_baseline:
+            cl = args.cpu_sample_len or L
+            t0 = time.perf_counter()
+            cpu_us = cpu_baseline(rank_k, rank_v, cl)
+            rec["cpu_baseline"] = {"value": round(cpu_us, 1), "unit": "us", "cores": torch.get_num_threads(),
+                                   "kind": "port",
+                                   "sample": "oracle.decode_step (CPU port of the reference's PyTorch decode branch) at "
+                                             "the same shapes, %d cached positions, 1 timed run after 1 warm-up; host %s"
+                                             % (cl, _cpu_model()),
+                                   "seconds_spent": round(time.perf_counter() - t0, 1)}
+        print(json.dumps(rec), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip() + " x%d logical" % (os.cpu_count() or 0)
+    except OSError:
+        pass
+    return "unknown"
+
+
+if __name__ == "__main__":
+    main()

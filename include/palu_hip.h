@@ -71,6 +71,58 @@ int palu_abx_rope_f16(const void* a, int64_t sa_h, int64_t sa_d,
                       int H, int G, int L, int R, int D,
                       const float* inv_freq, int pos0, palu_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * softmax + latent-space P.V   (replaces kernel/palu_attention.py:219 "/sqrt(D)", :229-234 mask,
+ * :238 softmax(fp32)->fp16, :246-251 attn[1,G,gs,L] @ V_lat[1,G,L,Rv])
+ *
+ *   x[h,l]  = fp16(fp16(scores[h,l]) / sqrt_d) (+ mask[l])          -- the reference's fp16 tensors
+ *   ctx[h,:] = sum_l softmax_l(x[h,:])[l] * v[h/gs, l, :]            -- fp32 math, one fp16 rounding
+ *
+ * scores: [H, L] fp16 (abx output), mask: [L] fp16 additive or NULL, v: [G, L, Rv] fp16 with
+ * 16-byte aligned rows, ctx: [H, Rv] fp16 (= the [1,1,H*Rv] o_proj input), probs: [H, L] fp16 or
+ * NULL (the attn_weights of output_attentions=True).  workspace: palu_pv_workspace_bytes() bytes.
+ * gs = H/G in {1,2,4,8}; Rv % 8 == 0.
+ */
+int palu_pv_nsplit(int G, int L);
+size_t palu_pv_workspace_bytes(int H, int G, int L, int Rv);
+int palu_softmax_pv_f16(const void* scores, int64_t ss_h, const void* mask,
+                        const void* v, int64_t sv_g, int64_t sv_l,
+                        void* ctx, void* probs, int64_t sp_h, void* workspace,
+                        int H, int G, int L, int Rv, float sqrt_d, palu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Batch-1 projections.
+ * palu_gemv_f16: y[N] = W[N,K] x[K], fp16 in/out, fp32 accumulate (nn.Linear without bias:
+ *   o_proj at kernel/palu_attention.py:257).  K % 8 == 0, K <= 32768.
+ * palu_decode_qkv_f16: the three input projections of one token (palu_attention.py:164-168),
+ *   RoPE of q at `pos` (:214-215; angle = fl32(pos*inv_freq)), and the append of the new latent
+ *   rows into row `row` of the pre-allocated caches k_cache [G,Lmax,Rk], v_cache [G,Lmax,Rv]
+ *   (replaces DynamicCache.update's torch.cat at :193).  q_out: [H*D] fp16.
+ */
+int palu_gemv_f16(const void* W, int64_t ldw, const void* x, void* y, int N, int K, palu_stream_t stream);
+int palu_decode_qkv_f16(const void* wq, int64_t ldq, const void* vtk, int64_t ldk, const void* vtv, int64_t ldv,
+                        const void* x, void* q_out,
+                        void* k_cache, int64_t sk_g, int64_t sk_l, void* v_cache, int64_t sv_g, int64_t sv_l,
+                        const float* inv_freq, int H, int D, int hidden, int G, int Rk, int Rv,
+                        int pos, int row, palu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole decode step (5 launches on `stream`): qkv+RoPE+append -> abx -> softmax.PV -> o_proj.
+ * Drop-in for the decode branch of LlamaPaluAttention.forward (kernel/palu_attention.py:207-257),
+ * batch 1.  hidden: [hidden_size] fp16; caches hold `cache_len` valid rows on entry and
+ * cache_len+1 on return; mask: [cache_len+1] fp16 additive or NULL; out: [hidden_size] fp16;
+ * probs: [H, cache_len+1] fp16 or NULL.  workspace: palu_decode_workspace_bytes(H,G,D,Lcap,Rv)
+ * bytes, valid for any cache_len < Lcap.  wo: [hidden_size, H*Rv] (U_v already folded in).
+ */
+size_t palu_decode_workspace_bytes(int H, int G, int D, int Lcap, int Rv);
+int palu_decode_step_f16(const void* hidden,
+                         const void* wq, int64_t ldq, const void* vtk, int64_t ldk, const void* vtv, int64_t ldv,
+                         const void* bfrag, const void* wo, int64_t ldo,
+                         void* k_cache, int64_t sk_g, int64_t sk_l, void* v_cache, int64_t sv_g, int64_t sv_l,
+                         const void* mask, const float* inv_freq, void* out, void* probs, int64_t sp_h,
+                         void* workspace, int Lcap, int H, int G, int D, int hidden_size, int Rk, int Rv,
+                         int cache_len, int pos, palu_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,9 @@ class PaluError(RuntimeError):
 
 
 def _load():
+    # torch bundles its own libamdhip64: import it FIRST so that libpalu_hip.so binds to the HIP runtime
+    # torch already initialised (two runtimes in one process do not see each other's devices/streams)
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: build it with `python -m palu_amd.build` "
@@ -38,6 +41,15 @@ SIGNATURES = {
     "palu_abx_set_fold": (i32, [i32]),
     "palu_abx_prepare_b": (i32, [vp, i64, i64, i64, i32, i32, i32, i32, vp, vp]),
     "palu_abx_rope_f16": (i32, [vp, i64, i64, vp, vp, i64, i64, vp, i64, i32, i32, i32, i32, i32, vp, i32, vp]),
+    "palu_pv_nsplit": (i32, [i32, i32]),
+    "palu_pv_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "palu_softmax_pv_f16": (i32, [vp, i64, vp, vp, i64, i64, vp, vp, i64, vp, i32, i32, i32, i32, f32, vp]),
+    "palu_gemv_f16": (i32, [vp, i64, vp, vp, i32, i32, vp]),
+    "palu_decode_qkv_f16": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, vp, i64, i64, vp, i64, i64, vp,
+                                  i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "palu_decode_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
+    "palu_decode_step_f16": (i32, [vp, vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64, i64, vp, i64, i64,
+                                   vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

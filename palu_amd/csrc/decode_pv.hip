@@ -1,0 +1,316 @@
+// Softmax + latent-space P.V of the decode step, as split-L streaming kernels.
+//
+// Replaces kernel/palu_attention.py:219 (/sqrt(D)), :229-234 (mask), :238 (softmax fp32 -> fp16)
+// and :246-251 (attn[1,G,gs,L] @ V_lat[1,G,L,Rv]).  This is the genuinely HBM-bound part of the
+// step (the V latents are 3x the K latents and are touched once): no MFMA, no LDS staging of V --
+// every lane streams 16-byte row chunks straight into registers (deep unroll, late waits) and the
+// gs heads of a group share each V row.  Split-L with a log-sum-exp merge (flash-decoding):
+//   pv_partial : WG = (group g, L-range) -> local max m, local sum S, partial sum_l e^(x-m) V[l,:]
+//   pv_combine : merges the splits, normalises, rounds once to fp16
+//   probs      : optional attention weights (output_attentions=True), fp16 like :238
+// x = fp16(fp16(score)/sqrt(D)) [+ mask], the rounding points of the reference's fp16 tensors.
+#include "palu_common.h"
+
+namespace {
+
+constexpr int PV_THREADS = 256;
+
+struct PvParams {
+  const h16* scores;   // [H, L] raw abx output
+  int64_t ss_h;
+  const h16* mask;     // [L] additive or null
+  const h16* v;        // [G, L, Rv]
+  int64_t sv_g, sv_l;
+  float* part;         // [G][nsplit][gs][Rv]
+  float* ml;           // [G][nsplit][gs][2] (max, sum)
+  int G, gs, L, Rv, nsplit, rps;
+  float inv_scale;     // sqrt(D): the reference DIVIDES by it (palu_attention.py:219)
+};
+
+static __device__ __forceinline__ float scaled_logit(h16 s, float inv_scale, const h16* mask, int l) {
+  // fp16 tensor / python float -> fp32 divide, rounded to fp16 (torch semantics); then + mask in fp16
+  h16 x = (h16)((float)s / inv_scale);
+  if (mask) x = (h16)((float)x + (float)mask[l]);
+  return (float)x;
+}
+
+static __device__ __forceinline__ float block_max(float v, float* sh, int tid) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((tid & 63) == 0) sh[tid >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+static __device__ __forceinline__ float block_sum(float v, float* sh, int tid) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((tid & 63) == 0) sh[tid >> 6] = v;
+  __syncthreads();
+  return (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+template <int GS>
+__global__ __launch_bounds__(PV_THREADS) void pv_partial_kernel(PvParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* pl = reinterpret_cast<float*>(smem_raw);  // [GS][rps] logits -> probabilities; later the reduce buffer
+  __shared__ float sh[4];
+
+  const int tid = threadIdx.x;
+  const int g = blockIdx.x % p.G;
+  const int split = blockIdx.x / p.G;
+  const int l0 = split * p.rps;
+  const int n = max(0, min(p.L - l0, p.rps));
+  float* ml = p.ml + ((size_t)(g * p.nsplit + split) * GS) * 2;
+  float* part = p.part + (size_t)(g * p.nsplit + split) * GS * p.Rv;
+
+  // thread = (row group rg, 16-byte column chunk cc) of the V stream
+  const int cpr = p.Rv >> 3;            // 16-byte chunks per row
+  const int rpp = PV_THREADS / cpr;     // rows per pass
+  const int rg = tid / cpr, cc = tid - rg * cpr;
+  const bool streamer = rg < rpp;
+  constexpr int U = 4;                  // rows per batch; two batches in flight (software pipeline)
+  const h16* vb = p.v + (int64_t)g * p.sv_g + (int64_t)l0 * p.sv_l + cc * 8;
+  const int nlast = max(n - 1, 0);
+  // rows beyond the range are clamped (re-read, weight 0) so that the loop body is branch-free
+  auto load_batch = [&](u32x4 (&raw)[U], int i) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      raw[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (int64_t)min(i + u * rpp, nlast) * p.sv_l));
+  };
+  u32x4 rawA[U], rawB[U];
+  if (streamer) load_batch(rawA, rg);   // in flight while the softmax statistics are computed
+
+  // ---- phase A: logits, local max, probabilities, local sum (per head of the group)
+  float mloc[GS], sloc[GS];
+#pragma unroll
+  for (int h = 0; h < GS; ++h) {
+    const h16* sc = p.scores + (int64_t)(g * GS + h) * p.ss_h + l0;
+    float mx = -INFINITY;
+    for (int i = tid; i < n; i += PV_THREADS) {
+      float x = scaled_logit(sc[i], p.inv_scale, p.mask, l0 + i);
+      pl[h * p.rps + i] = x;
+      mx = fmaxf(mx, x);
+    }
+    mx = block_max(mx, sh, tid);
+    float sm = 0.f;
+    for (int i = tid; i < n; i += PV_THREADS) {
+      float e = (mx == -INFINITY) ? 0.f : __expf(pl[h * p.rps + i] - mx);
+      pl[h * p.rps + i] = e;
+      sm += e;
+    }
+    for (int i = n + tid; i < p.rps; i += PV_THREADS) pl[h * p.rps + i] = 0.f;   // weights of clamped rows
+    sm = block_sum(sm, sh, tid);
+    mloc[h] = mx;
+    sloc[h] = sm;
+  }
+  if (tid == 0) {
+#pragma unroll
+    for (int h = 0; h < GS; ++h) {
+      ml[2 * h] = mloc[h];
+      ml[2 * h + 1] = sloc[h];
+    }
+  }
+  __syncthreads();
+
+  // ---- phase B: stream the V rows, two batches of U rows in flight per thread
+  float acc[GS][8];
+#pragma unroll
+  for (int h = 0; h < GS; ++h)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[h][j] = 0.f;
+  auto consume = [&](const u32x4 (&raw)[U], int i) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      h16x8 v8 = __builtin_bit_cast(h16x8, raw[u]);
+      float vf[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) vf[j] = (float)v8[j];
+      const int row = min(i + u * rpp, p.rps - 1);
+#pragma unroll
+      for (int h = 0; h < GS; ++h) {
+        float ph = (i + u * rpp < n) ? pl[h * p.rps + row] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[h][j] = fmaf(ph, vf[j], acc[h][j]);
+      }
+    }
+  };
+  if (streamer) {
+    const int stride = U * rpp;
+    int i = rg;   // rawA holds the batch whose first row is i (issued before phase A)
+    for (;;) {
+      load_batch(rawB, i + stride);   // one batch ahead; clamped beyond the range (weight 0 in consume)
+      consume(rawA, i);
+      i += stride;
+      if (i >= n) break;
+      load_batch(rawA, i + stride);
+      consume(rawB, i);
+      i += stride;
+      if (i >= n) break;
+    }
+  }
+  __syncthreads();   // everyone is done reading the probabilities: reuse the buffer for the reduction
+
+  // ---- phase C: sum the row groups -> partial context [GS][Rv]
+  float* redb = pl;   // [rpp][GS][Rv]
+  if (rg < rpp) {
+#pragma unroll
+    for (int h = 0; h < GS; ++h) {
+      float* d = redb + ((size_t)rg * GS + h) * p.Rv + cc * 8;
+      *reinterpret_cast<f32x4*>(d) = f32x4{acc[h][0], acc[h][1], acc[h][2], acc[h][3]};
+      *reinterpret_cast<f32x4*>(d + 4) = f32x4{acc[h][4], acc[h][5], acc[h][6], acc[h][7]};
+    }
+  }
+  __syncthreads();
+  const int tot = GS * p.Rv;
+  for (int o = tid; o < tot; o += PV_THREADS) {
+    float s = 0.f;
+    for (int r = 0; r < rpp; ++r) s += redb[(size_t)r * tot + o];
+    part[o] = s;
+  }
+}
+
+struct CombineParams {
+  const float* part;
+  const float* ml;
+  h16* ctx;        // [H, Rv]
+  float* stats;    // [H][2] global (max, sum) -- consumed by the probs kernel
+  int G, gs, Rv, nsplit;
+};
+
+// grid (H, ceil(Rv/64)), 512 threads: the 8 waves share the splits of one head for 64 context columns
+// (8 independent loads in flight per lane: the merge is latency-, not bandwidth-bound), LDS sum at the end.
+constexpr int CB_WAVES = 8;
+__global__ __launch_bounds__(64 * CB_WAVES) void pv_combine_kernel(CombineParams p) {
+  __shared__ float red[CB_WAVES][64];
+  __shared__ float redt[CB_WAVES];
+  const int h = blockIdx.x, g = h / p.gs, hh = h - g * p.gs;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int r = blockIdx.y * 64 + lane;
+  const float* ml = p.ml + ((size_t)g * p.nsplit * p.gs + hh) * 2;
+  const size_t ml_stride = (size_t)p.gs * 2;
+  // global max over the splits (every wave computes it: nsplit is small)
+  float M = -INFINITY;
+  for (int s = lane; s < p.nsplit; s += 64) M = fmaxf(M, ml[s * ml_stride]);
+  M = wave_max(M);
+  const float* part = p.part + ((size_t)g * p.nsplit * p.gs + hh) * p.Rv + min(r, p.Rv - 1);
+  const size_t pstride = (size_t)p.gs * p.Rv;
+  float acc = 0.f, tot = 0.f;
+  constexpr int UN = 8;
+  for (int s0 = wv * UN; s0 < p.nsplit; s0 += CB_WAVES * UN) {
+    float m[UN], sm[UN], pv[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int s = min(s0 + u, p.nsplit - 1);
+      m[u] = ml[s * ml_stride];
+      sm[u] = ml[s * ml_stride + 1];
+      pv[u] = part[s * pstride];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const float wgt = (s0 + u < p.nsplit && m[u] != -INFINITY) ? __expf(m[u] - M) : 0.f;
+      acc = fmaf(wgt, pv[u], acc);
+      tot = fmaf(wgt, sm[u], tot);
+    }
+  }
+  red[wv][lane] = acc;
+  if (lane == 0) redt[wv] = tot;
+  __syncthreads();
+  if (wv == 0) {
+    float a = 0.f, t = 0.f;
+#pragma unroll
+    for (int k = 0; k < CB_WAVES; ++k) {
+      a += red[k][lane];
+      t += redt[k];
+    }
+    if (blockIdx.y == 0 && lane == 0) {
+      p.stats[2 * h] = M;
+      p.stats[2 * h + 1] = t;
+    }
+    if (r < p.Rv) p.ctx[(size_t)h * p.Rv + r] = (h16)(a / t);
+  }
+}
+
+// attention weights: softmax(x, fp32).to(fp16)  (palu_attention.py:238)
+__global__ void probs_kernel(const h16* scores, int64_t ss_h, const h16* mask, const float* stats, h16* probs,
+                             int64_t sp_h, int L, float inv_scale) {
+  const int h = blockIdx.y;
+  const float M = stats[2 * h], S = stats[2 * h + 1];
+  for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < L; l += gridDim.x * blockDim.x) {
+    float x = scaled_logit(scores[h * ss_h + l], inv_scale, mask, l);
+    probs[h * sp_h + l] = (h16)(__expf(x - M) / S);
+  }
+}
+
+int pv_rows_per_split(int G, int L) {
+  // ~4 workgroups per CU in flight; 64-row granularity; at most 1024 rows (LDS) and at least 128
+  long long target = 4LL * palu_num_cus();
+  long long rps = ((long long)L * G + target - 1) / target;
+  rps = (rps + 63) / 64 * 64;
+  if (rps < 128) rps = 128;
+  if (rps > 1024) rps = 1024;
+  return (int)rps;
+}
+
+}  // namespace
+
+extern "C" int palu_pv_nsplit(int G, int L) {
+  if (L <= 0 || G <= 0) return 0;
+  int rps = pv_rows_per_split(G, L);
+  return (L + rps - 1) / rps;
+}
+
+extern "C" size_t palu_pv_workspace_bytes(int H, int G, int L, int Rv) {
+  int ns = palu_pv_nsplit(G, L);
+  // part [H][ns][Rv] + ml [H][ns][2] + stats [H][2], fp32
+  return ((size_t)H * ns * (Rv + 2) + (size_t)H * 2) * sizeof(float);
+}
+
+extern "C" int palu_softmax_pv_f16(const void* scores, int64_t ss_h, const void* mask, const void* v, int64_t sv_g,
+                                   int64_t sv_l, void* ctx, void* probs, int64_t sp_h, void* workspace, int H, int G,
+                                   int L, int Rv, float sqrt_d, palu_stream_t stream) {
+  PALU_REQUIRE(H > 0 && G > 0 && H % G == 0 && L > 0 && Rv > 0, PALU_ERR_ARG, "softmax_pv: bad shape");
+  PALU_REQUIRE(scores && v && ctx && workspace, PALU_ERR_ARG, "softmax_pv: null pointer");
+  const int gs = H / G;
+  PALU_REQUIRE(gs == 1 || gs == 2 || gs == 4 || gs == 8, PALU_ERR_UNSUPPORTED,
+               "softmax_pv: group size %d not supported (1,2,4,8)", gs);
+  PALU_REQUIRE(Rv % 8 == 0 && Rv / 8 <= PV_THREADS, PALU_ERR_UNSUPPORTED, "softmax_pv: Rv must be a multiple of 8, <= 2048");
+  PALU_REQUIRE(((uintptr_t)v & 15) == 0 && sv_g % 8 == 0 && sv_l % 8 == 0 && sv_l >= Rv, PALU_ERR_ARG,
+               "softmax_pv: v rows must be 16-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int rps = pv_rows_per_split(G, L);
+  const int ns = (L + rps - 1) / rps;
+  float* ws = (float*)workspace;
+  PvParams p;
+  p.scores = (const h16*)scores; p.ss_h = ss_h; p.mask = (const h16*)mask;
+  p.v = (const h16*)v; p.sv_g = sv_g; p.sv_l = sv_l;
+  p.part = ws;
+  p.ml = ws + (size_t)H * ns * Rv;
+  float* stats = p.ml + (size_t)H * ns * 2;
+  p.G = G; p.gs = gs; p.L = L; p.Rv = Rv; p.nsplit = ns; p.rps = rps;
+  p.inv_scale = sqrt_d;
+  size_t lds = (size_t)gs * rps * sizeof(float);
+  size_t lds_red = (size_t)(PV_THREADS / (Rv / 8)) * gs * Rv * sizeof(float);
+  if (lds_red > lds) lds = lds_red;
+  PALU_REQUIRE(lds <= 64 * 1024, PALU_ERR_UNSUPPORTED, "softmax_pv: LDS budget exceeded");
+  dim3 grid(G * ns), block(PV_THREADS);
+  switch (gs) {
+    case 1: hipLaunchKernelGGL(pv_partial_kernel<1>, grid, block, lds, s, p); break;
+    case 2: hipLaunchKernelGGL(pv_partial_kernel<2>, grid, block, lds, s, p); break;
+    case 4: hipLaunchKernelGGL(pv_partial_kernel<4>, grid, block, lds, s, p); break;
+    default: hipLaunchKernelGGL(pv_partial_kernel<8>, grid, block, lds, s, p); break;
+  }
+  PALU_LAUNCH_CHECK();
+  CombineParams c;
+  c.part = p.part; c.ml = p.ml; c.ctx = (h16*)ctx; c.stats = stats;
+  c.G = G; c.gs = gs; c.Rv = Rv; c.nsplit = ns;
+  hipLaunchKernelGGL(pv_combine_kernel, dim3(H, (Rv + 63) / 64), dim3(64 * CB_WAVES), 0, s, c);
+  PALU_LAUNCH_CHECK();
+  if (probs) {
+    int bx = (L + 255) / 256;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(probs_kernel, dim3(bx, H), dim3(256), 0, s, (const h16*)scores, ss_h, (const h16*)mask,
+                       (const float*)stats, (h16*)probs, sp_h, L, sqrt_d);
+    PALU_LAUNCH_CHECK();
+  }
+  return PALU_OK;
+}

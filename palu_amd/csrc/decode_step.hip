@@ -1,0 +1,53 @@
+// One-token decode of the low-rank attention module as a fixed sequence of 5 kernel launches on one
+// stream (hipGraph-capturable): the drop-in for the decode branch of LlamaPaluAttention.forward
+// (kernel/palu_attention.py:147-263, branch :207-219).
+#include "palu_common.h"
+
+namespace {
+inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+struct StepWs {
+  size_t q, scores, ctx, pv, total;
+};
+StepWs step_layout(int H, int G, int D, int Lcap, int Rv) {
+  StepWs w;
+  size_t o = 0;
+  w.q = o;      o += align256((size_t)H * D * 2);
+  w.scores = o; o += align256((size_t)H * ((size_t)Lcap + 8) * 2);
+  w.ctx = o;    o += align256((size_t)H * Rv * 2);
+  w.pv = o;     o += align256(palu_pv_workspace_bytes(H, G, Lcap, Rv));
+  w.total = o;
+  return w;
+}
+}  // namespace
+
+extern "C" size_t palu_decode_workspace_bytes(int H, int G, int D, int Lcap, int Rv) {
+  if (H <= 0 || G <= 0 || D <= 0 || Lcap <= 0 || Rv <= 0) return 0;
+  return step_layout(H, G, D, Lcap, Rv).total;
+}
+
+extern "C" int palu_decode_step_f16(const void* hidden, const void* wq, int64_t ldq, const void* vtk, int64_t ldk,
+                                    const void* vtv, int64_t ldv, const void* bfrag, const void* wo, int64_t ldo,
+                                    void* k_cache, int64_t sk_g, int64_t sk_l, void* v_cache, int64_t sv_g,
+                                    int64_t sv_l, const void* mask, const float* inv_freq, void* out, void* probs,
+                                    int64_t sp_h, void* workspace, int Lcap, int H, int G, int D, int hidden_size,
+                                    int Rk, int Rv, int cache_len, int pos, palu_stream_t stream) {
+  PALU_REQUIRE(workspace && Lcap > cache_len && cache_len >= 0, PALU_ERR_ARG,
+               "decode_step: cache_len %d must be < workspace capacity %d", cache_len, Lcap);
+  const StepWs w = step_layout(H, G, D, Lcap, Rv);
+  char* ws = (char*)workspace;
+  void* q = ws + w.q;
+  void* scores = ws + w.scores;
+  void* ctx = ws + w.ctx;
+  void* pvws = ws + w.pv;
+  const int L = cache_len + 1;
+  const int64_t ss_h = ((int64_t)Lcap + 8) & ~(int64_t)7;
+  int rc = palu_decode_qkv_f16(wq, ldq, vtk, ldk, vtv, ldv, hidden, q, k_cache, sk_g, sk_l, v_cache, sv_g, sv_l,
+                               inv_freq, H, D, hidden_size, G, Rk, Rv, pos, cache_len, stream);
+  if (rc) return rc;
+  rc = palu_abx_rope_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, scores, ss_h, H, G, L, Rk, D, inv_freq, 0, stream);
+  if (rc) return rc;
+  rc = palu_softmax_pv_f16(scores, ss_h, mask, v_cache, sv_g, sv_l, ctx, probs, sp_h, pvws, H, G, L, Rv,
+                           sqrtf((float)D), stream);
+  if (rc) return rc;
+  return palu_gemv_f16(wo, ldo, ctx, out, hidden_size, H * Rv, stream);
+}

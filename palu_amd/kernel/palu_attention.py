@@ -1,0 +1,393 @@
+"""Host-side mirror of the reference's `kernel/palu_attention.py` for the decode path.
+
+Same class names, constructor arguments, method names, return tuples and error behaviour as
+`HeadwiseLowRankModule` (kernel/palu_attention.py:16-122) and `LlamaPaluAttention` (:124-308), so
+`run_latency_attention.py` and the reference's tests read unchanged -- but:
+
+  * the decode branch (q_len == 1, :207-257) is ONE call into the HIP library
+    (`palu_decode_step_f16`: qkv GEMV + RoPE + in-place cache append -> MFMA abx -> split-L
+    softmax.PV -> o_proj GEMV); there is no PyTorch fallback for it;
+  * the cache is a pre-allocated latent cache (`LatentCache`) that implements the 4.37.2 protocol
+    the reference uses (`get_usable_length`, `update`) with an in-place row append instead of
+    `torch.cat` (which re-copied the whole cache every step, :193);
+  * the module does not inherit from `transformers.LlamaAttention` (the reference pins 4.37.2; the
+    attributes it relied on are gone in 5.x), it only reads the config fields the reference reads.
+
+The prefill branch (q_len > 1, :196-206) is composed from torch ops (rocBLAS) for now -- it is the
+"next" row N1 of SURVEY.md 8(f), not part of the decode hot path.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+from typing import List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from .. import _lib
+from .abx_rope import abx as recompute_k_gemv  # same alias as kernel/palu_attention.py:13
+from .abx_rope import prepare_b, rope_inv_freq
+
+__all__ = ["HeadwiseLowRankModule", "LlamaPaluAttention", "LatentCache", "DynamicCache", "build_b", "fuse_wo"]
+
+
+# ------------------------------------------------------------------------------------ cache
+class LatentCache:
+    """Pre-allocated latent KV cache, one (k, v) pair of [1, G, capacity, R] fp16 buffers per layer.
+
+    Implements what the reference asks of HF-4.37.2's DynamicCache (kernel/palu_attention.py:185,193):
+    `get_usable_length(new_len, layer_idx)` and `update(k, v, layer_idx) -> (K_all, V_all)` where the
+    returned tensors are views `[1, G, L, R]` of the buffers.  Rows are appended in place; capacity
+    grows geometrically (one copy) only when exhausted, so a decode step never re-copies the cache.
+    """
+
+    def __init__(self, capacity: int = 0, headroom: int = 256):
+        self._k: List[Optional[torch.Tensor]] = []
+        self._v: List[Optional[torch.Tensor]] = []
+        self._len: List[int] = []
+        self._min_capacity = int(capacity)
+        self._headroom = int(headroom)
+
+    def __len__(self):
+        return len(self._k)
+
+    def _ensure_layer(self, layer_idx: int):
+        while len(self._k) <= layer_idx:
+            self._k.append(None)
+            self._v.append(None)
+            self._len.append(0)
+
+    def get_seq_length(self, layer_idx: int = 0) -> int:
+        return self._len[layer_idx] if layer_idx < len(self._len) else 0
+
+    def get_usable_length(self, new_seq_length: int, layer_idx: int = 0) -> int:
+        return self.get_seq_length(layer_idx)
+
+    def capacity(self, layer_idx: int = 0) -> int:
+        return 0 if layer_idx >= len(self._k) or self._k[layer_idx] is None else self._k[layer_idx].shape[2]
+
+    def reserve(self, layer_idx: int, rows: int, like_k: torch.Tensor, like_v: torch.Tensor):
+        """Make room for `rows` rows in total (keeps the valid prefix)."""
+        self._ensure_layer(layer_idx)
+        cur = self.capacity(layer_idx)
+        if cur >= rows:
+            return
+        new_cap = max(rows, self._min_capacity, 2 * cur)
+        new_cap = (new_cap + 63) // 64 * 64
+        n = self._len[layer_idx]
+        for store, like in ((self._k, like_k), (self._v, like_v)):
+            buf = torch.empty((1, like.shape[1], new_cap, like.shape[3]), dtype=like.dtype, device=like.device)
+            if n:
+                buf[:, :, :n].copy_(store[layer_idx][:, :, :n])
+            store[layer_idx] = buf
+
+    def buffers(self, layer_idx: int = 0):
+        return self._k[layer_idx], self._v[layer_idx]
+
+    def advance(self, layer_idx: int, rows: int = 1):
+        """Account for rows a kernel wrote in place (decode path)."""
+        self._len[layer_idx] += rows
+
+    def update(self, key_states: torch.Tensor, value_states: torch.Tensor, layer_idx: int, cache_kwargs=None):
+        if key_states.dim() != 4 or value_states.dim() != 4:
+            raise ValueError("LatentCache.update expects [bsz, groups, seq, rank] tensors")
+        self._ensure_layer(layer_idx)
+        t = key_states.shape[2]
+        n = self._len[layer_idx]
+        self.reserve(layer_idx, n + t + self._headroom, key_states, value_states)
+        self._k[layer_idx][:, :, n:n + t].copy_(key_states)
+        self._v[layer_idx][:, :, n:n + t].copy_(value_states)
+        self._len[layer_idx] = n + t
+        return self._k[layer_idx][:, :, :n + t], self._v[layer_idx][:, :, :n + t]
+
+
+DynamicCache = LatentCache  # name used by run_latency_attention.py:62-65 and the reference tests
+
+
+
+# ------------------------------------------------------------------------- weight re-layouts
+def fold_u_per_head(u_weights, head_dim: int) -> torch.Tensor:
+    """[G x (gs*D, R)] -> [H, D, R]: head h = g*gs + j owns rows j*D:(j+1)*D of U_g."""
+    stacked = torch.stack(list(u_weights))                      # [G, gs*D, R]
+    G, gsD, R = stacked.shape
+    return stacked.reshape(G * (gsD // head_dim), head_dim, R)
+
+
+def build_b(u_weights, group_size: int, head_dim: int) -> torch.Tensor:
+    """abx operand B[h] = U_{h//gs}.weight[(h%gs)*D:(h%gs+1)*D, :]^T -> [H, R, D]
+    (kernel/palu_attention.py:108-114)."""
+    return fold_u_per_head(u_weights, head_dim).transpose(1, 2).contiguous()
+
+
+def fuse_wo(wo: torch.Tensor, uv_weights, head_dim: int) -> torch.Tensor:
+    """W_o'[:, h*Rv:(h+1)*Rv] = W_o[:, h*D:(h+1)*D] @ U_v[h//gs][(h%gs)*D:(h%gs+1)*D, :]
+    (kernel/palu_attention.py:285-306) -> [hidden, H*Rv], fp32."""
+    uv = fold_u_per_head([u.float() for u in uv_weights], head_dim)        # [H, D, Rv]
+    H = uv.shape[0]
+    w = wo.float().reshape(-1, H, head_dim)                                # [hidden, H, D]
+    return torch.einsum("ohd,hdr->ohr", w, uv).reshape(w.shape[0], -1)
+
+
+# ------------------------------------------------------------------------- low-rank projection
+class HeadwiseLowRankModule(nn.Module):
+    """Head-group-wise low-rank linear: y = cat_g U_g (VT x)[ranks of g]  (kernel/palu_attention.py:16-77).
+
+    `VT`: Linear(in_features -> sum(ranks)); `U_list[g]`: Linear(ranks[g] -> out_features/len(ranks));
+    `B` (set by `from_linear(..., attn_module=...)`): [H, R, D] per-head reconstruction used by abx.
+    """
+
+    def __init__(self, ranks, in_features, out_features, bias):
+        super().__init__()
+        self.ranks = ranks
+        self.num_groups = len(ranks)
+        self.in_features = in_features
+        self.out_features = out_features
+        self.group_dim = out_features // self.num_groups
+        if self.group_dim * self.num_groups != self.out_features:
+            raise ValueError(
+                f"out_features must be divisible by num_groups (got `out_features`: {self.out_features}"
+                f" and `num_groups`: {self.num_groups}).")
+        self.VT = nn.Linear(in_features, sum(ranks), bias=False)
+        ups = []
+        for r in ranks:
+            lin = nn.Linear(r, self.group_dim, bias=bias)
+            nn.init.normal_(lin.weight)
+            ups.append(lin)
+        self.U_list = nn.ModuleList(ups)
+
+    @staticmethod
+    def _check3(x):
+        assert x.dim() == 3, f"hidden_states should have 3 dimensions, got {x.dim()}"
+
+    def project_to_latent(self, hidden_states: torch.Tensor):
+        """[bsz, seq, in_features] -> [bsz, seq, sum(ranks)]  (:59-65)"""
+        self._check3(hidden_states)
+        return self.VT(hidden_states)
+
+    def reconstruct(self, hidden_states: torch.Tensor):
+        """[bsz, seq, sum(ranks)] -> [bsz, seq, out_features]  (:67-77)"""
+        self._check3(hidden_states)
+        pieces = torch.split(hidden_states, list(self.ranks), dim=-1)
+        return torch.cat([u(z) for u, z in zip(self.U_list, pieces)], dim=-1)
+
+    def forward(self, hidden_states: torch.Tensor):
+        self._check3(hidden_states)
+        return self.reconstruct(self.VT(hidden_states))
+
+    @staticmethod
+    def from_linear(old_module: nn.Linear, ranks: list, attn_module=None):
+        """Per-group truncated SVD of a dense projection (:79-122): W_g = (U S)[:, :r] . Vt[:r].
+        With `attn_module` the kernel operand B[h] = U_{h//gs}[(h%gs)D:(h%gs+1)D, :]^T is built (:108-114)."""
+        new = HeadwiseLowRankModule(ranks, old_module.in_features, old_module.out_features,
+                                    bias=old_module.bias is not None)
+        G = len(ranks)
+        w = old_module.weight.data.reshape(G, -1, old_module.in_features).float()
+        vt_rows = []
+        for g, r in enumerate(ranks):
+            u, s, vh = torch.linalg.svd(w[g], full_matrices=False)
+            left = (u[:, :r] * s[:r]).contiguous()
+            if new.U_list[g].weight.data.shape != left.shape:
+                raise ValueError(f"{new.U_list[g].weight.data.shape} != {left.shape}")
+            new.U_list[g].weight.data = left
+            vt_rows.append(vh[:r, :])
+        if attn_module is not None:
+            new.B = nn.Parameter(build_b([u.weight.data for u in new.U_list], attn_module.group_size,
+                                         attn_module.head_dim))
+        vt = torch.cat(vt_rows, dim=0).contiguous()
+        assert new.VT.weight.data.shape == vt.shape
+        new.VT.weight.data = vt
+        return new
+
+
+# --------------------------------------------------------------------------------- attention
+def _rotate_half(x):
+    h = x.shape[-1] // 2
+    return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+
+
+class LlamaPaluAttention(nn.Module):
+    """Llama attention with a low-rank latent KV cache (kernel/palu_attention.py:124-308).
+
+    Reads from `config`: hidden_size, num_attention_heads, attention_bias, group_size, num_groups,
+    total_rank_k, total_rank_v (+ optional head_dim, rope_theta, attention_dropout,
+    max_position_embeddings) -- the same fields as :129-145.
+    """
+
+    def __init__(self, config, layer_idx: Optional[int] = None):
+        super().__init__()
+        self.config = config
+        self.layer_idx = layer_idx
+        self.hidden_size = config.hidden_size
+        self.num_heads = config.num_attention_heads
+        self.head_dim = getattr(config, "head_dim", None) or self.hidden_size // self.num_heads
+        self.num_key_value_heads = self.num_heads          # the module is MHA-only (:143, :201)
+        self.attention_dropout = getattr(config, "attention_dropout", 0.0)
+        self.rope_theta = float(getattr(config, "rope_theta", None) or 10000.0)
+        bias = getattr(config, "attention_bias", False)
+
+        self.group_size = config.group_size
+        self.num_groups = config.num_groups
+        self.total_rank_k = config.total_rank_k
+        self.total_rank_v = config.total_rank_v
+        self.group_rank_k = self.total_rank_k // self.num_groups
+        self.group_rank_v = self.total_rank_v // self.num_groups
+        self.fused_hidden_dim_o = self.group_rank_v * self.num_heads
+        self.rank_k_list = [self.group_rank_k] * self.num_groups
+        self.rank_v_list = [self.group_rank_v] * self.num_groups
+
+        out = self.num_heads * self.head_dim
+        self.q_proj = nn.Linear(self.hidden_size, out, bias=bias)
+        self.k_proj = HeadwiseLowRankModule(self.rank_k_list, self.hidden_size, out, bias=bias)
+        self.v_proj = HeadwiseLowRankModule(self.rank_v_list, self.hidden_size, out, bias=bias)
+        self.o_proj = nn.Linear(self.fused_hidden_dim_o, self.hidden_size, bias=bias)
+        self._ws = None          # HIP workspace (grows with the cache capacity)
+        self._ws_cap = 0
+
+    # -- helpers -----------------------------------------------------------------------------
+    def _rope_tables(self, positions: torch.Tensor, dtype):
+        """cos/sin rows for `positions` like HF-4.37.2's rotary_emb + apply_rotary_pos_emb:
+        fp32 table from fl32(pos)*inv_freq, cast to the activation dtype (:214-215)."""
+        inv = rope_inv_freq(positions.device, self.head_dim, self.rope_theta)
+        ang = torch.outer(positions.to(inv.dtype), inv)
+        ang = torch.cat((ang, ang), dim=-1)
+        return ang.cos().to(dtype), ang.sin().to(dtype)
+
+    def _workspace(self, device, capacity: int):
+        if self._ws is None or self._ws_cap < capacity or self._ws.device != device:
+            nbytes = _lib.lib.palu_decode_workspace_bytes(self.num_heads, self.num_groups, self.head_dim,
+                                                          capacity, self.group_rank_v)
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            self._ws_cap = capacity
+        return self._ws
+
+    def _decode_fused(self, hidden_states, attention_mask, pos, cache: "LatentCache", output_attentions):
+        """q_len == 1, U_v folded into o_proj: the whole step in the HIP library."""
+        if self.q_proj.bias is not None:
+            raise NotImplementedError("attention_bias=True is not supported by the HIP decode step")
+        dev = hidden_states.device
+        li = self.layer_idx
+        n = cache.get_seq_length(li)
+        H, G, D = self.num_heads, self.num_groups, self.head_dim
+        if cache.capacity(li) < n + 1:
+            like_k = torch.empty((1, G, 0, self.group_rank_k), dtype=hidden_states.dtype, device=dev)
+            like_v = torch.empty((1, G, 0, self.group_rank_v), dtype=hidden_states.dtype, device=dev)
+            cache.reserve(li, n + 1 + cache._headroom, like_k, like_v)
+        kbuf, vbuf = cache.buffers(li)
+        cap = kbuf.shape[2]
+        ws = self._workspace(dev, cap + 8)
+        frag = prepare_b(self.k_proj.B, G)
+        inv = rope_inv_freq(dev, D, self.rope_theta)
+        out = torch.empty((1, 1, self.hidden_size), dtype=hidden_states.dtype, device=dev)
+        probs = torch.empty((1, H, 1, n + 1), dtype=hidden_states.dtype, device=dev) if output_attentions else None
+        mask_ptr = 0
+        if attention_mask is not None:
+            attention_mask = attention_mask.reshape(-1).to(hidden_states.dtype).contiguous()
+            mask_ptr = attention_mask.data_ptr()
+        wq, vtk, vtv, wo = self.q_proj.weight, self.k_proj.VT.weight, self.v_proj.VT.weight, self.o_proj.weight
+        x = hidden_states.reshape(-1)
+        if not x.is_contiguous():
+            x = x.contiguous()
+        _lib.check(_lib.lib.palu_decode_step_f16(
+            x.data_ptr(), wq.data_ptr(), wq.stride(0), vtk.data_ptr(), vtk.stride(0), vtv.data_ptr(), vtv.stride(0),
+            frag.data_ptr(), wo.data_ptr(), wo.stride(0),
+            kbuf.data_ptr(), kbuf.stride(1), kbuf.stride(2), vbuf.data_ptr(), vbuf.stride(1), vbuf.stride(2),
+            mask_ptr, inv.data_ptr(), out.data_ptr(),
+            0 if probs is None else probs.data_ptr(), 0 if probs is None else probs.stride(1),
+            ws.data_ptr(), self._ws_cap, H, G, D, self.hidden_size, self.group_rank_k, self.group_rank_v,
+            n, int(pos), _lib.current_stream()), "palu_decode_step_f16")
+        cache.advance(li, 1)
+        return out, probs
+
+    # -- forward -----------------------------------------------------------------------------
+    def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                position_ids: Optional[torch.LongTensor] = None, past_key_value=None,
+                output_attentions: bool = False, golden_kernel: bool = False, **kwargs
+                ) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[object]]:
+        if "padding_mask" in kwargs:
+            warnings.warn("Passing `padding_mask` is deprecated; use `attention_mask` instead.")
+        bsz, q_len, _ = hidden_states.size()
+        H, G, D = self.num_heads, self.num_groups, self.head_dim
+        if past_key_value is not None and self.layer_idx is None:
+            raise ValueError(
+                f"The cache structure has changed since version v4.36. If you are using {self.__class__.__name__} "
+                "for auto-regressive decoding with k/v caching, please make sure to initialize the attention class "
+                "with a layer index.")
+        past = 0 if past_key_value is None else past_key_value.get_usable_length(q_len, self.layer_idx)
+        kv_seq_len = q_len + past
+        if attention_mask is not None and attention_mask.size() != (bsz, 1, q_len, kv_seq_len):
+            raise ValueError(
+                f"Attention mask should be of size {(bsz, 1, q_len, kv_seq_len)}, but is {attention_mask.size()}")
+
+        fused_o = self.o_proj.in_features == self.fused_hidden_dim_o
+        if (q_len == 1 and bsz == 1 and isinstance(past_key_value, LatentCache) and fused_o
+                and hidden_states.is_cuda and hidden_states.dtype == torch.float16 and hasattr(self.k_proj, "B")):
+            pos = kv_seq_len - 1 if position_ids is None else int(position_ids.reshape(-1)[-1])
+            out, probs = self._decode_fused(hidden_states, attention_mask, pos, past_key_value, output_attentions)
+            return out, probs, past_key_value
+
+        # ---- general path (prefill, no_fusion, foreign cache objects): torch composition -------
+        query_states = self.q_proj(hidden_states).view(bsz, q_len, H, D).transpose(1, 2)
+        key_h = self.k_proj.project_to_latent(hidden_states).view(bsz, q_len, G, self.group_rank_k).transpose(1, 2)
+        val_h = self.v_proj.project_to_latent(hidden_states).view(bsz, q_len, G, self.group_rank_v).transpose(1, 2)
+        if past_key_value is not None:
+            key_h, val_h = past_key_value.update(key_h, val_h, self.layer_idx)
+        if position_ids is None:
+            position_ids = torch.arange(past, kv_seq_len, device=hidden_states.device).unsqueeze(0)
+        pos = position_ids.to(hidden_states.device).reshape(-1, q_len)
+        cos, sin = self._rope_tables(pos.reshape(-1), query_states.dtype)
+        cos = cos.view(pos.shape[0], 1, q_len, D)
+        sin = sin.view(pos.shape[0], 1, q_len, D)
+        query_states = query_states * cos + _rotate_half(query_states) * sin
+        if q_len > 1:
+            if bsz != 1:
+                raise ValueError("LlamaPaluAttention supports batch size 1 only (kernel/palu_attention.py:248,251)")
+            lat = key_h.transpose(1, 2).reshape(bsz, kv_seq_len, self.total_rank_k)
+            key_states = self.k_proj.reconstruct(lat).view(bsz, kv_seq_len, H, D).transpose(1, 2)
+            kpos = torch.arange(kv_seq_len, device=hidden_states.device) if past else pos.reshape(-1)
+            kc, ks = self._rope_tables(kpos, key_states.dtype)
+            if past == 0:
+                key_states = key_states * cos + _rotate_half(key_states) * sin
+            else:
+                key_states = key_states * kc.view(1, 1, kv_seq_len, D) + _rotate_half(key_states) * ks.view(1, 1, kv_seq_len, D)
+            attn_weights = torch.matmul(query_states, key_states.transpose(2, 3)) / math.sqrt(D)
+        else:
+            attn_weights = recompute_k_gemv(query_states.squeeze(0), self.k_proj.B, key_h.squeeze(0),
+                                            theta=self.rope_theta).unsqueeze(0) / math.sqrt(D)
+        if attn_weights.size() != (bsz, H, q_len, kv_seq_len):
+            raise ValueError(
+                f"Attention weights should be of size {(bsz, H, q_len, kv_seq_len)}, but is {attn_weights.size()}")
+        if attention_mask is not None:
+            attn_weights = attn_weights + attention_mask
+        attn_weights = nn.functional.softmax(attn_weights, dim=-1, dtype=torch.float32).to(query_states.dtype)
+        attn_weights = nn.functional.dropout(attn_weights, p=self.attention_dropout, training=self.training)
+        # latent-space P.V (:246-251): heads of a group share the group's V latents
+        ctx = torch.matmul(attn_weights.reshape(1, G, q_len * self.group_size, kv_seq_len), val_h)
+        ctx = ctx.reshape(1, H, q_len, self.group_rank_v)
+        if fused_o:
+            attn_output = ctx.transpose(1, 2).contiguous().reshape(bsz, q_len, -1)
+        else:                                  # no_fusion: reconstruct V per head, dense o_proj
+            uv = fold_u_per_head([u.weight for u in self.v_proj.U_list], D)             # [H, D, Rv]
+            full = torch.einsum("hqr,hdr->hqd", ctx[0], uv.to(ctx.dtype))
+            attn_output = full.transpose(0, 1).reshape(bsz, q_len, H * D)
+        attn_output = self.o_proj(attn_output)
+        if not output_attentions:
+            attn_weights = None
+        return attn_output, attn_weights, past_key_value
+
+    # -- construction from a dense attention module ------------------------------------------
+    @staticmethod
+    def from_attention(module, config, no_fusion: bool = False):
+        """Decompose k/v projections per head group and (unless `no_fusion`) fold U_v into o_proj:
+        W_o'[:, h*Rv:(h+1)*Rv] = W_o[:, h*D:(h+1)*D] @ U_v[h//gs][(h%gs)*D:(h%gs+1)*D, :]  (:265-308)."""
+        new = LlamaPaluAttention(config, getattr(module, "layer_idx", None))
+        new.q_proj = module.q_proj
+        new.k_proj = HeadwiseLowRankModule.from_linear(module.k_proj, new.rank_k_list, new)
+        new.v_proj = HeadwiseLowRankModule.from_linear(module.v_proj, new.rank_v_list)
+        if no_fusion:
+            new.o_proj = module.o_proj
+            return new
+        fused = fuse_wo(module.o_proj.weight.data, [u.weight.data for u in new.v_proj.U_list], new.head_dim)
+        with torch.no_grad():
+            new.o_proj.weight.copy_(fused)
+        return new

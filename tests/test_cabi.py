@@ -1,0 +1,63 @@
+"""The C-ABI library loads on a GPU-less host and exports exactly what include/palu_hip.h declares
+(no compute calls here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "palu_hip.h")
+
+
+def _declared():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(palu_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_declares_entry_points():
+    names = _declared()
+    for must in ("palu_abx_rope_f16", "palu_abx_prepare_b", "palu_softmax_pv_f16", "palu_decode_step_f16",
+                 "palu_gemv_f16", "palu_decode_qkv_f16", "palu_last_error"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from palu_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in _declared():
+        assert hasattr(lib, name), f"{name} declared in palu_hip.h but not exported by libpalu_hip.so"
+
+
+def test_binding_table_matches_header():
+    from palu_amd import _lib
+    declared = set(_declared())
+    bound = set(_lib.SIGNATURES)
+    assert declared == bound, (sorted(declared - bound), sorted(bound - declared))
+
+
+def test_extern_c_no_cxx_symbols_leak():
+    from palu_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = [l.split()[-1] for l in out.splitlines() if " T " in l]
+    palu = [s for s in exported if s.startswith("palu_")]
+    assert set(_declared()) <= set(palu)
+
+
+def test_host_only_entry_points_work_without_gpu():
+    from palu_amd import _lib
+    import numpy as np
+    buf = (ctypes.c_float * 64)()
+    assert _lib.lib.palu_rope_inv_freq_host(10000.0, 128, buf) == 0
+    ref = 1.0 / (10000.0 ** (np.arange(0, 128, 2, dtype=np.float32) / 128))
+    np.testing.assert_allclose(np.array(buf[:]), ref, rtol=2e-7)
+    assert _lib.lib.palu_rope_inv_freq_host(10000.0, 127, buf) == -1          # PALU_ERR_ARG
+    assert b"rope_inv_freq" in _lib.lib.palu_last_error()
+    assert _lib.lib.palu_abx_bfrag_bytes(32, 8, 128) == 32 * 128 * 128 * 2
+    assert _lib.lib.palu_abx_bfrag_bytes(32, 8, 512) == 32 * 512 * 128 * 2
+    assert _lib.lib.palu_abx_bfrag_bytes(32, 5, 128) == 0                       # H % G != 0
+    assert _lib.lib.palu_pv_workspace_bytes(32, 8, 2048, 96) > 0
+    assert _lib.lib.palu_decode_workspace_bytes(32, 8, 128, 4096, 96) > 0
+    assert _lib.lib.palu_version() >= 100

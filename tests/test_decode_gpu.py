@@ -1,0 +1,282 @@
+"""GPU parity of the decode-step kernels (softmax.PV, GEMVs, full step) against the CPU oracle and
+the golden vectors generated from the reference.  Criterion P1 of SURVEY.md 8(c):
+assert_close(rtol=1e-3, atol=1e-3) on attention weights and attention output."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+
+import oracle
+from tests.golden import inputs as gi
+
+DEV = "cuda"
+
+
+def _lib():
+    from palu_amd import _lib
+    return _lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def softmax_pv(scores, v, mask=None, want_probs=False):
+    """scores [H,L] fp16, v [G,L,Rv] fp16 (cuda) -> ctx [H,Rv], probs [H,L]"""
+    lib = _lib()
+    H, L = scores.shape
+    G, _, Rv = v.shape
+    ws = torch.empty(lib.lib.palu_pv_workspace_bytes(H, G, L, Rv), dtype=torch.uint8, device=DEV)
+    ctx = torch.empty(H, Rv, dtype=torch.float16, device=DEV)
+    probs = torch.empty(H, L, dtype=torch.float16, device=DEV) if want_probs else None
+    lib.check(lib.lib.palu_softmax_pv_f16(scores.data_ptr(), scores.stride(0), 0 if mask is None else mask.data_ptr(),
+                                          v.data_ptr(), v.stride(0), v.stride(1), ctx.data_ptr(),
+                                          0 if probs is None else probs.data_ptr(), 0 if probs is None else probs.stride(0),
+                                          ws.data_ptr(), H, G, L, Rv, math.sqrt(128.0), _stream()), "softmax_pv")
+    return ctx, probs
+
+
+def ref_softmax_pv(scores, v, mask=None):
+    """CPU restatement of kernel/palu_attention.py:219,229-251 on fp16 tensors."""
+    H, L = scores.shape
+    G = v.shape[0]
+    x = scores / math.sqrt(128.0)
+    if mask is not None:
+        x = x + mask.reshape(1, L)
+    p = torch.softmax(x, dim=-1, dtype=torch.float32).to(torch.float16)
+    ctx = torch.matmul(p.reshape(G, H // G, L), v)
+    return ctx.reshape(H, -1), p
+
+
+@pytest.mark.parametrize("H,gs,L,Rv", [(32, 4, 2049, 96), (32, 4, 1, 384), (32, 4, 129, 384), (8, 2, 700, 64),
+                                       (4, 1, 333, 192), (16, 8, 5000, 128), (32, 4, 70000, 64)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_softmax_pv(H, gs, L, Rv, masked):
+    rng = np.random.default_rng(H + L + Rv)
+    G = H // gs
+    scores = torch.from_numpy((rng.standard_normal((H, L)) * 30).astype(np.float16))
+    v = torch.from_numpy(rng.standard_normal((G, L, Rv)).astype(np.float16))
+    mask = None
+    if masked:
+        m = np.zeros(L, dtype=np.float16)
+        m[rng.random(L) < 0.3] = np.float16(-65504.0)
+        m[L - 1] = 0
+        mask = torch.from_numpy(m)
+    ctx, probs = softmax_pv(scores.to(DEV), v.to(DEV), None if mask is None else mask.to(DEV), want_probs=True)
+    rctx, rp = ref_softmax_pv(scores, v, mask)
+    torch.testing.assert_close(probs.cpu(), rp, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(ctx.cpu(), rctx, rtol=1e-3, atol=1e-3)
+    # against exact fp64 softmax of the same fp16 logits: tighter
+    x = (scores / math.sqrt(128.0))
+    x = x if mask is None else x + mask.reshape(1, L)
+    p64 = torch.softmax(x.double(), dim=-1)
+    c64 = torch.matmul(p64.reshape(G, gs, L), v.double()).reshape(H, Rv)
+    assert (ctx.cpu().double() - c64).abs().max().item() <= 1e-3 * max(1.0, c64.abs().max().item())
+
+
+def test_softmax_pv_fully_masked_split_and_strided_cache():
+    """A whole split masked out (-inf after the fp16 add) must not poison the merge; V as a view of a
+    larger pre-allocated cache."""
+    rng = np.random.default_rng(3)
+    H, G, L, Rv, cap = 32, 8, 3000, 96, 4096
+    scores = torch.from_numpy((rng.standard_normal((H, L)) * 5).astype(np.float16))
+    cache = torch.from_numpy(rng.standard_normal((G, cap, Rv)).astype(np.float16)).to(DEV)
+    m = np.zeros(L, dtype=np.float16)
+    m[:2000] = -np.inf
+    mask = torch.from_numpy(m)
+    ctx, probs = softmax_pv(scores.to(DEV), cache[:, :L], mask.to(DEV), want_probs=True)
+    rctx, rp = ref_softmax_pv(scores, cache[:, :L].cpu(), mask)
+    assert torch.isfinite(ctx.float()).all()
+    torch.testing.assert_close(probs.cpu(), rp, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(ctx.cpu(), rctx, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("N,K", [(4096, 4096), (4096, 12288), (100, 768), (7, 264), (4096, 3072)])
+def test_gemv(N, K):
+    lib = _lib()
+    rng = np.random.default_rng(N + K)
+    W = torch.from_numpy((rng.standard_normal((N, K)) / math.sqrt(K)).astype(np.float16)).to(DEV)
+    x = torch.from_numpy(rng.standard_normal(K).astype(np.float16)).to(DEV)
+    y = torch.empty(N, dtype=torch.float16, device=DEV)
+    lib.check(lib.lib.palu_gemv_f16(W.data_ptr(), W.stride(0), x.data_ptr(), y.data_ptr(), N, K, _stream()), "gemv")
+    ref = (W.double().cpu() @ x.double().cpu())
+    assert (y.cpu().double() - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())
+    cpu16 = torch.nn.functional.linear(x.cpu().reshape(1, -1), W.cpu()).reshape(-1)
+    torch.testing.assert_close(y.cpu(), cpu16, rtol=2e-3, atol=2e-3)
+
+
+def _module_from_palu_weights(hidden, H, D, gs, rank_k, rank_v, w):
+    from palu_amd.kernel.palu_attention import LlamaPaluAttention, build_b
+
+    class Cfg:
+        pass
+    cfg = Cfg()
+    cfg.hidden_size, cfg.num_attention_heads, cfg.attention_bias = hidden, H, False
+    cfg.group_size, cfg.num_groups = gs, H // gs
+    cfg.total_rank_k, cfg.total_rank_v = rank_k, rank_v
+    m = LlamaPaluAttention(cfg, 0)
+    with torch.no_grad():
+        m.q_proj.weight.copy_(w["wq"])
+        m.k_proj.VT.weight.copy_(w["vt_k"])
+        m.v_proj.VT.weight.copy_(w["vt_v"])
+        for i, u in enumerate(w["u_k"]):
+            m.k_proj.U_list[i].weight.copy_(u)
+        m.o_proj.weight.copy_(w["wo"])
+    m.k_proj.B = nn.Parameter(build_b(w["u_k"], gs, D))
+    return m.eval().to(DEV, torch.float16)
+
+
+@pytest.mark.parametrize("case", gi.STEP_CASES, ids=[c[0] for c in gi.STEP_CASES])
+def test_decode_step_golden(golden_dir, case):
+    """Whole decode step through LlamaPaluAttention.forward (one C-ABI call) vs the reference's outputs."""
+    from palu_amd.kernel.palu_attention import LatentCache
+    tag, seed, hidden, H, D, gs, rank_k, rank_v, L, with_mask = case
+    g = np.load(os.path.join(golden_dir, "g3_decode_step.npz"))
+    w, k_lat, v_lat, tok, mask = gi.step_inputs(seed, hidden, H, D, gs, rank_k, rank_v, L, with_mask)
+    flat = [w["wq"], w["vt_k"], w["vt_v"], w["wo"], *w["u_k"], k_lat, v_lat, tok]
+    assert gi.digest(*flat) == str(g[tag + "/digest"])
+    m = _module_from_palu_weights(hidden, H, D, gs, rank_k, rank_v, w)
+    cache = LatentCache()
+    cache.update(k_lat.unsqueeze(0).to(DEV), v_lat.unsqueeze(0).to(DEV), 0)
+    am = None if mask is None else mask.reshape(1, 1, 1, L + 1).to(DEV)
+    with torch.no_grad():
+        out, probs, cache2 = m(tok.reshape(1, 1, hidden).to(DEV), attention_mask=am,
+                               position_ids=torch.arange(L, L + 1), past_key_value=cache, output_attentions=True)
+    assert cache2 is cache and cache.get_seq_length(0) == L + 1
+    assert out.shape == (1, 1, hidden) and probs.shape == (1, H, 1, L + 1)
+    torch.testing.assert_close(probs.cpu().reshape(H, L + 1), torch.from_numpy(g[tag + "/attn_weights"]),
+                               rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(out.cpu().reshape(-1), torch.from_numpy(g[tag + "/attn_output"]), rtol=1e-3, atol=1e-3)
+    kb, vb = cache.buffers(0)
+    torch.testing.assert_close(kb[0, :, L].cpu(), torch.from_numpy(g[tag + "/k_new"]), rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(vb[0, :, L].cpu(), torch.from_numpy(g[tag + "/v_new"]), rtol=2e-3, atol=2e-3)
+    # and against the oracle run on the same inputs (tighter on the output scale)
+    wd = {"wq": w["wq"].half(), "vt_k": w["vt_k"].half(), "vt_v": w["vt_v"].half(),
+          "b": oracle.build_b_from_u(w["u_k"], gs, D).half(), "wo": w["wo"].half()}
+    o2, p2, _, _ = oracle.decode_step(tok, L, wd, k_lat, v_lat, mask)
+    assert (out.cpu().reshape(-1).float() - o2.float()).abs().max().item() <= 1e-3
+
+
+def test_decode_steps_grow_the_cache_in_place():
+    """Several consecutive steps: same result as feeding the oracle step by step; buffers never move."""
+    from palu_amd.kernel.palu_attention import LatentCache
+    tag, seed, hidden, H, D, gs, rank_k, rank_v, L, _ = gi.STEP_CASES[0]
+    w, k_lat, v_lat, tok, _ = gi.step_inputs(seed, hidden, H, D, gs, rank_k, rank_v, L, False)
+    m = _module_from_palu_weights(hidden, H, D, gs, rank_k, rank_v, w)
+    cache = LatentCache(capacity=256)
+    cache.update(k_lat.unsqueeze(0).to(DEV), v_lat.unsqueeze(0).to(DEV), 0)
+    ptr = cache.buffers(0)[0].data_ptr()
+    wd = {"wq": w["wq"].half(), "vt_k": w["vt_k"].half(), "vt_v": w["vt_v"].half(),
+          "b": oracle.build_b_from_u(w["u_k"], gs, D).half(), "wo": w["wo"].half()}
+    kc, vc = k_lat, v_lat
+    rng = np.random.default_rng(0)
+    for step in range(5):
+        t = torch.from_numpy(rng.standard_normal(hidden).astype(np.float16))
+        with torch.no_grad():
+            out, _, _ = m(t.reshape(1, 1, hidden).to(DEV), position_ids=torch.arange(L + step, L + step + 1),
+                          past_key_value=cache)
+        ref, _, kc, vc = oracle.decode_step(t, L + step, wd, kc, vc)
+        assert (out.cpu().reshape(-1).float() - ref.float()).abs().max().item() <= 1e-3
+    assert cache.buffers(0)[0].data_ptr() == ptr and cache.get_seq_length(0) == L + 5
+
+
+def test_reference_test_scenario(golden_dir):
+    """kernel/test_palu_attention.py:158-195: full-rank (4096/4096) Palu from a dense attention via
+    per-group SVD, prefill 63 tokens into the cache, decode 1 token: attention weights and output vs the
+    values the reference module produced (and vs vanilla attention), rtol=atol=1e-3."""
+    from palu_amd.kernel.palu_attention import LatentCache, LlamaPaluAttention
+    g = np.load(os.path.join(golden_dir, "g3b_reftest.npz"))
+    rng = np.random.default_rng(4242)
+    hidden, H, D, gs = 4096, 32, 128, 4
+
+    class Dense(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.layer_idx, self.head_dim = 0, D
+            for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
+                setattr(self, n, nn.Linear(hidden, hidden, bias=False))
+    attn = Dense()
+    ws = []
+    with torch.no_grad():
+        for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            wt = torch.from_numpy(rng.uniform(-1 / 64, 1 / 64, (hidden, hidden)).astype(np.float32))
+            getattr(attn, n).weight.copy_(wt)
+            ws.append(wt)
+    prompt = torch.from_numpy(rng.standard_normal((1, 63, hidden)).astype(np.float16))
+    tok = torch.from_numpy(rng.standard_normal((1, 1, hidden)).astype(np.float16))
+    assert gi.digest(*ws, prompt, tok) == str(g["digest"])
+
+    class Cfg:
+        pass
+    cfg = Cfg()
+    cfg.hidden_size, cfg.num_attention_heads, cfg.attention_bias = hidden, H, False
+    cfg.group_size, cfg.num_groups, cfg.total_rank_k, cfg.total_rank_v = gs, H // gs, 4096, 4096
+    torch.set_num_threads(min(32, max(1, os.cpu_count() or 1)))   # 64 SVDs of 512x4096: oversubscription hurts
+    palu = LlamaPaluAttention.from_attention(attn, cfg).eval().to(DEV, torch.float16)
+    cache = LatentCache()
+    with torch.no_grad():
+        po, _, _ = palu(prompt.to(DEV), past_key_value=cache, position_ids=torch.arange(63).unsqueeze(0))
+        do, dp, _ = palu(tok.to(DEV), output_attentions=True, past_key_value=cache,
+                         position_ids=torch.arange(63, 64).unsqueeze(0))
+    torch.testing.assert_close(po[0, -1].cpu(), torch.from_numpy(g["prefill_output_last"]), rtol=2e-3, atol=2e-3)
+    for name_w, name_o in (("decode_weights", "decode_output"), ("vanilla_weights", "vanilla_output")):
+        torch.testing.assert_close(dp[0, :, 0].cpu().float(), torch.from_numpy(g[name_w]).float(), rtol=1e-3, atol=1e-3)
+        torch.testing.assert_close(do.reshape(-1).cpu().float(), torch.from_numpy(g[name_o]).float(), rtol=1e-3, atol=1e-3)
+
+
+def test_decode_step_under_graph_capture():
+    """run_latency_attention.py:81-90 captures one forward in a graph and replays it."""
+    from palu_amd.kernel.palu_attention import LatentCache
+    tag, seed, hidden, H, D, gs, rank_k, rank_v, L, _ = gi.STEP_CASES[0]
+    w, k_lat, v_lat, tok, _ = gi.step_inputs(seed, hidden, H, D, gs, rank_k, rank_v, L, False)
+    m = _module_from_palu_weights(hidden, H, D, gs, rank_k, rank_v, w)
+
+    def fresh_cache():
+        c = LatentCache(capacity=512)
+        c.update(k_lat.unsqueeze(0).to(DEV), v_lat.unsqueeze(0).to(DEV), 0)
+        return c
+    x = tok.reshape(1, 1, hidden).to(DEV)
+    pos = torch.arange(L, L + 1)
+    with torch.no_grad():
+        eager, _, _ = m(x, position_ids=pos, past_key_value=fresh_cache())          # also warms the caches
+    cache = fresh_cache()
+    static_x = x.clone()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.no_grad(), torch.cuda.stream(s):
+        m(static_x, position_ids=pos, past_key_value=fresh_cache())
+    torch.cuda.current_stream().wait_stream(s)
+    graph = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(graph):
+        out, _, _ = m(static_x, position_ids=pos, past_key_value=cache)
+    for _ in range(3):
+        static_x.copy_(x)
+        graph.replay()
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out, eager, rtol=0, atol=0)
+
+
+def test_decode_step_full_size_c2_properties():
+    """BASELINE config 2 (rank 1024/3072, gs 4, L=64k): the step vs an fp32 torch-GPU recomputation from
+    the kernels' own intermediate (scores), plus linearity of the context in V."""
+    torch.manual_seed(0)
+    H, G, L, Rv = 32, 8, 65536, 384
+    scores = (torch.randn(H, L, device=DEV) * 12).half()
+    v = torch.randn(G, L, Rv, device=DEV, dtype=torch.float16)
+    ctx, probs = softmax_pv(scores, v, want_probs=True)
+    x = (scores / math.sqrt(128.0)).float()
+    p = torch.softmax(x, dim=-1)
+    ref = torch.matmul(p.reshape(G, 4, L), v.float()).reshape(H, Rv)
+    torch.testing.assert_close(ctx.float(), ref, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(probs.float(), p, rtol=1e-3, atol=1e-3)
+    assert abs(probs.float().sum(-1) - 1).max().item() < 5e-2
+    v2 = torch.randn(G, L, Rv, device=DEV, dtype=torch.float16)
+    c2, _ = softmax_pv(scores, v2)
+    c12, _ = softmax_pv(scores, (v.float() * 0.5 + v2.float() * 0.25).half())
+    torch.testing.assert_close(c12.float(), ctx.float() * 0.5 + c2.float() * 0.25, rtol=2e-3, atol=2e-3)

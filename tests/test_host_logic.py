@@ -1,0 +1,159 @@
+"""CPU tests of the host-side mirror (no GPU): the reference's own CPU tests
+(kernel/test_palu_attention.py:34-133) restated against palu_amd, plus the latent cache."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+from palu_amd.kernel.palu_attention import (HeadwiseLowRankModule, LatentCache, LlamaPaluAttention, build_b,
+                                            fuse_wo)
+
+
+class Cfg:
+    def __init__(self, hidden=512, heads=4, gs=2, rk=None, rv=None):
+        self.hidden_size = hidden
+        self.num_attention_heads = heads
+        self.attention_bias = False
+        self.group_size = gs
+        self.num_groups = heads // gs
+        self.total_rank_k = hidden if rk is None else rk
+        self.total_rank_v = hidden if rv is None else rv
+
+
+class DenseAttn(nn.Module):
+    """Minimal stand-in for LlamaAttention: what from_attention reads (q/k/v/o_proj, layer_idx, head_dim)."""
+
+    def __init__(self, cfg, layer_idx=0):
+        super().__init__()
+        d = cfg.hidden_size
+        self.layer_idx = layer_idx
+        self.head_dim = d // cfg.num_attention_heads
+        self.q_proj, self.k_proj = nn.Linear(d, d, bias=False), nn.Linear(d, d, bias=False)
+        self.v_proj, self.o_proj = nn.Linear(d, d, bias=False), nn.Linear(d, d, bias=False)
+
+
+@pytest.fixture(autouse=True)
+def _seed():
+    torch.manual_seed(0)
+
+
+def test_lr_layer_init():                                  # test_palu_attention.py:34-53
+    m = HeadwiseLowRankModule([2, 2], 6, 6, False)
+    x = torch.randn(1, 5, 6)
+    torch.testing.assert_close(m(x), m.reconstruct(m.project_to_latent(x)))
+    with pytest.raises(ValueError):
+        HeadwiseLowRankModule([2, 2, 2, 2], 6, 6, False)   # out_features % num_groups (:27-31)
+    with pytest.raises(AssertionError):
+        m(torch.randn(5, 6))
+
+
+def test_lr_layer_from_linear():                           # :55-74 full rank -> lossless
+    lin = nn.Linear(10, 6, False)
+    svd = HeadwiseLowRankModule.from_linear(lin, [3, 3])
+    x = torch.randn(1, 5, 10)
+    torch.testing.assert_close(lin(x), svd(x))
+
+
+def test_inherit_no_fusion():                              # :76-90
+    cfg = Cfg()
+    attn = DenseAttn(cfg)
+    palu = LlamaPaluAttention.from_attention(attn, cfg, no_fusion=True)
+    torch.testing.assert_close(attn.q_proj.weight, palu.q_proj.weight)
+    torch.testing.assert_close(attn.o_proj.weight, palu.o_proj.weight)
+    x = torch.randn(1, 16, cfg.hidden_size)
+    torch.testing.assert_close(attn.k_proj(x), palu.k_proj(x), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(attn.v_proj(x), palu.v_proj(x), rtol=1e-4, atol=1e-5)
+
+
+def test_inherit_fusion_algebra():                         # :92-133
+    cfg = Cfg()
+    H, gs, D = cfg.num_attention_heads, cfg.group_size, cfg.hidden_size // cfg.num_attention_heads
+    G, Rv = H // gs, cfg.total_rank_v // (H // gs)
+    attn = DenseAttn(cfg)
+    palu = LlamaPaluAttention.from_attention(attn, cfg)
+    assert palu.o_proj.weight.shape == (cfg.hidden_size, H * Rv)
+    assert palu.k_proj.B.shape == (H, cfg.total_rank_k // G, D)
+    q_len = 12
+    x = torch.randn(1, q_len, cfg.hidden_size)
+    w = torch.randn(1, H, q_len, q_len)
+    v = attn.v_proj(x).view(1, q_len, H, D).transpose(1, 2)
+    ref = attn.o_proj(torch.matmul(w, v).transpose(1, 2).reshape(1, q_len, -1))
+    vh = palu.v_proj.project_to_latent(x).reshape(1, q_len, G, Rv).transpose(1, 2)
+    lat = torch.matmul(w.reshape(1, G, q_len * gs, q_len), vh).reshape(1, H, q_len, Rv)
+    got = palu.o_proj(lat.transpose(1, 2).reshape(1, q_len, -1))
+    torch.testing.assert_close(ref, got, rtol=1e-3, atol=1e-4)
+
+
+def test_prefill_forward_matches_dense_attention_cpu_fp32():
+    """Full-rank Palu prefill (torch-composed branch) == vanilla attention, fp32 on CPU."""
+    cfg = Cfg()
+    H, D = cfg.num_attention_heads, cfg.hidden_size // cfg.num_attention_heads
+    attn = DenseAttn(cfg)
+    palu = LlamaPaluAttention.from_attention(attn, cfg).eval()
+    T = 9
+    x = torch.randn(1, T, cfg.hidden_size)
+    out, probs, _ = palu(x, output_attentions=True)
+    # vanilla
+    import oracle
+    q = attn.q_proj(x).view(T, H, D).transpose(0, 1)
+    k = attn.k_proj(x).view(T, H, D).transpose(0, 1)
+    v = attn.v_proj(x).view(T, H, D).transpose(0, 1)
+    cos, sin = oracle.rope_cos_sin(T, D)
+    q, k = oracle.rope_rotate(q, cos, sin), oracle.rope_rotate(k, cos, sin)
+    p = torch.softmax(q @ k.transpose(1, 2) / D ** 0.5, dim=-1)
+    ref = attn.o_proj((p @ v).transpose(0, 1).reshape(1, T, H * D))
+    torch.testing.assert_close(probs[0], p, rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(out, ref, rtol=1e-3, atol=1e-4)
+    # no_fusion variant takes the dense o_proj branch
+    palu2 = LlamaPaluAttention.from_attention(attn, cfg, no_fusion=True).eval()
+    out2, _, _ = palu2(x)
+    torch.testing.assert_close(out2, ref, rtol=1e-3, atol=1e-4)
+
+
+def test_b_layout_and_fusion_against_reference_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g4_layout.npz"))
+    gs, D = int(g["gs"]), int(g["D"])
+    np.testing.assert_array_equal(build_b([torch.from_numpy(u) for u in g["u_k"]], gs, D).numpy(), g["b"])
+    fused = fuse_wo(torch.from_numpy(g["wo"]), [torch.from_numpy(u) for u in g["u_v"]], D)
+    np.testing.assert_allclose(fused.numpy(), g["wo_fused"], rtol=0, atol=1e-6)
+
+
+def test_forward_argument_validation():
+    cfg = Cfg()
+    palu = LlamaPaluAttention(cfg, None)
+    x = torch.randn(1, 3, cfg.hidden_size)
+    with pytest.raises(ValueError):          # cache without layer index (:179-184)
+        palu(x, past_key_value=LatentCache())
+    palu = LlamaPaluAttention(cfg, 0)
+    with pytest.raises(ValueError):          # mask shape (:230-233)
+        palu(x, attention_mask=torch.zeros(1, 1, 3, 4))
+    with pytest.raises(RuntimeError):        # decode on CPU: no fallback for the HIP op
+        palu.k_proj.B = nn.Parameter(torch.zeros(4, 128, 128))
+        c = LatentCache()
+        palu(x, past_key_value=c)
+        palu(x[:, :1].half(), past_key_value=c)
+
+
+def test_latent_cache_protocol():
+    c = LatentCache(capacity=8, headroom=2)
+    assert c.get_usable_length(1, 0) == 0
+    k0, v0 = torch.randn(1, 2, 5, 4), torch.randn(1, 2, 5, 6)
+    ka, va = c.update(k0, v0, 0)
+    assert ka.shape == (1, 2, 5, 4) and va.shape == (1, 2, 5, 6) and c.get_usable_length(1, 0) == 5
+    torch.testing.assert_close(ka, k0)
+    base = c.buffers(0)[0].data_ptr()
+    k1, v1 = torch.randn(1, 2, 1, 4), torch.randn(1, 2, 1, 6)
+    ka, va = c.update(k1, v1, 0)
+    assert c.buffers(0)[0].data_ptr() == base, "append must be in place while capacity lasts"
+    torch.testing.assert_close(ka, torch.cat((k0, k1), dim=2))
+    torch.testing.assert_close(va, torch.cat((v0, v1), dim=2))
+    for _ in range(20):                      # growth keeps the prefix
+        ka, va = c.update(k1, v1, 0)
+    assert ka.shape[2] == 26 and c.capacity(0) >= 26
+    torch.testing.assert_close(ka[:, :, :5], k0)
+    c.update(k0, v0, 2)                      # sparse layer indices
+    assert c.get_seq_length(2) == 5 and c.get_seq_length(1) == 0 and len(c) == 3
+    with pytest.raises(ValueError):
+        c.update(k0[0], v0[0], 0)

@@ -1,9 +1,10 @@
 #!/bin/bash
-# usage: tools/prof.sh <tag> <python driver and args...>
-# kernel-trace stats + separate PMC passes (never combined with other trace domains), outputs
-# under gpurun_out/prof_<tag>/.  Run on the GPU box via gpurun.
+# usage: tools/prof.sh <tag> <kernel-name-like-pattern> <python driver and args...>
+# rocprofv3 kernel-trace stats + separate PMC passes (never combined with other trace domains);
+# outputs under gpurun_out/prof_<tag>/ (summary.txt is what gets copied to profiles/).
 set -u
 TAG=$1; shift
+PAT=$1; shift
 export TMPDIR=/tmp
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
@@ -12,12 +13,12 @@ export PYTHONPATH=$ROOT
 cd /tmp
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -- python $ROOT/"$@" > $OUT/trace.log 2>&1
 i=0
-for PMC in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" \
+for PMC in ${PMC_PASSES:-"SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" \
            "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS" \
-           "FETCH_SIZE" "WRITE_SIZE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_MISC"; do
+           "FETCH_SIZE" "WRITE_SIZE SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR"}; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $PMC -d $OUT/pmc$i -o p -- python $ROOT/"$@" > $OUT/pmc$i.log 2>&1
 done
 cd $ROOT
-python tools/prof_summary.py $OUT "%abx_rope%" > $OUT/summary.txt 2>&1
+python tools/prof_summary.py $OUT "$PAT" > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
