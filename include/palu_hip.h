@@ -123,6 +123,36 @@ int palu_decode_step_f16(const void* hidden,
                          void* workspace, int Lcap, int H, int G, int D, int hidden_size, int Rk, int Rv,
                          int cache_len, int pos, palu_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * 3/4-bit latent quantisation (palu/model/modules/quant.py:5-41, reference defaults: asymmetric,
+ * one (scale, zero) per (token, head-group) row, clip 1.0 -- utils.py:103-108, svd_linear.py:124-139).
+ * The reference only fake-quantises; the packed layout is this build's:
+ *   codes [G, rows, R*bits/8] bytes: little-endian bit stream, code j at bits [j*bits,(j+1)*bits)
+ *   meta  [G, rows, 2] fp16: (scale, zero)
+ * Codes and dequantised values are bit-exact with quantize_tensor's fp16 arithmetic.
+ * x / dequant / out: [G, rows, R] fp16 with the given element strides; dequant may be NULL.
+ * bits = 4 needs R % 8 == 0, bits = 3 needs R % 32 == 0.  Byte strides for codes.
+ */
+size_t palu_packed_row_bytes(int R, int bits);
+int palu_quantize_pack(const void* x, int64_t sx_g, int64_t sx_l,
+                       void* codes, int64_t sc_g, int64_t sc_l, void* meta, int64_t sm_g, int64_t sm_l,
+                       void* dequant, int64_t sd_g, int64_t sd_l,
+                       int G, int nrows, int R, int bits, palu_stream_t stream);
+int palu_unpack_dequant(const void* codes, int64_t sc_g, int64_t sc_l, const void* meta, int64_t sm_g, int64_t sm_l,
+                        void* out, int64_t so_g, int64_t so_l, int G, int nrows, int R, int bits,
+                        palu_stream_t stream);
+/* raw integer pack/unpack of uint8 codes (ncodes % 8 == 0), bit-exact inverse pair */
+int palu_pack_codes(const void* codes_u8, void* packed, int64_t ncodes, int bits, palu_stream_t stream);
+int palu_unpack_codes(const void* packed, void* codes_u8, int64_t ncodes, int bits, palu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Hadamard: y = (x . H_n) * scale over the last dim of a [rows, n] array, Sylvester order, n = 2^m.
+ * Replaces fast_hadamard_transform.hadamard_transform (external CUDA op; call sites
+ * palu/model/modules/hadamard_utils.py:141,145,177).  dtype: 0 = fp16, 1 = fp32.  In place allowed.
+ */
+int palu_hadamard_transform(const void* x, void* y, int64_t rows, int n, float scale, int dtype,
+                            palu_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

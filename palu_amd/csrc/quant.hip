@@ -1,0 +1,213 @@
+// 3/4-bit latent quantisation: quantise+pack (cache append), unpack+dequantise, raw pack/unpack.
+//
+// The reference only has FAKE quantisation (palu/model/modules/quant.py:5-41 returns the
+// dequantised tensor; README.md:24 lists the packed kernel as TODO), so the bit layout is this
+// build's (DESIGN.md "packed latent format"):
+//   codes : per (group, position) row of R codes, little-endian bit stream, code j at bits
+//           [j*b, (j+1)*b) of the row  (b=4: two codes per byte; b=3: 32 codes per 3 uint32)
+//   meta  : per row one (scale, zero) pair of fp16  (asymmetric, whole-row groups: the reference
+//           defaults lt_group_size=0, lt_sym=False, lt_clip_ratio=1.0 of utils.py:103-108)
+// The integer codes and the dequantised values are BIT-EXACT with quantize_tensor's fp16
+// arithmetic: every op below is the fp32 op on fp16 operands rounded once to fp16, which is what
+// torch's CPU half kernels compute (and is exact-equivalent for +,-,*,/ since 24 >= 2*11+2).
+#include "palu_common.h"
+
+namespace {
+
+static __device__ __forceinline__ float r16(float x) { return (float)(h16)x; }  // round to fp16, keep as float
+
+// one wave per row; R <= 2048
+template <int BITS>
+__global__ __launch_bounds__(256) void quantize_pack_kernel(const h16* __restrict__ x, int64_t sx_g, int64_t sx_l,
+                                                            unsigned char* __restrict__ codes, int64_t sc_g, int64_t sc_l,
+                                                            h16* __restrict__ meta, int64_t sm_g, int64_t sm_l,
+                                                            h16* __restrict__ deq, int64_t sd_g, int64_t sd_l,
+                                                            int G, int nrows, int R) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wid >= (int64_t)G * nrows) return;
+  const int g = (int)(wid / nrows), l = (int)(wid % nrows);
+  const h16* row = x + g * sx_g + l * sx_l;
+  constexpr float QMAX = (float)((1 << BITS) - 1);
+  // each lane owns 32-code words: word wdx covers codes [32*wdx, 32*wdx+32)
+  float mx = -INFINITY, mn = INFINITY;
+  for (int j = lane; j < R; j += 64) {
+    float v = (float)row[j];
+    mx = fmaxf(mx, v);
+    mn = fminf(mn, v);
+  }
+  mx = wave_max(mx);
+  mn = -wave_max(-mn);
+  // quant.py:36-38: scales = (max-min).clamp(min=1e-5)/q_max ; base = round(-min/scales).clamp(0, q_max)
+  float range = r16(mx - mn);
+  const float floor16 = (float)(h16)1e-5f;   // the clamp constant is cast to fp16 (a subnormal)
+  range = fmaxf(range, floor16);
+  const float scale = r16(range / QMAX);
+  float zero = rintf(r16(-mn / scale));
+  zero = fminf(fmaxf(zero, 0.f), QMAX);
+  if (lane == 0) {
+    h16* m = meta + g * sm_g + l * sm_l;
+    m[0] = (h16)scale;
+    m[1] = (h16)zero;
+  }
+  unsigned char* crow = codes + g * sc_g + l * sc_l;
+  h16* drow = deq ? deq + g * sd_g + l * sd_l : nullptr;
+  // a lane packs 8 consecutive codes (one 3- or 4-byte unit) per step
+  for (int u = lane; u < (R >> 3); u += 64) {
+    unsigned bits = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float w = (float)row[8 * u + e];
+      // quant.py:39: clamp(round(w/scales) + base, q_min, q_max)
+      float q = r16(rintf(r16(w / scale)) + zero);
+      q = fminf(fmaxf(q, 0.f), QMAX);
+      bits |= (unsigned)q << (BITS * e);
+      if (drow) drow[8 * u + e] = (h16)(r16(q - zero) * scale);   // (q - base) * scales, fp16
+    }
+    unsigned char* d = crow + u * BITS;
+    if (BITS == 4) {
+      *reinterpret_cast<unsigned*>(d) = bits;
+    } else {
+      d[0] = (unsigned char)bits;
+      d[1] = (unsigned char)(bits >> 8);
+      d[2] = (unsigned char)(bits >> 16);
+    }
+  }
+}
+
+template <int BITS>
+__global__ __launch_bounds__(256) void unpack_dequant_kernel(const unsigned char* __restrict__ codes, int64_t sc_g,
+                                                             int64_t sc_l, const h16* __restrict__ meta, int64_t sm_g,
+                                                             int64_t sm_l, h16* __restrict__ out, int64_t so_g,
+                                                             int64_t so_l, int G, int nrows, int R) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per 8 codes
+  const int upr = R >> 3;
+  if (idx >= (int64_t)G * nrows * upr) return;
+  const int u = (int)(idx % upr);
+  const int64_t rl = idx / upr;
+  const int g = (int)(rl / nrows), l = (int)(rl % nrows);
+  const unsigned char* d = codes + g * sc_g + l * sc_l + u * BITS;
+  unsigned bits = (BITS == 4) ? *reinterpret_cast<const unsigned*>(d)
+                              : ((unsigned)d[0] | ((unsigned)d[1] << 8) | ((unsigned)d[2] << 16));
+  const h16* m = meta + g * sm_g + l * sm_l;
+  const float scale = (float)m[0], zero = (float)m[1];
+  h16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const float q = (float)((bits >> (BITS * e)) & ((1u << BITS) - 1));
+    o[e] = (h16)(r16(q - zero) * scale);
+  }
+  *reinterpret_cast<h16x8*>(out + g * so_g + l * so_l + 8 * u) = o;
+}
+
+template <int BITS>
+__global__ void pack_codes_kernel(const unsigned char* __restrict__ in, unsigned char* __restrict__ out, int64_t nunits) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= nunits) return;
+  unsigned bits = 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) bits |= ((unsigned)in[8 * u + e] & ((1u << BITS) - 1)) << (BITS * e);
+  unsigned char* d = out + u * BITS;
+#pragma unroll
+  for (int k = 0; k < BITS; ++k) d[k] = (unsigned char)(bits >> (8 * k));
+}
+
+template <int BITS>
+__global__ void unpack_codes_kernel(const unsigned char* __restrict__ in, unsigned char* __restrict__ out, int64_t nunits) {
+  const int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= nunits) return;
+  const unsigned char* d = in + u * BITS;
+  unsigned bits = 0;
+#pragma unroll
+  for (int k = 0; k < BITS; ++k) bits |= (unsigned)d[k] << (8 * k);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) out[8 * u + e] = (unsigned char)((bits >> (BITS * e)) & ((1u << BITS) - 1));
+}
+
+bool quant_shape_ok(int bits, int R) {
+  if (bits == 4) return R > 0 && R % 8 == 0;
+  if (bits == 3) return R > 0 && R % 32 == 0;
+  return false;
+}
+
+}  // namespace
+
+extern "C" size_t palu_packed_row_bytes(int R, int bits) { return quant_shape_ok(bits, R) ? (size_t)R * bits / 8 : 0; }
+
+extern "C" int palu_quantize_pack(const void* x, int64_t sx_g, int64_t sx_l, void* codes, int64_t sc_g, int64_t sc_l,
+                                  void* meta, int64_t sm_g, int64_t sm_l, void* dequant, int64_t sd_g, int64_t sd_l,
+                                  int G, int nrows, int R, int bits, palu_stream_t stream) {
+  PALU_REQUIRE(x && codes && meta && G > 0 && nrows >= 0, PALU_ERR_ARG, "quantize_pack: bad arguments");
+  PALU_REQUIRE(quant_shape_ok(bits, R), PALU_ERR_UNSUPPORTED,
+               "quantize_pack: bits must be 3 (R %% 32 == 0) or 4 (R %% 8 == 0), got bits=%d R=%d", bits, R);
+  PALU_REQUIRE(bits != 4 || (sc_g % 4 == 0 && sc_l % 4 == 0 && ((uintptr_t)codes & 3) == 0), PALU_ERR_ARG,
+               "quantize_pack: 4-bit rows must be 4-byte aligned");
+  PALU_REQUIRE(sm_l >= 2, PALU_ERR_ARG, "quantize_pack: meta rows hold (scale, zero)");
+  if (nrows == 0) return PALU_OK;
+  const int64_t waves = (int64_t)G * nrows;
+  dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (bits == 4)
+    hipLaunchKernelGGL(quantize_pack_kernel<4>, grid, block, 0, s, (const h16*)x, sx_g, sx_l, (unsigned char*)codes, sc_g,
+                       sc_l, (h16*)meta, sm_g, sm_l, (h16*)dequant, sd_g, sd_l, G, nrows, R);
+  else
+    hipLaunchKernelGGL(quantize_pack_kernel<3>, grid, block, 0, s, (const h16*)x, sx_g, sx_l, (unsigned char*)codes, sc_g,
+                       sc_l, (h16*)meta, sm_g, sm_l, (h16*)dequant, sd_g, sd_l, G, nrows, R);
+  PALU_LAUNCH_CHECK();
+  return PALU_OK;
+}
+
+extern "C" int palu_unpack_dequant(const void* codes, int64_t sc_g, int64_t sc_l, const void* meta, int64_t sm_g,
+                                   int64_t sm_l, void* out, int64_t so_g, int64_t so_l, int G, int nrows, int R, int bits,
+                                   palu_stream_t stream) {
+  PALU_REQUIRE(codes && meta && out && G > 0 && nrows >= 0, PALU_ERR_ARG, "unpack_dequant: bad arguments");
+  PALU_REQUIRE(quant_shape_ok(bits, R), PALU_ERR_UNSUPPORTED, "unpack_dequant: unsupported bits=%d R=%d", bits, R);
+  PALU_REQUIRE(so_g % 8 == 0 && so_l % 8 == 0 && ((uintptr_t)out & 15) == 0, PALU_ERR_ARG,
+               "unpack_dequant: output rows must be 16-byte aligned");
+  PALU_REQUIRE(bits != 4 || (sc_g % 4 == 0 && sc_l % 4 == 0 && ((uintptr_t)codes & 3) == 0), PALU_ERR_ARG,
+               "unpack_dequant: 4-bit rows must be 4-byte aligned");
+  if (nrows == 0) return PALU_OK;
+  const int64_t n = (int64_t)G * nrows * (R / 8);
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  if (bits == 4)
+    hipLaunchKernelGGL(unpack_dequant_kernel<4>, grid, block, 0, s, (const unsigned char*)codes, sc_g, sc_l,
+                       (const h16*)meta, sm_g, sm_l, (h16*)out, so_g, so_l, G, nrows, R);
+  else
+    hipLaunchKernelGGL(unpack_dequant_kernel<3>, grid, block, 0, s, (const unsigned char*)codes, sc_g, sc_l,
+                       (const h16*)meta, sm_g, sm_l, (h16*)out, so_g, so_l, G, nrows, R);
+  PALU_LAUNCH_CHECK();
+  return PALU_OK;
+}
+
+extern "C" int palu_pack_codes(const void* codes_u8, void* packed, int64_t ncodes, int bits, palu_stream_t stream) {
+  PALU_REQUIRE(codes_u8 && packed && ncodes >= 0 && ncodes % 8 == 0 && (bits == 3 || bits == 4), PALU_ERR_ARG,
+               "pack_codes: need bits in {3,4} and a multiple of 8 codes");
+  if (ncodes == 0) return PALU_OK;
+  const int64_t nu = ncodes / 8;
+  dim3 grid((unsigned)((nu + 255) / 256)), block(256);
+  if (bits == 4)
+    hipLaunchKernelGGL(pack_codes_kernel<4>, grid, block, 0, (hipStream_t)stream, (const unsigned char*)codes_u8,
+                       (unsigned char*)packed, nu);
+  else
+    hipLaunchKernelGGL(pack_codes_kernel<3>, grid, block, 0, (hipStream_t)stream, (const unsigned char*)codes_u8,
+                       (unsigned char*)packed, nu);
+  PALU_LAUNCH_CHECK();
+  return PALU_OK;
+}
+
+extern "C" int palu_unpack_codes(const void* packed, void* codes_u8, int64_t ncodes, int bits, palu_stream_t stream) {
+  PALU_REQUIRE(codes_u8 && packed && ncodes >= 0 && ncodes % 8 == 0 && (bits == 3 || bits == 4), PALU_ERR_ARG,
+               "unpack_codes: need bits in {3,4} and a multiple of 8 codes");
+  if (ncodes == 0) return PALU_OK;
+  const int64_t nu = ncodes / 8;
+  dim3 grid((unsigned)((nu + 255) / 256)), block(256);
+  if (bits == 4)
+    hipLaunchKernelGGL(unpack_codes_kernel<4>, grid, block, 0, (hipStream_t)stream, (const unsigned char*)packed,
+                       (unsigned char*)codes_u8, nu);
+  else
+    hipLaunchKernelGGL(unpack_codes_kernel<3>, grid, block, 0, (hipStream_t)stream, (const unsigned char*)packed,
+                       (unsigned char*)codes_u8, nu);
+  PALU_LAUNCH_CHECK();
+  return PALU_OK;
+}
