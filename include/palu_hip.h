@@ -153,6 +153,30 @@ int palu_unpack_codes(const void* packed, void* codes_u8, int64_t ncodes, int bi
 int palu_hadamard_transform(const void* x, void* y, int64_t rows, int n, float scale, int dtype,
                             palu_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Quantised-latent variants (3/4-bit codes + per-row (scale, zero), layout above).  The reference has
+ * no such kernels (README.md:24 TODO); semantics = the fp16 entry points applied to the fake-quantised
+ * latents quantize_tensor(x) (svd_linear.py:84-90,124-139), i.e. dequantised values bit-identical.
+ * abx_q supports (bits, R) in {(4,32), (4,64), (4,128), (3,128)}; softmax_pv_q needs Rv % 32 == 0,
+ * gs in {1,2,4}.  Byte strides for codes, element strides for meta.
+ */
+int palu_abx_rope_q(const void* a, int64_t sa_h, int64_t sa_d, const void* bfrag,
+                    const void* codes, int64_t sc_g, int64_t sc_l, const void* meta, int64_t sm_g, int64_t sm_l,
+                    void* out, int64_t so_h, int H, int G, int L, int R, int D, int bits,
+                    const float* inv_freq, int pos0, palu_stream_t stream);
+int palu_softmax_pv_q(const void* scores, int64_t ss_h, const void* mask,
+                      const void* codes, int64_t sc_g, int64_t sc_l, const void* meta, int64_t sm_g, int64_t sm_l,
+                      void* ctx, void* probs, int64_t sp_h, void* workspace,
+                      int H, int G, int L, int Rv, int bits, float sqrt_d, palu_stream_t stream);
+int palu_decode_step_q(const void* hidden,
+                       const void* wq, int64_t ldq, const void* vtk, int64_t ldk, const void* vtv, int64_t ldv,
+                       const void* bfrag, const void* wo, int64_t ldo,
+                       void* k_codes, int64_t skc_g, int64_t skc_l, void* k_meta, int64_t skm_g, int64_t skm_l,
+                       void* v_codes, int64_t svc_g, int64_t svc_l, void* v_meta, int64_t svm_g, int64_t svm_l,
+                       const void* mask, const float* inv_freq, void* out, void* probs, int64_t sp_h,
+                       void* workspace, int Lcap, int H, int G, int D, int hidden_size, int Rk, int Rv,
+                       int bits, int cache_len, int pos, palu_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

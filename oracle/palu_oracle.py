@@ -126,7 +126,7 @@ def fuse_uv_into_wo(wo: torch.Tensor, uv_weights, group_size: int, head_dim: int
 def decode_step(hidden: torch.Tensor, position: int, weights: Dict[str, torch.Tensor],
                 k_lat: torch.Tensor, v_lat: torch.Tensor,
                 attention_mask: Optional[torch.Tensor] = None,
-                theta: float = 10000.0, max_pos: Optional[int] = None):
+                theta: float = 10000.0, max_pos: Optional[int] = None, latent_bits: int = 16):
     """One-token decode of the low-rank attention module (batch 1), fp16 tensors on CPU.
 
     hidden [hidden] fp16; weights: wq [H*D,hidden], vt_k [G*Rk,hidden], vt_v [G*Rv,hidden],
@@ -148,6 +148,11 @@ def decode_step(hidden: torch.Tensor, position: int, weights: Dict[str, torch.Te
     q = torch.nn.functional.linear(h2, wq).reshape(H, 1, D)
     k_new = torch.nn.functional.linear(h2, vt_k).reshape(G, 1, Rk)
     v_new = torch.nn.functional.linear(h2, vt_v).reshape(G, 1, Rv)
+    if latent_bits < 16:
+        # accuracy-path semantics: project -> fake-quantise each (token, group) latent row -> attend
+        # (palu/model/modules/svd_linear.py:84-90,124-139); the caches passed in are already fake-quantised
+        k_new = quantize_rows(k_new.reshape(G, Rk), latent_bits)[0].reshape(G, 1, Rk)
+        v_new = quantize_rows(v_new.reshape(G, Rv), latent_bits)[0].reshape(G, 1, Rv)
     k_all = torch.cat((k_lat, k_new), dim=1)
     v_all = torch.cat((v_lat, v_new), dim=1)
     L = k_all.shape[1]

@@ -47,6 +47,11 @@ SIGNATURES = {
     "palu_gemv_f16": (i32, [vp, i64, vp, vp, i32, i32, vp]),
     "palu_decode_qkv_f16": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, vp, i64, i64, vp, i64, i64, vp,
                                   i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "palu_abx_rope_q": (i32, [vp, i64, i64, vp, vp, i64, i64, vp, i64, i64, vp, i64, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
+    "palu_softmax_pv_q": (i32, [vp, i64, vp, vp, i64, i64, vp, i64, i64, vp, vp, i64, vp, i32, i32, i32, i32, i32, f32, vp]),
+    "palu_decode_step_q": (i32, [vp, vp, i64, vp, i64, vp, i64, vp, vp, i64,
+                                 vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64,
+                                 vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "palu_packed_row_bytes": (sz, [i32, i32]),
     "palu_quantize_pack": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, vp]),
     "palu_unpack_dequant": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, vp]),

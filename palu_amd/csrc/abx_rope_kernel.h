@@ -1,0 +1,782 @@
+// abx_rope kernels (shared by abx_rope.hip [fp16 latents] and abx_rope_q.hip [3/4-bit latents])
+// abx_rope: fused  K = X.B  ->  RoPE  ->  q.K^T   for the low-rank latent key cache.
+//
+// Replaces the reference's only GPU kernel, Triton `_abx_fwd` (kernel/abx_rope.py:44-111) and
+// its launcher `abx` (:114-150); numerics follow the PyTorch oracle `torch_abx` (:152-171) with
+// fp32 kept through RoPE and the q-dot (one fp16 rounding at the store).
+//
+// MI355X design (not a translation of the Triton tiling):
+//   * one 512-thread workgroup (8 waves, 2 per SIMD) per CU, persistent over a contiguous
+//     range of 128-row tiles of one latent group g: the X tile is read from HBM exactly once
+//     and shared by all heads of the group through LDS;
+//   * the reconstruction is a dense [L x R].[R x gs*D] GEMM (arithmetic intensity gs*D = 512
+//     flop/byte > machine ridge), so it runs on MFMA: v_mfma_f32_32x32x16_f16 with
+//       A = rows of B^T held in REGISTERS for the whole kernel (B is a weight: wave w owns the
+//           8 RoPE pairs {8w..8w+7, 64+8w..64+8w+7} of every head of the block), pre-laid-out by
+//           abx_prepare_b so the prologue is 16-byte lane-linear loads,
+//       B = X rows read from LDS with one ds_read_b128 per 16-deep k-step (XOR-swizzled rows,
+//           conflict free), shared by all heads;
+//   * the M-rows of each MFMA are ordered (pair, head, half) so that a lane ends up holding
+//     k[i] and k[i+64] of 4 RoPE pairs x all heads for ONE position: the rotation coefficients
+//     are computed once per (position, pair) and reused by every head, the d-reduction is
+//     in-lane, then one cross-half shuffle and a cross-wave LDS sum;
+//   * RoPE angles follow the oracle exactly: angle = fl32(l * inv_freq) (kernel/
+//     pytorch_reference.py:5-6).  cos/sin of the exact product l*inv_freq are carried by a
+//     rotation recurrence (+32 positions per step) and corrected to the fp32-rounded angle by a
+//     second-order expansion in the (exactly computed) rounding residual.
+#pragma once
+#include <stdlib.h>
+
+#include "palu_common.h"
+
+namespace {
+
+constexpr int TL = 128;        // rows (cache positions) per tile
+constexpr int NTHREADS = 512;  // 8 waves
+constexpr int HEAD_DIM = 128;
+#ifndef PALU_ABX_PRIO
+#define PALU_ABX_PRIO 1
+#endif
+
+struct AbxParams {
+  const h16* a;
+  int64_t sa_h, sa_d;
+  const u32x4* bfrag;
+  const h16* x;
+  int64_t sx_g, sx_l;
+  h16* out;
+  int64_t so_h;
+  const float* inv_freq;
+  int H, G, gs, HB, L, R, pos0;
+  int nch;       // workgroups per (group, head-block)
+  int nt_total;  // number of 128-row tiles covering L
+  int nkc;       // 128-column chunks of R (chunked kernel only)
+  unsigned long long* dbg;  // optional per-wave cycle stamps (timing build only)
+  unsigned out_bytes;       // extent of `out` for the bounds-checked buffer store
+  int prio_mode;            // 0 none, 1 static (waves 4-7), 2 alternating per half tile
+  // quantised latents (QBITS > 0): packed codes [G, L, R*bits/8] + (scale, zero) fp16 pairs [G, L, 2]
+  const unsigned char* xq;
+  int64_t sq_g, sq_l;       // bytes
+  const h16* xmeta;
+  int64_t sm_g, sm_l;       // elements
+};
+
+// heads per workgroup = 2*NMB; each MFMA M-block carries 2 heads x 8 pairs x {i, i+64}
+inline int abx_nmb(int gs) { return gs >= 3 ? 2 : 1; }
+
+// ---------------------------------------------------------------------------------------------
+// B [H,R,D] -> MFMA A-operand fragments.
+// u32x4 index = ((((gb*8 + w)*NMB + mb)*NKS + ks)*64 + lane);  lane = m + 32*hi holds row m of the
+// M-block, k = 16*ks + 8*hi .. +7.  Row m  <->  u = m&1 (0: d=i, 1: d=i+64), t = (m>>1)&1 (head
+// 2*mb+t of the block), pair = m>>2 (i = 8*w + pair).  Invalid heads / r >= R are zero.
+__global__ void abx_prepare_b_kernel(const h16* __restrict__ b, int64_t sb_h, int64_t sb_r, int64_t sb_d,
+                                     int H, int G, int R, int nmb, int hb_per_g, int nks,
+                                     u32x4* __restrict__ out, int64_t total) {
+  int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int lane = (int)(idx & 63);
+  int64_t t = idx >> 6;
+  int ks = (int)(t % nks); t /= nks;
+  int mb = (int)(t % nmb); t /= nmb;
+  int w = (int)(t % 8); t /= 8;
+  int gb = (int)t;
+  int g = gb / hb_per_g, hb = gb % hb_per_g;
+  int m = lane & 31, hi = lane >> 5;
+  int u = m & 1, tt = (m >> 1) & 1, pair = m >> 2;
+  int gs = H / G;
+  int hloc = hb * (2 * nmb) + 2 * mb + tt;
+  bool valid = hloc < gs;
+  int h = g * gs + hloc;
+  int d = 8 * w + pair + 64 * u;
+  h16x8 v;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    int r = 16 * ks + 8 * hi + e;
+    v[e] = (valid && r < R) ? b[h * sb_h + r * sb_r + d * sb_d] : (h16)0.f;
+  }
+  out[idx] = *reinterpret_cast<u32x4*>(&v);
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int NKS>
+struct LdsGeom {
+  static constexpr int CPR = 2 * NKS;              // 16-byte chunks per LDS row
+  static constexpr int RB = 32 * NKS;              // LDS row bytes (power of two: NKS in {2,4,8})
+  static constexpr int TILE_BYTES = TL * RB;
+  static constexpr int SPT = TL * CPR / NTHREADS;  // staging slots per thread
+  static constexpr int RPB = 256 / RB;             // rows per 256-byte bank row
+  static constexpr int SH = (RPB == 4) ? 2 : (RPB == 2 ? 1 : 0);
+  static constexpr int MASK = CPR - 1;
+  // chunk position of global chunk c in LDS row `row` (XOR swizzle, an involution)
+  static __device__ __forceinline__ int swz(int row, int c) { return c ^ ((row >> SH) & MASK); }
+};
+
+
+// sin/cos of the EXACT product l*f (both fp32 values, product exact in fp64): two-term Cody-Waite
+// reduction in fp64 (|n| < 2^24 here), fp32 minimax polynomials on [-pi/4, pi/4] (abs err ~1e-7).
+static __device__ __forceinline__ void sincos_exact_product(float l, float f, float* s, float* c) {
+  const double x = (double)l * (double)f;
+  const double nd = __builtin_rint(x * 0.6366197723675814);
+  double rd = __builtin_fma(-nd, 1.5707963267948966, x);
+  rd = __builtin_fma(-nd, 6.123233995736766e-17, rd);
+  const float r = (float)rd;
+  const float r2 = r * r;
+  float sp = fmaf(r2, fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f), -1.6666654611e-1f);
+  sp = fmaf(r * r2, sp, r);
+  float cp = fmaf(r2, fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f), 4.166664568298827e-2f);
+  cp = fmaf(r2 * r2, cp, fmaf(-0.5f, r2, 1.0f));
+  const int q = (int)(long long)nd & 3;
+  const float ss = (q & 1) ? cp : sp;
+  const float cc = (q & 1) ? sp : cp;
+  *s = (q & 2) ? -ss : ss;
+  *c = ((q + 1) & 2) ? -cc : cc;
+}
+
+constexpr int abx_smem_fast(int nks) { return 3 * TL * 32 * nks + 3 * 8 * 4 * TL * (int)sizeof(float); }
+constexpr int abx_smem_bytes(int nks, int nred) { return 2 * TL * 32 * nks + nred * 8 * 4 * TL * (int)sizeof(float); }
+
+template <int NKS, int NMB, bool CHUNKED>
+__global__ __launch_bounds__(NTHREADS, 2) void abx_rope_generic_kernel(AbxParams p) {
+  using Geo = LdsGeom<NKS>;
+  constexpr int HPW = 2 * NMB;
+  constexpr int NACC = CHUNKED ? 4 : 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem + 2 * Geo::TILE_BYTES);  // [2][8][4][TL]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 31, hi = lane >> 5;
+
+  const int ngb = p.G * p.HB;
+  const int gb = blockIdx.x % ngb;
+  const int cidx = blockIdx.x / ngb;
+  const int g = gb / p.HB, hb = gb % p.HB;
+
+  // contiguous tile range of this workgroup
+  const int base = p.nt_total / p.nch, rem = p.nt_total % p.nch;
+  const int tile0 = cidx * base + min(cidx, rem);
+  const int ntile = base + (cidx < rem ? 1 : 0);
+  if (ntile <= 0) return;
+  const int NKC = CHUNKED ? p.nkc : 1;
+  const int nunit = ntile * NKC;
+  const int nks_tot = NKS * NKC;
+
+  const h16* xg = p.x + (int64_t)g * p.sx_g;
+
+  // ---- staging slots of this thread: LDS slot s = tid + 512*k  ->  (row, chunk position)
+  int st_row[Geo::SPT], st_col[Geo::SPT];
+#pragma unroll
+  for (int k = 0; k < Geo::SPT; ++k) {
+    int s = tid + NTHREADS * k;
+    int row = s / Geo::CPR, pp = s % Geo::CPR;
+    st_row[k] = row;
+    st_col[k] = Geo::swz(row, pp) * 8;  // global column (elements) inside the 16*NKS-wide chunk
+  }
+  u32x4 pf[Geo::SPT];
+  auto load_unit = [&](int u) {
+    int tt = u / NKC, kc = u - tt * NKC;
+    int row0 = (tile0 + tt) * TL;
+#pragma unroll
+    for (int k = 0; k < Geo::SPT; ++k) {
+      int l = min(row0 + st_row[k], p.L - 1);
+      int col = kc * (16 * NKS) + st_col[k];
+      const u32x4* src = reinterpret_cast<const u32x4*>(xg + (int64_t)l * p.sx_l + col);
+      if (CHUNKED && col >= p.R) {
+        pf[k] = u32x4{0u, 0u, 0u, 0u};
+      } else {
+        pf[k] = __builtin_nontemporal_load(src);
+      }
+    }
+  };
+  auto store_unit = [&](int buf) {
+    char* dst = smem + buf * Geo::TILE_BYTES;
+#pragma unroll
+    for (int k = 0; k < Geo::SPT; ++k)
+      *reinterpret_cast<u32x4*>(dst + (size_t)(tid + NTHREADS * k) * 16) = pf[k];
+  };
+
+  load_unit(0);
+
+  // ---- B fragments (registers for the whole kernel unless CHUNKED)
+  const u32x4* bf_base = p.bfrag + ((int64_t)(gb * 8 + w) * NMB) * nks_tot * 64 + lane;
+  h16x8 bf[NMB][NKS];
+  if (!CHUNKED) {
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        u32x4 v = bf_base[(int64_t)(mb * nks_tot + ks) * 64];
+        bf[mb][ks] = *reinterpret_cast<h16x8*>(&v);
+      }
+  }
+
+  // ---- query values of this lane's 4 pairs x HPW heads: (a[h][i], a[h][i+64]), i = 8w + 2j + hi
+  float q1[HPW][4], q2[HPW][4];
+#pragma unroll
+  for (int s = 0; s < HPW; ++s) {
+    int hloc = hb * HPW + s;
+    bool valid = hloc < p.gs;
+    int h = p.G > 0 ? g * p.gs + (valid ? hloc : 0) : 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int i = 8 * w + 2 * j + hi;
+      float v1 = (float)p.a[h * p.sa_h + i * p.sa_d];
+      float v2 = (float)p.a[h * p.sa_h + (i + 64) * p.sa_d];
+      q1[s][j] = valid ? v1 : 0.f;
+      q2[s][j] = valid ? v2 : 0.f;
+    }
+  }
+
+  // ---- RoPE state of this lane: position l = pos0 + row0 + n (+32 per block), 4 pairs
+  float fr[4], rc[4], rs[4], cs[4], sn[4];
+  float lf = (float)(p.pos0 + tile0 * TL + n);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    fr[j] = p.inv_freq[8 * w + 2 * j + hi];
+    float ang = lf * fr[j];
+    float lo = fmaf(lf, fr[j], -ang);  // exact: l*f = ang + lo
+    float so, co;
+    sincosf(ang, &so, &co);
+    float hh = 0.5f * lo * lo;
+    cs[j] = fmaf(-hh, co, fmaf(-lo, so, co));  // cos(ang + lo)
+    sn[j] = fmaf(-hh, so, fmaf(lo, co, so));   // sin(ang + lo)
+    sincosf(32.0f * fr[j], &rs[j], &rc[j]);
+  }
+
+  f32x16 acc[NACC][NMB];
+
+  store_unit(0);
+  if (nunit > 1) load_unit(1);
+
+  auto reduce_store = [&](int tt) {
+    // thread -> (head slot, position): sum the 8 waves' partials, round once to fp16
+    int slot = tid >> 7, pos = tid & 127;
+    if (slot < HPW) {
+      const float* r = red + (size_t)(tt & 1) * (8 * 4 * TL) + slot * TL + pos;
+      float s = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < 8; ++ww) s += r[ww * 4 * TL];
+      int l = (tile0 + tt) * TL + pos;
+      int hloc = hb * HPW + slot;
+      if (l < p.L && hloc < p.gs) p.out[(int64_t)(g * p.gs + hloc) * p.so_h + l] = (h16)s;
+    }
+  };
+
+  auto epilogue_block = [&](int tt, int blk, f32x16 (&ac)[NMB]) {
+    float part[HPW];
+#pragma unroll
+    for (int s = 0; s < HPW; ++s) part[s] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // coefficients at the oracle's fp32-rounded angle
+      float ang = lf * fr[j];
+      float lo = fmaf(lf, fr[j], -ang);  // exact angle = ang + lo  ->  want cos/sin(exact - lo)
+      float hh = 0.5f * lo * lo;
+      float cc = fmaf(-hh, cs[j], fmaf(lo, sn[j], cs[j]));
+      float ss = fmaf(-hh, sn[j], fmaf(-lo, cs[j], sn[j]));
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          float k1 = ac[mb][4 * j + 2 * t], k2 = ac[mb][4 * j + 2 * t + 1];
+          int s = 2 * mb + t;
+          float t1 = fmaf(q2[s][j], k2, q1[s][j] * k1);
+          float t2 = fmaf(-q1[s][j], k2, q2[s][j] * k1);
+          part[s] = fmaf(cc, t1, fmaf(ss, t2, part[s]));
+        }
+      // advance the exact-angle state by 32 positions
+      float c2 = fmaf(-sn[j], rs[j], cs[j] * rc[j]);
+      float s2 = fmaf(cs[j], rs[j], sn[j] * rc[j]);
+      cs[j] = c2;
+      sn[j] = s2;
+    }
+    lf += 32.0f;
+    float* rdst = red + (size_t)(tt & 1) * (8 * 4 * TL) + (size_t)w * (4 * TL) + blk * 32 + n;
+#pragma unroll
+    for (int s = 0; s < HPW; ++s) {
+      // lanes n and n+32 hold complementary pairs: swap halves in-register (no LDS round trip);
+      // both halves then hold the same sum and write the same word (benign duplicate store).
+      unsigned pv = __float_as_uint(part[s]);
+      auto sw = __builtin_amdgcn_permlane32_swap(pv, pv, false, false);
+      rdst[s * TL] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+  };
+
+  for (int u = 0; u < nunit; ++u) {
+    const int tt = u / NKC, kc = u - tt * NKC;
+    __syncthreads();
+    if (u + 1 < nunit) store_unit((u + 1) & 1);
+    if (u + 2 < nunit) load_unit(u + 2);
+    if (kc == 0 && tt > 0) reduce_store(tt - 1);
+
+    if (CHUNKED) {
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          u32x4 v = bf_base[(int64_t)(mb * nks_tot + kc * NKS + ks) * 64];
+          bf[mb][ks] = *reinterpret_cast<h16x8*>(&v);
+        }
+    }
+
+    const char* xs = smem + (u & 1) * Geo::TILE_BYTES;
+#pragma unroll
+    for (int blk = 0; blk < 4; ++blk) {
+      const int ai = CHUNKED ? blk : 0;
+      if (!CHUNKED || kc == 0) {
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[ai][mb][e] = 0.f;
+      }
+      const int row = blk * 32 + n;
+      const char* xrow = xs + row * Geo::RB;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const int c = Geo::swz(row, 2 * ks + hi);
+        h16x8 xf = *reinterpret_cast<const h16x8*>(xrow + c * 16);
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb)
+          acc[ai][mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[mb][ks], xf, acc[ai][mb], 0, 0, 0);
+      }
+      if (!CHUNKED) epilogue_block(tt, blk, acc[0]);
+    }
+    if (CHUNKED && kc == NKC - 1) {
+#pragma unroll
+      for (int blk = 0; blk < 4; ++blk) epilogue_block(tt, blk, acc[blk]);
+    }
+  }
+  __syncthreads();
+  reduce_store(ntile - 1);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Fast path: R in {32, 64, 128} (NKS = R/16 k-steps), B fragments register-resident.
+//
+// FOLD: the query is folded into the B fragments once per launch (in registers):
+//   P[r,i] = q_i B[r,i] + q_{i+64} B[r,i+64],  Q[r,i] = q_{i+64} B[r,i] - q_i B[r,i+64]
+// so that the MFMA directly produces U = x.P and V = x.Q and the score is sum_i cos*U + sin*V
+// (2 FMAs per pair and head instead of 6).  P and Q are rounded to fp16 (MFMA operands): one
+// extra operand rounding, the same size as the oracle's own fp16 rounding of K (abx_rope.py:164).
+//
+// Software pipeline: the MFMAs of block b+1 and the RoPE/reduction epilogue of block b are
+// independent instruction streams in one basic block (two accumulator sets), so the matrix pipe
+// and the VALU overlap inside a wave as well as across the two waves of a SIMD.
+template <int NKS, int NMB, bool FOLD, bool TIMING = false, int QBITS = 0>
+__global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
+  using Geo = LdsGeom<NKS>;
+  constexpr int HPW = 2 * NMB;
+  constexpr int NRING = 3;                // X tiles resident in LDS
+  constexpr int RED_STRIDE = 8 * 4 * TL;  // floats per red buffer: [8 waves][4 slots][TL]
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* red = reinterpret_cast<float*>(smem + NRING * Geo::TILE_BYTES);  // [3][8][4][TL]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 31, hi = lane >> 5;
+  int stamp_i = 0;
+  auto stamp = [&]() {
+    if (TIMING) {
+      unsigned long long t = __builtin_readcyclecounter();
+      if (lane == 0 && stamp_i < 64) p.dbg[((size_t)blockIdx.x * 8 + w) * 64 + stamp_i] = t;
+      ++stamp_i;
+    }
+  };
+  stamp();
+
+  const int ngb = p.G * p.HB;
+  const int gb = blockIdx.x % ngb;
+  const int cidx = blockIdx.x / ngb;
+  const int g = gb / p.HB, hb = gb % p.HB;
+
+  const int base = p.nt_total / p.nch, rem = p.nt_total % p.nch;
+  const int tile0 = cidx * base + min(cidx, rem);
+  const int ntile = base + (cidx < rem ? 1 : 0);
+  if (ntile <= 0) return;
+
+  const h16* xg = p.x + (int64_t)g * p.sx_g;
+
+  // ---- staging by LDS-DMA (global_load_lds_dwordx4): wave w, piece k fills the 64 consecutive 16-byte
+  //      LDS slots [512k + 64w, +64) of a tile; the XOR swizzle is applied to the per-lane SOURCE
+  //      address (the DMA destination is lane-linear).  Hidden from the compiler (inline asm), so the
+  //      completion wait is ours: s_waitcnt vmcnt(0) before the barrier that publishes the tile.
+  auto dma_tile = [&](int tt, int slot) {
+    const int row0 = (tile0 + tt) * TL;
+#pragma unroll
+    for (int k = 0; k < Geo::SPT; ++k) {
+      const int s = tid + NTHREADS * k;
+      const int row = s / Geo::CPR, pp = s % Geo::CPR;
+      const int l = min(row0 + row, p.L - 1);
+      const h16* src = xg + (int64_t)l * p.sx_l + Geo::swz(row, pp) * 8;
+      const unsigned dst = (unsigned)(slot * Geo::TILE_BYTES + (NTHREADS * k + 64 * w) * 16);
+      unsigned keep;
+      asm volatile(
+          "s_mov_b32 %0, m0\n\t"
+          "s_mov_b32 m0, %2\n\t"
+          "s_nop 0\n\t"
+          "global_load_lds_dwordx4 %1, off\n\t"
+          "s_mov_b32 m0, %0"
+          : "=&s"(keep)
+          : "v"(src), "s"(dst)
+          : "memory");
+    }
+  };
+  auto dma_wait = [&]() {
+    if (QBITS == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+
+  // ---- quantised staging (QBITS = 3/4): thread = (row = tid/4, quarter of the row); the packed codes of
+  //      tile t+3 travel in registers while tiles t..t+2 sit in the LDS ring; they are dequantised exactly
+  //      like quant.py:39 -- (code - zero) exact in fp16 via the 1024+code trick, one fp16 multiply by
+  //      scale -- and written to the same swizzled fp16 tile image the MFMA loop reads.
+  constexpr int CPQ = 4 * NKS;                               // codes per thread and tile (R/4)
+  constexpr int NW = QBITS ? (CPQ * QBITS) / 32 : 1;         // packed dwords per thread and tile
+  static_assert(QBITS == 0 || (CPQ * QBITS) % 32 == 0, "packed quarter rows must be whole dwords");
+  unsigned qraw[NW];
+  unsigned qmeta = 0;
+  const unsigned char* xqg = QBITS ? p.xq + (int64_t)g * p.sq_g : nullptr;
+  const h16* xmg = QBITS ? p.xmeta + (int64_t)g * p.sm_g : nullptr;
+  auto load_q = [&](int tt) {
+    const int row = tid >> 2, quarter = tid & 3;
+    const int l = min((tile0 + tt) * TL + row, p.L - 1);
+    const unsigned* src = reinterpret_cast<const unsigned*>(xqg + (int64_t)l * p.sq_l) + quarter * NW;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) qraw[k] = __builtin_nontemporal_load(src + k);
+    qmeta = *reinterpret_cast<const unsigned*>(xmg + (int64_t)l * p.sm_l);
+  };
+  auto store_q = [&](int slot) {
+    const int row = tid >> 2, quarter = tid & 3;
+    const h16x2 m2 = __builtin_bit_cast(h16x2, qmeta);
+    const h16x2 scale2 = h16x2{m2[0], m2[0]};
+    const h16 nb = -((h16)1024.f + m2[1]);                  // exact: zero is an integer in [0, 15]
+    const h16x2 negbias2 = h16x2{nb, nb};
+    char* dst = smem + slot * Geo::TILE_BYTES + row * Geo::RB;
+#pragma unroll
+    for (int gq = 0; gq < CPQ / 8; ++gq) {
+      unsigned grp;                                          // 8 codes, code e at bits [QBITS*e, +QBITS)
+      if (QBITS == 4) {
+        grp = qraw[gq];
+      } else {
+        grp = gq == 0 ? qraw[0]
+            : gq == 1 ? __builtin_amdgcn_alignbit(qraw[1 % NW], qraw[0], 24)
+            : gq == 2 ? __builtin_amdgcn_alignbit(qraw[2 % NW], qraw[1 % NW], 16)
+                      : (qraw[2 % NW] >> 8);
+      }
+      u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned c0 = (grp >> (QBITS * (2 * e))) & ((1u << QBITS) - 1);
+        const unsigned c1 = (grp >> (QBITS * (2 * e + 1))) & ((1u << QBITS) - 1);
+        const unsigned pw = 0x64006400u | c0 | (c1 << 16);   // (1024 + c0, 1024 + c1) as fp16
+        h16x2 v = __builtin_bit_cast(h16x2, pw);
+        v = (v + negbias2) * scale2;
+        o[e] = __builtin_bit_cast(unsigned, v);
+      }
+      const int c = quarter * (CPQ / 8) + gq;
+      *reinterpret_cast<u32x4*>(dst + Geo::swz(row, c) * 16) = o;
+    }
+  };
+
+  if (QBITS == 0) {
+    dma_tile(0, 0);
+    dma_tile(min(1, ntile - 1), 1);
+  } else {
+    load_q(0);
+    store_q(0);
+    load_q(min(1, ntile - 1));
+    store_q(1);
+    load_q(min(2, ntile - 1));
+  }
+
+  // ---- B fragments (issued early; consumed by the fold / first MFMA)
+  const u32x4* bf_base = p.bfrag + ((int64_t)(gb * 8 + w) * NMB) * NKS * 64 + lane;
+  h16x8 bf[NMB][NKS];
+#pragma unroll
+  for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      u32x4 v = bf_base[(int64_t)(mb * NKS + ks) * 64];
+      bf[mb][ks] = *reinterpret_cast<h16x8*>(&v);
+    }
+
+  stamp();  // 1: B loads issued
+  // ---- RoPE state of this lane (C layout: position n, pairs i = 8w + 2j + hi), started one block
+  //      early because the pipeline runs one (discarded) epilogue before the first real block.
+  float fr[4], rc[4], rs[4], cs[4], sn[4];
+  float lf = (float)(p.pos0 + tile0 * TL + n - 32);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    fr[j] = p.inv_freq[8 * w + 2 * j + hi];
+    sincos_exact_product(lf, fr[j], &sn[j], &cs[j]);
+    sincos_exact_product(32.0f, fr[j], &rs[j], &rc[j]);
+  }
+
+  stamp();  // 2: rope init done
+  // ---- query: either folded into the fragments (FOLD) or kept per (pair, head) for the epilogue
+  float q1[FOLD ? 1 : HPW][4], q2[FOLD ? 1 : HPW][4];
+  if (FOLD) {
+    // A-fragment lane = row m of the M-block: u = m&1, t = (m>>1)&1, pair = m>>2.
+    //   row u=0 (B[:,i])    <- P = q_i B[:,i] + q_{i+64} B[:,i+64]
+    //   row u=1 (B[:,i+64]) <- Q = q_{i+64} B[:,i] - q_i B[:,i+64]
+    // i.e. new = c_own*own + q_{i+64}*partner with c_own = +/-q_i; partner row = lane^1 (DPP).
+    // v_dot2_f32_f16: both products exact in fp32, one rounding to fp16 at the end.
+    const int m = lane & 31;
+    const int u = m & 1, t = (m >> 1) & 1, pair = m >> 2;
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+      int hloc = hb * HPW + 2 * mb + t;
+      bool valid = hloc < p.gs;
+      int h = g * p.gs + (valid ? hloc : 0);
+      int i = 8 * w + pair;
+      h16 qi = valid ? p.a[h * p.sa_h + i * p.sa_d] : (h16)0.f;
+      h16 qj = valid ? p.a[h * p.sa_h + (i + 64) * p.sa_d] : (h16)0.f;
+      h16x2 coef;
+      coef[0] = u ? -qi : qi;
+      coef[1] = qj;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        u32x4 own = __builtin_bit_cast(u32x4, bf[mb][ks]);
+        u32x4 res;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          unsigned ow = own[e];
+          unsigned par = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ow, 0xB1, 0xF, 0xF, false);  // lane^1
+          unsigned lo2 = __builtin_amdgcn_perm(par, ow, 0x05040100u);  // (own.lo, par.lo)
+          unsigned hi2 = __builtin_amdgcn_perm(par, ow, 0x07060302u);  // (own.hi, par.hi)
+          float r0 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, lo2), coef, 0.f, false);
+          float r1 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, hi2), coef, 0.f, false);
+          h16x2 r2;
+          r2[0] = (h16)r0;
+          r2[1] = (h16)r1;
+          res[e] = __builtin_bit_cast(unsigned, r2);
+        }
+        bf[mb][ks] = __builtin_bit_cast(h16x8, res);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < HPW; ++s) {
+      int hloc = hb * HPW + s;
+      bool valid = hloc < p.gs;
+      int h = g * p.gs + (valid ? hloc : 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int i = 8 * w + 2 * j + hi;
+        float v1 = (float)p.a[h * p.sa_h + i * p.sa_d];
+        float v2 = (float)p.a[h * p.sa_h + (i + 64) * p.sa_d];
+        q1[s][j] = valid ? v1 : 0.f;
+        q2[s][j] = valid ? v2 : 0.f;
+      }
+    }
+  }
+
+  // scores leave through a buffer store: invalid (row >= L, padded head, pipeline warm-up) lanes get an
+  // out-of-range offset that the hardware drops, so the store needs no branch inside the MFMA stream
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+
+  auto reduce_store = [&](int tt) {
+    const int slot = tid >> 7, pos = tid & 127;
+    const float* r = red + (size_t)((tt + 3) % 3) * RED_STRIDE + (slot & 3) * TL + pos;
+    float s = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 8; ++ww) s += r[ww * 4 * TL];
+    const int l = (tile0 + tt) * TL + pos;
+    const int hloc = hb * HPW + slot;
+    const bool ok = tt >= 0 && slot < HPW && l < p.L && hloc < p.gs;
+    const unsigned off = ok ? (unsigned)(((int64_t)(g * p.gs + hloc) * p.so_h + l) * 2) : 0xFFFFFFF0u;
+    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (h16)s), orsrc, off, 0, 0);
+  };
+
+  // X fragments are prefetched XD k-steps ahead through a ring of XD registers-sets: the fragment of
+  // k-step ks lives in xf[ks % XD] and is refilled with the fragment XD k-steps later (possibly of the
+  // next block) right after its MFMAs have issued -> LDS latency never sits in front of an MFMA.
+  constexpr int XD = NKS < 4 ? NKS : 4;
+  h16x8 xf[XD];
+  auto read_frag = [&](const char* xs, int blk, int ks) {
+    const int row = blk * 32 + n;
+    return *reinterpret_cast<const h16x8*>(xs + row * Geo::RB + Geo::swz(row, 2 * ks + hi) * 16);
+  };
+  auto load_xf = [&](const char* xs, int blk) {
+#pragma unroll
+    for (int ks = 0; ks < XD; ++ks) xf[ks] = read_frag(xs, blk, ks);
+  };
+  // MFMAs of one 32-row block (this tile `xs`, block `blk`); (nxs, nblk) = the block that follows
+  auto mfma_block = [&](f32x16 (&ac)[NMB], const char* xs, int blk, const char* nxs, int nblk) {
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) ac[mb][e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb)
+        ac[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[mb][ks], xf[ks % XD], ac[mb], 0, 0, 0);
+      xf[ks % XD] = (ks + XD < NKS) ? read_frag(xs, blk, ks + XD) : read_frag(nxs, nblk, ks + XD - NKS);
+    }
+  };
+
+  auto epilogue = [&](int tt, int blk, const f32x16 (&ac)[NMB]) {
+    float part[HPW];
+#pragma unroll
+    for (int s = 0; s < HPW; ++s) part[s] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // cos/sin at the oracle's fp32-rounded angle ang = fl(l*f): exact angle = ang + lo, |lo| <= ulp(ang)/2
+      // (first order in lo; the dropped term lo^2/2 is < 3.1e-5 for positions < 2^18)
+      float ang = lf * fr[j];
+      float lo = fmaf(lf, fr[j], -ang);
+      float cc = fmaf(lo, sn[j], cs[j]);
+      float ss = fmaf(-lo, cs[j], sn[j]);
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          float k1 = ac[mb][4 * j + 2 * t], k2 = ac[mb][4 * j + 2 * t + 1];
+          int s = 2 * mb + t;
+          if (FOLD) {
+            part[s] = fmaf(cc, k1, fmaf(ss, k2, part[s]));
+          } else {
+            float t1 = fmaf(q2[s][j], k2, q1[s][j] * k1);
+            float t2 = fmaf(-q1[s][j], k2, q2[s][j] * k1);
+            part[s] = fmaf(cc, t1, fmaf(ss, t2, part[s]));
+          }
+        }
+      float c2 = fmaf(-sn[j], rs[j], cs[j] * rc[j]);  // advance the exact-angle state by 32 positions
+      float s2 = fmaf(cs[j], rs[j], sn[j] * rc[j]);
+      cs[j] = c2;
+      sn[j] = s2;
+    }
+    lf += 32.0f;
+    float* rdst = red + (size_t)((tt + 3) % 3) * RED_STRIDE + (size_t)w * (4 * TL) + blk * 32 + n;
+#pragma unroll
+    for (int s = 0; s < HPW; ++s) {
+      // lanes n and n+32 hold complementary pairs: swap halves in-register; both halves then hold
+      // the same sum and write the same word (benign duplicate store, keeps the block branch-free)
+      unsigned pv = __float_as_uint(part[s]);
+      auto sw = __builtin_amdgcn_permlane32_swap(pv, pv, false, false);
+      rdst[s * TL] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
+  };
+
+  f32x16 accA[NMB], accB[NMB];
+#pragma unroll
+  for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) accB[mb][e] = 0.f;
+
+  stamp();  // 3: fold done
+
+  // the second-dispatched half of the workgroup loses issue arbitration on every segment
+  // (priority, then age): give it static priority so both waves of a SIMD finish together
+  const bool young = w >= 4;
+  if (p.prio_mode == 1 && young) __builtin_amdgcn_s_setprio(1);
+
+  dma_wait();
+  stamp();  // 4: first tiles landed
+  __syncthreads();
+  load_xf(smem, 0);
+
+  for (int tt = 0; tt < ntile; ++tt) {
+    stamp();  // 5+2*tt: arrive at barrier
+    if (tt > 0) {
+      dma_wait();  // this wave's pieces of tile tt+1 have landed -> published by the barrier
+      __syncthreads();
+    }
+    stamp();  // 6+2*tt: leave barrier
+    if (p.prio_mode == 2 && young) __builtin_amdgcn_s_setprio(1);  // young half leads the first half tile
+    // one straight-line region per tile: MFMAs of block b+1, RoPE epilogue of block b, staging of tile
+    // tt+2 into the ring, prefetch of tile tt+3, cross-wave reduction + store of tile tt-2
+    const char* xs = smem + (tt % NRING) * Geo::TILE_BYTES;
+    const char* xn = smem + ((tt + 1) % NRING) * Geo::TILE_BYTES;
+    mfma_block(accA, xs, 0, xs, 1);
+    if (QBITS == 0) {
+      dma_tile(min(tt + 2, ntile - 1), (tt + 2) % NRING);
+    } else {
+      store_q((tt + 2) % NRING);              // registers hold tile min(tt+2, ntile-1)
+      load_q(min(tt + 3, ntile - 1));
+    }
+    epilogue(tt - 1, 3, accB);  // tt == 0: discarded (writes a slot that is rewritten before use)
+    __builtin_amdgcn_sched_barrier(0);  // keep each {MFMA block b+1, epilogue b} pair its own scheduling region
+    mfma_block(accB, xs, 1, xs, 2);
+    reduce_store(tt - 2);
+    epilogue(tt, 0, accA);
+    __builtin_amdgcn_sched_barrier(0);
+    if (p.prio_mode == 2 && young) __builtin_amdgcn_s_setprio(0);  // ... the old half catches up in the second
+    mfma_block(accA, xs, 2, xs, 3);
+    epilogue(tt, 1, accB);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block(accB, xs, 3, xn, 0);  // prefetches block 0 of the next tile (staged one barrier ago)
+    epilogue(tt, 2, accA);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  epilogue(ntile - 1, 3, accB);
+  stamp();
+  dma_wait();
+  __syncthreads();
+  reduce_store(ntile - 2);
+  reduce_store(ntile - 1);
+  stamp();
+}
+
+
+template <typename K>
+int launch_kernel(K kern, int smem, bool* attr_done, const AbxParams& p, int nwg, hipStream_t stream) {
+  if (!*attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) {
+      palu_set_error("hipFuncSetAttribute(%d B LDS) failed: %s", smem, hipGetErrorString(e));
+      return PALU_ERR_LAUNCH;
+    }
+    *attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), smem, stream, p);
+  PALU_LAUNCH_CHECK();
+  return PALU_OK;
+}
+
+struct AbxPlan {
+  int gs, nmb, hpw, hb, nks_tot, nkc;
+  bool chunked;
+};
+
+inline bool abx_plan(int H, int G, int R, AbxPlan* pl) {
+  if (H <= 0 || G <= 0 || H % G != 0 || R <= 0 || R % 8 != 0) return false;
+  pl->gs = H / G;
+  pl->nmb = abx_nmb(pl->gs);
+  pl->hpw = 2 * pl->nmb;
+  pl->hb = (pl->gs + pl->hpw - 1) / pl->hpw;
+  pl->chunked = !(R == 32 || R == 64 || R == 128);
+  pl->nkc = pl->chunked ? (R + 127) / 128 : 1;
+  pl->nks_tot = pl->chunked ? 8 * pl->nkc : R / 16;
+  return true;
+}
+
+inline int abx_prio_mode() {
+  static int m = -1;
+  if (m < 0) {
+    const char* e = getenv("PALU_ABX_PRIO_MODE");
+    m = e ? atoi(e) : 2;
+  }
+  return m;
+}
+
+// fills the launch-independent part of the parameters; returns the number of workgroups
+inline int abx_fill_params(AbxParams& p, const AbxPlan& pl, int H, int G, int L, int R, int pos0) {
+  p.H = H; p.G = G; p.gs = pl.gs; p.HB = pl.hb; p.L = L; p.R = R; p.pos0 = pos0;
+  p.nt_total = (L + TL - 1) / TL;
+  p.nkc = pl.nkc;
+  p.dbg = nullptr;
+  p.prio_mode = abx_prio_mode();
+  const int ngb = G * pl.hb;
+  int nch = palu_num_cus() / ngb;   // one 8-wave workgroup per CU
+  if (nch < 1) nch = 1;
+  if (nch > p.nt_total) nch = p.nt_total;
+  p.nch = nch;
+  return nch * ngb;
+}
+
+}  // namespace

@@ -1,0 +1,52 @@
+// abx on QUANTISED latent keys: same kernel as abx_rope.hip with the tile staging replaced by
+// packed-code loads + in-register dequantisation (abx_rope_kernel.h, QBITS = 3/4).  The dequantised
+// fp16 values are bit-identical to the reference's fake-quant output (quant.py:39), so scores equal
+// those of the fp16 kernel run on quantize_tensor(x).  Flops are unchanged (the kernel is MFMA-bound);
+// only the HBM bytes shrink (32.5 MB at C3 instead of 139.5 MB).
+#include "abx_rope_kernel.h"
+
+namespace {
+template <int NKS, int NMB, int QBITS>
+int launch_abx_q(const AbxParams& p, int nwg, hipStream_t stream) {
+  static bool attr_done = false;
+  return launch_kernel(abx_rope_kernel<NKS, NMB, true, false, QBITS>, abx_smem_fast(NKS), &attr_done, p, nwg, stream);
+}
+}  // namespace
+
+extern "C" int palu_abx_rope_q(const void* a, int64_t sa_h, int64_t sa_d, const void* bfrag, const void* codes,
+                               int64_t sc_g, int64_t sc_l, const void* meta, int64_t sm_g, int64_t sm_l, void* out,
+                               int64_t so_h, int H, int G, int L, int R, int D, int bits, const float* inv_freq,
+                               int pos0, palu_stream_t stream) {
+  AbxPlan pl;
+  PALU_REQUIRE(abx_plan(H, G, R, &pl), PALU_ERR_ARG, "abx_q: bad shape H=%d G=%d R=%d", H, G, R);
+  PALU_REQUIRE(D == HEAD_DIM, PALU_ERR_UNSUPPORTED, "abx_q: head_dim must be 128 (got %d)", D);
+  PALU_REQUIRE((bits == 4 && (R == 32 || R == 64 || R == 128)) || (bits == 3 && R == 128), PALU_ERR_UNSUPPORTED,
+               "abx_q: supported (bits, R): (4, 32|64|128), (3, 128); got (%d, %d)", bits, R);
+  PALU_REQUIRE(L >= 0, PALU_ERR_ARG, "abx_q: negative L");
+  if (L == 0) return PALU_OK;
+  PALU_REQUIRE(a && bfrag && codes && meta && out && inv_freq, PALU_ERR_ARG, "abx_q: null pointer");
+  PALU_REQUIRE(((uintptr_t)codes & 3) == 0 && sc_g % 4 == 0 && sc_l % 4 == 0 && sc_l >= (int64_t)R * bits / 8,
+               PALU_ERR_ARG, "abx_q: packed rows must be 4-byte aligned");
+  PALU_REQUIRE(((uintptr_t)meta & 3) == 0 && sm_g % 2 == 0 && sm_l % 2 == 0 && sm_l >= 2, PALU_ERR_ARG,
+               "abx_q: meta rows must be 4-byte aligned (scale, zero) pairs");
+  PALU_REQUIRE(((uintptr_t)bfrag & 15) == 0, PALU_ERR_ARG, "abx_q: bfrag must be 16-byte aligned");
+  PALU_REQUIRE((int64_t)pos0 + L < (1 << 24), PALU_ERR_UNSUPPORTED, "abx_q: positions must stay below 2^24");
+  const int64_t ob = ((int64_t)(H - 1) * so_h + L) * 2;
+  PALU_REQUIRE(ob > 0 && ob < 0xFFFFFFF0ll, PALU_ERR_UNSUPPORTED, "abx_q: out extent must be < 4 GiB");
+
+  AbxParams p = {};
+  p.a = (const h16*)a; p.sa_h = sa_h; p.sa_d = sa_d;
+  p.bfrag = (const u32x4*)bfrag;
+  p.xq = (const unsigned char*)codes; p.sq_g = sc_g; p.sq_l = sc_l;
+  p.xmeta = (const h16*)meta; p.sm_g = sm_g; p.sm_l = sm_l;
+  p.out = (h16*)out; p.so_h = so_h; p.out_bytes = (unsigned)ob;
+  p.inv_freq = inv_freq;
+  const int nwg = abx_fill_params(p, pl, H, G, L, R, pos0);
+  hipStream_t s = (hipStream_t)stream;
+  if (bits == 3) return pl.nmb == 2 ? launch_abx_q<8, 2, 3>(p, nwg, s) : launch_abx_q<8, 1, 3>(p, nwg, s);
+  switch (R) {
+    case 32: return pl.nmb == 2 ? launch_abx_q<2, 2, 4>(p, nwg, s) : launch_abx_q<2, 1, 4>(p, nwg, s);
+    case 64: return pl.nmb == 2 ? launch_abx_q<4, 2, 4>(p, nwg, s) : launch_abx_q<4, 1, 4>(p, nwg, s);
+    default: return pl.nmb == 2 ? launch_abx_q<8, 2, 4>(p, nwg, s) : launch_abx_q<8, 1, 4>(p, nwg, s);
+  }
+}

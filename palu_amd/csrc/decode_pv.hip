@@ -169,6 +169,173 @@ __global__ __launch_bounds__(PV_THREADS) void pv_partial_kernel(PvParams p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Quantised V latents (3/4-bit codes + per-row (scale, zero), quant.hip layout).  Same split-L scheme;
+// a thread owns a 32-code chunk of the row (16 B at 4 bit, 12 B at 3 bit).  Dequantisation is folded
+// into the accumulation:  sum_l p_l (c_l - z_l) s_l = sum_l (p_l s_l) c_l  -  sum_l p_l s_l z_l
+// so the inner loop is: extract code, int->float, one FMA per head; the second term is one FMA per row.
+struct PvQParams {
+  const h16* scores;
+  int64_t ss_h;
+  const h16* mask;
+  const unsigned char* codes;  // [G, L, Rv*bits/8]
+  int64_t sc_g, sc_l;          // bytes
+  const h16* meta;             // [G, L, 2]
+  int64_t sm_g, sm_l;          // elements
+  float* part;
+  float* ml;
+  int G, gs, L, Rv, nsplit, rps;
+  float inv_scale;
+};
+
+template <int BITS>
+struct QChunk {
+  unsigned w[BITS];   // 32 codes = BITS dwords
+  unsigned meta;      // (scale, zero) fp16 pair
+};
+
+template <int GS, int BITS>
+__global__ __launch_bounds__(PV_THREADS) void pv_partial_q_kernel(PvQParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* pl = reinterpret_cast<float*>(smem_raw);
+  __shared__ float sh[4];
+  const int tid = threadIdx.x;
+  const int g = blockIdx.x % p.G;
+  const int split = blockIdx.x / p.G;
+  const int l0 = split * p.rps;
+  const int n = max(0, min(p.L - l0, p.rps));
+  float* ml = p.ml + ((size_t)(g * p.nsplit + split) * GS) * 2;
+  float* part = p.part + (size_t)(g * p.nsplit + split) * GS * p.Rv;
+
+  const int cpr = p.Rv >> 5;            // 32-code chunks per row
+  const int rpp = PV_THREADS / cpr;
+  const int rg = tid / cpr, cc = tid - rg * cpr;
+  const bool streamer = rg < rpp;
+  constexpr int U = 2;
+  const unsigned char* cb = p.codes + (int64_t)g * p.sc_g + (int64_t)l0 * p.sc_l + cc * (4 * BITS);
+  const h16* mb = p.meta + (int64_t)g * p.sm_g + (int64_t)l0 * p.sm_l;
+  const int nlast = max(n - 1, 0);
+  auto load_batch = [&](QChunk<BITS> (&raw)[U], int i) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = min(i + u * rpp, nlast);
+      const unsigned* src = reinterpret_cast<const unsigned*>(cb + (int64_t)r * p.sc_l);
+#pragma unroll
+      for (int k = 0; k < BITS; ++k) raw[u].w[k] = __builtin_nontemporal_load(src + k);
+      raw[u].meta = *reinterpret_cast<const unsigned*>(mb + (int64_t)r * p.sm_l);
+    }
+  };
+  QChunk<BITS> rawA[U], rawB[U];
+  if (streamer) load_batch(rawA, rg);
+
+  float mloc[GS], sloc[GS];
+#pragma unroll
+  for (int h = 0; h < GS; ++h) {
+    const h16* sc = p.scores + (int64_t)(g * GS + h) * p.ss_h + l0;
+    float mx = -INFINITY;
+    for (int i = tid; i < n; i += PV_THREADS) {
+      float x = scaled_logit(sc[i], p.inv_scale, p.mask, l0 + i);
+      pl[h * p.rps + i] = x;
+      mx = fmaxf(mx, x);
+    }
+    mx = block_max(mx, sh, tid);
+    float sm = 0.f;
+    for (int i = tid; i < n; i += PV_THREADS) {
+      float e = (mx == -INFINITY) ? 0.f : __expf(pl[h * p.rps + i] - mx);
+      pl[h * p.rps + i] = e;
+      sm += e;
+    }
+    sm = block_sum(sm, sh, tid);
+    mloc[h] = mx;
+    sloc[h] = sm;
+  }
+  if (tid == 0) {
+#pragma unroll
+    for (int h = 0; h < GS; ++h) {
+      ml[2 * h] = mloc[h];
+      ml[2 * h + 1] = sloc[h];
+    }
+  }
+  __syncthreads();
+
+  float acc[GS][32];
+  float corr[GS];
+#pragma unroll
+  for (int h = 0; h < GS; ++h) {
+    corr[h] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) acc[h][j] = 0.f;
+  }
+  auto consume = [&](const QChunk<BITS> (&raw)[U], int i) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const unsigned mw = raw[u].meta;
+      const h16x2 m2 = __builtin_bit_cast(h16x2, mw);
+      const float sc = (float)m2[0], zp = (float)m2[1];
+      const bool ok = i + u * rpp < n;
+      const int row = min(i + u * rpp, p.rps - 1);
+      float wgt[GS];
+#pragma unroll
+      for (int h = 0; h < GS; ++h) {
+        wgt[h] = ok ? pl[h * p.rps + row] * sc : 0.f;
+        corr[h] = fmaf(wgt[h], zp, corr[h]);
+      }
+      // 8 codes per 4*BITS-bit group
+      unsigned grp[4];
+      if (BITS == 4) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) grp[k] = raw[u].w[k];
+      } else {
+        grp[0] = raw[u].w[0];
+        grp[1] = __builtin_amdgcn_alignbit(raw[u].w[1], raw[u].w[0], 24);
+        grp[2] = __builtin_amdgcn_alignbit(raw[u].w[2], raw[u].w[1], 16);
+        grp[3] = raw[u].w[2] >> 8;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float c = (float)((grp[k] >> (BITS * e)) & ((1u << BITS) - 1));
+#pragma unroll
+          for (int h = 0; h < GS; ++h) acc[h][8 * k + e] = fmaf(wgt[h], c, acc[h][8 * k + e]);
+        }
+    }
+  };
+  if (streamer) {
+    const int stride = U * rpp;
+    int i = rg;
+    for (;;) {
+      load_batch(rawB, i + stride);
+      consume(rawA, i);
+      i += stride;
+      if (i >= n) break;
+      load_batch(rawA, i + stride);
+      consume(rawB, i);
+      i += stride;
+      if (i >= n) break;
+    }
+  }
+  // ---- cross-row-group reduction, one head per pass through a [threads][32] LDS buffer
+  float* redb = pl;
+#pragma unroll
+  for (int h = 0; h < GS; ++h) {
+    __syncthreads();
+    if (streamer) {
+#pragma unroll
+      for (int j = 0; j < 32; j += 4)
+        *reinterpret_cast<f32x4*>(redb + (size_t)tid * 32 + j) =
+            f32x4{acc[h][j] - corr[h], acc[h][j + 1] - corr[h], acc[h][j + 2] - corr[h], acc[h][j + 3] - corr[h]};
+    }
+    __syncthreads();
+    for (int r = tid; r < p.Rv; r += PV_THREADS) {
+      const int c = r >> 5, j = r & 31;
+      float s = 0.f;
+      for (int q = 0; q < rpp; ++q) s += redb[(size_t)(q * cpr + c) * 32 + j];
+      part[h * p.Rv + r] = s;
+    }
+  }
+}
+
 struct CombineParams {
   const float* part;
   const float* ml;
@@ -299,6 +466,60 @@ extern "C" int palu_softmax_pv_f16(const void* scores, int64_t ss_h, const void*
     case 4: hipLaunchKernelGGL(pv_partial_kernel<4>, grid, block, lds, s, p); break;
     default: hipLaunchKernelGGL(pv_partial_kernel<8>, grid, block, lds, s, p); break;
   }
+  PALU_LAUNCH_CHECK();
+  CombineParams c;
+  c.part = p.part; c.ml = p.ml; c.ctx = (h16*)ctx; c.stats = stats;
+  c.G = G; c.gs = gs; c.Rv = Rv; c.nsplit = ns;
+  hipLaunchKernelGGL(pv_combine_kernel, dim3(H, (Rv + 63) / 64), dim3(64 * CB_WAVES), 0, s, c);
+  PALU_LAUNCH_CHECK();
+  if (probs) {
+    int bx = (L + 255) / 256;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(probs_kernel, dim3(bx, H), dim3(256), 0, s, (const h16*)scores, ss_h, (const h16*)mask,
+                       (const float*)stats, (h16*)probs, sp_h, L, sqrt_d);
+    PALU_LAUNCH_CHECK();
+  }
+  return PALU_OK;
+}
+
+extern "C" int palu_softmax_pv_q(const void* scores, int64_t ss_h, const void* mask, const void* codes, int64_t sc_g,
+                                 int64_t sc_l, const void* meta, int64_t sm_g, int64_t sm_l, void* ctx, void* probs,
+                                 int64_t sp_h, void* workspace, int H, int G, int L, int Rv, int bits, float sqrt_d,
+                                 palu_stream_t stream) {
+  PALU_REQUIRE(H > 0 && G > 0 && H % G == 0 && L > 0 && Rv > 0, PALU_ERR_ARG, "softmax_pv_q: bad shape");
+  PALU_REQUIRE(scores && codes && meta && ctx && workspace, PALU_ERR_ARG, "softmax_pv_q: null pointer");
+  PALU_REQUIRE(bits == 3 || bits == 4, PALU_ERR_UNSUPPORTED, "softmax_pv_q: bits must be 3 or 4");
+  const int gs = H / G;
+  PALU_REQUIRE(gs == 1 || gs == 2 || gs == 4, PALU_ERR_UNSUPPORTED, "softmax_pv_q: group size %d not supported (1,2,4)", gs);
+  PALU_REQUIRE(Rv % 32 == 0 && Rv / 32 <= PV_THREADS, PALU_ERR_UNSUPPORTED, "softmax_pv_q: Rv must be a multiple of 32");
+  PALU_REQUIRE(((uintptr_t)codes & 3) == 0 && sc_g % 4 == 0 && sc_l % 4 == 0 && ((uintptr_t)meta & 3) == 0 &&
+                   sm_g % 2 == 0 && sm_l % 2 == 0,
+               PALU_ERR_ARG, "softmax_pv_q: packed rows / meta must be 4-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  const int rps = pv_rows_per_split(G, L);
+  const int ns = (L + rps - 1) / rps;
+  float* ws = (float*)workspace;
+  PvQParams p;
+  p.scores = (const h16*)scores; p.ss_h = ss_h; p.mask = (const h16*)mask;
+  p.codes = (const unsigned char*)codes; p.sc_g = sc_g; p.sc_l = sc_l;
+  p.meta = (const h16*)meta; p.sm_g = sm_g; p.sm_l = sm_l;
+  p.part = ws;
+  p.ml = ws + (size_t)H * ns * Rv;
+  float* stats = p.ml + (size_t)H * ns * 2;
+  p.G = G; p.gs = gs; p.L = L; p.Rv = Rv; p.nsplit = ns; p.rps = rps;
+  p.inv_scale = sqrt_d;
+  size_t lds = (size_t)gs * rps * sizeof(float);
+  if (lds < (size_t)PV_THREADS * 32 * sizeof(float)) lds = (size_t)PV_THREADS * 32 * sizeof(float);
+  dim3 grid(G * ns), block(PV_THREADS);
+#define PALU_PVQ(GSV)                                                                            \
+  if (bits == 4) hipLaunchKernelGGL((pv_partial_q_kernel<GSV, 4>), grid, block, lds, s, p);      \
+  else hipLaunchKernelGGL((pv_partial_q_kernel<GSV, 3>), grid, block, lds, s, p)
+  switch (gs) {
+    case 1: PALU_PVQ(1); break;
+    case 2: PALU_PVQ(2); break;
+    default: PALU_PVQ(4); break;
+  }
+#undef PALU_PVQ
   PALU_LAUNCH_CHECK();
   CombineParams c;
   c.part = p.part; c.ml = p.ml; c.ctx = (h16*)ctx; c.stats = stats;

@@ -6,7 +6,7 @@
 namespace {
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 struct StepWs {
-  size_t q, scores, ctx, pv, total;
+  size_t q, scores, ctx, pv, knew, vnew, total;
 };
 StepWs step_layout(int H, int G, int D, int Lcap, int Rv) {
   StepWs w;
@@ -15,6 +15,8 @@ StepWs step_layout(int H, int G, int D, int Lcap, int Rv) {
   w.scores = o; o += align256((size_t)H * ((size_t)Lcap + 8) * 2);
   w.ctx = o;    o += align256((size_t)H * Rv * 2);
   w.pv = o;     o += align256(palu_pv_workspace_bytes(H, G, Lcap, Rv));
+  w.knew = o;   o += align256((size_t)4096 * 2);   // new latent rows before quantisation (G*Rk <= 4096)
+  w.vnew = o;   o += align256((size_t)16384 * 2);
   w.total = o;
   return w;
 }
@@ -48,6 +50,47 @@ extern "C" int palu_decode_step_f16(const void* hidden, const void* wq, int64_t 
   if (rc) return rc;
   rc = palu_softmax_pv_f16(scores, ss_h, mask, v_cache, sv_g, sv_l, ctx, probs, sp_h, pvws, H, G, L, Rv,
                            sqrtf((float)D), stream);
+  if (rc) return rc;
+  return palu_gemv_f16(wo, ldo, ctx, out, hidden_size, H * Rv, stream);
+}
+
+// Same step on a QUANTISED latent cache (3/4-bit codes + per-row (scale, zero); quant.hip layout):
+// qkv GEMV -> quantise+pack the two new latent rows into row `cache_len` -> abx with in-register
+// dequantisation -> softmax.PV on the codes -> o_proj.  7 launches.
+extern "C" int palu_decode_step_q(const void* hidden, const void* wq, int64_t ldq, const void* vtk, int64_t ldk,
+                                  const void* vtv, int64_t ldv, const void* bfrag, const void* wo, int64_t ldo,
+                                  void* k_codes, int64_t skc_g, int64_t skc_l, void* k_meta, int64_t skm_g, int64_t skm_l,
+                                  void* v_codes, int64_t svc_g, int64_t svc_l, void* v_meta, int64_t svm_g, int64_t svm_l,
+                                  const void* mask, const float* inv_freq, void* out, void* probs, int64_t sp_h,
+                                  void* workspace, int Lcap, int H, int G, int D, int hidden_size, int Rk, int Rv,
+                                  int bits, int cache_len, int pos, palu_stream_t stream) {
+  PALU_REQUIRE(workspace && Lcap > cache_len && cache_len >= 0, PALU_ERR_ARG,
+               "decode_step_q: cache_len %d must be < workspace capacity %d", cache_len, Lcap);
+  PALU_REQUIRE((size_t)G * Rk <= 4096 && (size_t)G * Rv <= 16384, PALU_ERR_UNSUPPORTED, "decode_step_q: rank too large");
+  const StepWs w = step_layout(H, G, D, Lcap, Rv);
+  char* ws = (char*)workspace;
+  void* q = ws + w.q;
+  void* scores = ws + w.scores;
+  void* ctx = ws + w.ctx;
+  void* pvws = ws + w.pv;
+  void* knew = ws + w.knew;
+  void* vnew = ws + w.vnew;
+  const int L = cache_len + 1;
+  const int64_t ss_h = ((int64_t)Lcap + 8) & ~(int64_t)7;
+  int rc = palu_decode_qkv_f16(wq, ldq, vtk, ldk, vtv, ldv, hidden, q, knew, Rk, 0, vnew, Rv, 0, inv_freq, H, D,
+                               hidden_size, G, Rk, Rv, pos, 0, stream);
+  if (rc) return rc;
+  rc = palu_quantize_pack(knew, Rk, 0, (char*)k_codes + (int64_t)cache_len * skc_l, skc_g, skc_l,
+                          (h16*)k_meta + (int64_t)cache_len * skm_l, skm_g, skm_l, nullptr, 0, 0, G, 1, Rk, bits, stream);
+  if (rc) return rc;
+  rc = palu_quantize_pack(vnew, Rv, 0, (char*)v_codes + (int64_t)cache_len * svc_l, svc_g, svc_l,
+                          (h16*)v_meta + (int64_t)cache_len * svm_l, svm_g, svm_l, nullptr, 0, 0, G, 1, Rv, bits, stream);
+  if (rc) return rc;
+  rc = palu_abx_rope_q(q, D, 1, bfrag, k_codes, skc_g, skc_l, k_meta, skm_g, skm_l, scores, ss_h, H, G, L, Rk, D, bits,
+                       inv_freq, 0, stream);
+  if (rc) return rc;
+  rc = palu_softmax_pv_q(scores, ss_h, mask, v_codes, svc_g, svc_l, v_meta, svm_g, svm_l, ctx, probs, sp_h, pvws, H, G, L,
+                         Rv, bits, sqrtf((float)D), stream);
   if (rc) return rc;
   return palu_gemv_f16(wo, ldo, ctx, out, hidden_size, H * Rv, stream);
 }

@@ -44,8 +44,8 @@ def prepare_b(b: torch.Tensor, num_groups: int) -> torch.Tensor:
     key = id(b)
     hit = _bfrag_cache.get(key)
     if hit is not None:
-        ref, ver, G, frag = hit
-        if ref() is b and ver == b._version and G == num_groups:
+        ref, ver, ptr, G, frag = hit
+        if ref() is b and ver == b._version and ptr == b.data_ptr() and G == num_groups:
             return frag
     H, R, D = b.shape
     nbytes = _lib.lib.palu_abx_bfrag_bytes(H, num_groups, R)
@@ -56,9 +56,9 @@ def prepare_b(b: torch.Tensor, num_groups: int) -> torch.Tensor:
                                            H, num_groups, R, D, frag.data_ptr(), _lib.current_stream()),
                "palu_abx_prepare_b")
     if len(_bfrag_cache) > 256:
-        for k in [k for k, v in _bfrag_cache.items() if v[0]() is None]:
+        for k in [k for k, v in list(_bfrag_cache.items()) if v[0]() is None]:
             del _bfrag_cache[k]
-    _bfrag_cache[key] = (weakref.ref(b), b._version, num_groups, frag)
+    _bfrag_cache[key] = (weakref.ref(b), b._version, b.data_ptr(), num_groups, frag)
     return frag
 
 

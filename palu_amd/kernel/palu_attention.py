@@ -29,7 +29,8 @@ from .. import _lib
 from .abx_rope import abx as recompute_k_gemv  # same alias as kernel/palu_attention.py:13
 from .abx_rope import prepare_b, rope_inv_freq
 
-__all__ = ["HeadwiseLowRankModule", "LlamaPaluAttention", "LatentCache", "DynamicCache", "build_b", "fuse_wo"]
+__all__ = ["HeadwiseLowRankModule", "LlamaPaluAttention", "LatentCache", "QuantLatentCache", "DynamicCache",
+           "build_b", "fuse_wo"]
 
 
 # ------------------------------------------------------------------------------------ cache
@@ -100,6 +101,91 @@ class LatentCache:
         self._v[layer_idx][:, :, n:n + t].copy_(value_states)
         self._len[layer_idx] = n + t
         return self._k[layer_idx][:, :, :n + t], self._v[layer_idx][:, :, :n + t]
+
+
+class QuantLatentCache:
+    """Packed 3/4-bit latent KV cache (DESIGN.md "packed latent format"): per layer
+    k_codes/v_codes uint8 [1, G, capacity, R*bits/8] and k_meta/v_meta fp16 [1, G, capacity, 2] = (scale, zero),
+    quantised per (token, head-group) row like the reference's defaults (svd_linear.py:124-139, quant.py:60-79).
+    Same protocol as LatentCache; `update` quantises the incoming fp16 latents on the GPU and returns the
+    DEQUANTISED [1, G, L, R] tensors (the fake-quant values the reference's accuracy path attends over)."""
+
+    def __init__(self, n_bits: int, capacity: int = 0, headroom: int = 256):
+        if n_bits not in (3, 4):
+            raise ValueError("QuantLatentCache: n_bits must be 3 or 4")
+        self.n_bits = n_bits
+        self._store = []          # per layer: dict(kc, km, vc, vm, Rk, Rv)
+        self._len: List[int] = []
+        self._min_capacity, self._headroom = int(capacity), int(headroom)
+
+    def __len__(self):
+        return len(self._store)
+
+    def _ensure_layer(self, layer_idx):
+        while len(self._store) <= layer_idx:
+            self._store.append(None)
+            self._len.append(0)
+
+    def get_seq_length(self, layer_idx: int = 0) -> int:
+        return self._len[layer_idx] if layer_idx < len(self._len) else 0
+
+    def get_usable_length(self, new_seq_length: int, layer_idx: int = 0) -> int:
+        return self.get_seq_length(layer_idx)
+
+    def capacity(self, layer_idx: int = 0) -> int:
+        st = self._store[layer_idx] if layer_idx < len(self._store) else None
+        return 0 if st is None else st["kc"].shape[2]
+
+    def reserve(self, layer_idx: int, rows: int, G: int, Rk: int, Rv: int, device):
+        from .quant import packed_row_bytes
+        self._ensure_layer(layer_idx)
+        cur = self.capacity(layer_idx)
+        if cur >= rows:
+            return
+        cap = (max(rows, self._min_capacity, 2 * cur) + 63) // 64 * 64
+        n = self._len[layer_idx]
+        old = self._store[layer_idx]
+        new = {"Rk": Rk, "Rv": Rv,
+               "kc": torch.zeros((1, G, cap, packed_row_bytes(Rk, self.n_bits)), dtype=torch.uint8, device=device),
+               "vc": torch.zeros((1, G, cap, packed_row_bytes(Rv, self.n_bits)), dtype=torch.uint8, device=device),
+               "km": torch.zeros((1, G, cap, 2), dtype=torch.float16, device=device),
+               "vm": torch.zeros((1, G, cap, 2), dtype=torch.float16, device=device)}
+        if old is not None and n:
+            for k in ("kc", "vc", "km", "vm"):
+                new[k][:, :, :n].copy_(old[k][:, :, :n])
+        self._store[layer_idx] = new
+
+    def buffers(self, layer_idx: int = 0):
+        return self._store[layer_idx]
+
+    def advance(self, layer_idx: int, rows: int = 1):
+        self._len[layer_idx] += rows
+
+    def dequantized(self, layer_idx: int = 0):
+        from .quant import unpack_dequant
+        st, n = self._store[layer_idx], self._len[layer_idx]
+        k = unpack_dequant(st["kc"][:, :, :n].contiguous(), st["km"][:, :, :n].contiguous(), self.n_bits, st["Rk"])
+        v = unpack_dequant(st["vc"][:, :, :n].contiguous(), st["vm"][:, :, :n].contiguous(), self.n_bits, st["Rv"])
+        return k, v
+
+    def update(self, key_states: torch.Tensor, value_states: torch.Tensor, layer_idx: int, cache_kwargs=None):
+        from .quant import quantize_pack
+        if key_states.dim() != 4 or value_states.dim() != 4:
+            raise ValueError("QuantLatentCache.update expects [bsz, groups, seq, rank] tensors")
+        _, G, t, Rk = key_states.shape
+        Rv = value_states.shape[3]
+        self._ensure_layer(layer_idx)
+        n = self._len[layer_idx]
+        self.reserve(layer_idx, n + t + self._headroom, G, Rk, Rv, key_states.device)
+        st = self._store[layer_idx]
+        kc, km = quantize_pack(key_states.half().contiguous(), self.n_bits)
+        vc, vm = quantize_pack(value_states.half().contiguous(), self.n_bits)
+        st["kc"][:, :, n:n + t].copy_(kc)
+        st["km"][:, :, n:n + t].copy_(km)
+        st["vc"][:, :, n:n + t].copy_(vc)
+        st["vm"][:, :, n:n + t].copy_(vm)
+        self._len[layer_idx] = n + t
+        return self.dequantized(layer_idx)
 
 
 DynamicCache = LatentCache  # name used by run_latency_attention.py:62-65 and the reference tests
@@ -299,6 +385,61 @@ class LlamaPaluAttention(nn.Module):
         cache.advance(li, 1)
         return out, probs
 
+    def _decode_fused_q(self, hidden_states, attention_mask, pos, cache: "QuantLatentCache", output_attentions):
+        """q_len == 1 on a packed 3/4-bit cache: palu_decode_step_q."""
+        if self.q_proj.bias is not None:
+            raise NotImplementedError("attention_bias=True is not supported by the HIP decode step")
+        dev = hidden_states.device
+        li = self.layer_idx
+        n = cache.get_seq_length(li)
+        H, G, D = self.num_heads, self.num_groups, self.head_dim
+        if cache.capacity(li) < n + 1:
+            cache.reserve(li, n + 1 + cache._headroom, G, self.group_rank_k, self.group_rank_v, dev)
+        st = cache.buffers(li)
+        cap = st["kc"].shape[2]
+        ws = self._workspace(dev, cap + 8)
+        frag = prepare_b(self.k_proj.B, G)
+        inv = rope_inv_freq(dev, D, self.rope_theta)
+        out = torch.empty((1, 1, self.hidden_size), dtype=hidden_states.dtype, device=dev)
+        probs = torch.empty((1, H, 1, n + 1), dtype=hidden_states.dtype, device=dev) if output_attentions else None
+        mask_ptr = 0
+        if attention_mask is not None:
+            attention_mask = attention_mask.reshape(-1).to(hidden_states.dtype).contiguous()
+            mask_ptr = attention_mask.data_ptr()
+        wq, vtk, vtv, wo = self.q_proj.weight, self.k_proj.VT.weight, self.v_proj.VT.weight, self.o_proj.weight
+        x = hidden_states.reshape(-1).contiguous()
+        kc, km, vc, vm = st["kc"], st["km"], st["vc"], st["vm"]
+        _lib.check(_lib.lib.palu_decode_step_q(
+            x.data_ptr(), wq.data_ptr(), wq.stride(0), vtk.data_ptr(), vtk.stride(0), vtv.data_ptr(), vtv.stride(0),
+            frag.data_ptr(), wo.data_ptr(), wo.stride(0),
+            kc.data_ptr(), kc.stride(1), kc.stride(2), km.data_ptr(), km.stride(1), km.stride(2),
+            vc.data_ptr(), vc.stride(1), vc.stride(2), vm.data_ptr(), vm.stride(1), vm.stride(2),
+            mask_ptr, inv.data_ptr(), out.data_ptr(),
+            0 if probs is None else probs.data_ptr(), 0 if probs is None else probs.stride(1),
+            ws.data_ptr(), self._ws_cap, H, G, D, self.hidden_size, self.group_rank_k, self.group_rank_v,
+            cache.n_bits, n, int(pos), _lib.current_stream()), "palu_decode_step_q")
+        cache.advance(li, 1)
+        return out, probs
+
+    @torch.no_grad()
+    def fuse_hadamard(self):
+        """Rotate the latent spaces by Hadamard matrices offline (the `--lt_hadamard` option:
+        svd_linear.py:156-168 `fused_hadamard_matrix`, applied here to the kernel-flavoured module):
+        VT_g <- (had(VT_g^T))^T, U_g <- had(U_g); consequently B[h] <- had(B[h]^T)^T and, with U_v folded into
+        o_proj, W_o'[:, h-block] <- had(W_o'[:, h-block]).  Outputs are unchanged up to rounding; the cached
+        latents are born rotated (flatter rows quantise better) and decode needs no online transform."""
+        from .hadamard_utils import apply_hadamard, fuse_hadamard_into_weights
+        for proj in (self.k_proj, self.v_proj):
+            fuse_hadamard_into_weights(proj.VT.weight.data, [u.weight.data for u in proj.U_list])
+        if hasattr(self.k_proj, "B"):
+            b = self.k_proj.B.data
+            self.k_proj.B = nn.Parameter(apply_hadamard(b.transpose(1, 2).contiguous()).transpose(1, 2).contiguous())
+        if self.o_proj.in_features == self.fused_hidden_dim_o:
+            w = self.o_proj.weight.data
+            Rv = self.group_rank_v
+            self.o_proj.weight.data = apply_hadamard(w.reshape(w.shape[0], self.num_heads, Rv).contiguous()).reshape(w.shape)
+        return self
+
     # -- forward -----------------------------------------------------------------------------
     def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                 position_ids: Optional[torch.LongTensor] = None, past_key_value=None,
@@ -320,10 +461,11 @@ class LlamaPaluAttention(nn.Module):
                 f"Attention mask should be of size {(bsz, 1, q_len, kv_seq_len)}, but is {attention_mask.size()}")
 
         fused_o = self.o_proj.in_features == self.fused_hidden_dim_o
-        if (q_len == 1 and bsz == 1 and isinstance(past_key_value, LatentCache) and fused_o
+        if (q_len == 1 and bsz == 1 and isinstance(past_key_value, (LatentCache, QuantLatentCache)) and fused_o
                 and hidden_states.is_cuda and hidden_states.dtype == torch.float16 and hasattr(self.k_proj, "B")):
             pos = kv_seq_len - 1 if position_ids is None else int(position_ids.reshape(-1)[-1])
-            out, probs = self._decode_fused(hidden_states, attention_mask, pos, past_key_value, output_attentions)
+            step = self._decode_fused_q if isinstance(past_key_value, QuantLatentCache) else self._decode_fused
+            out, probs = step(hidden_states, attention_mask, pos, past_key_value, output_attentions)
             return out, probs, past_key_value
 
         # ---- general path (prefill, no_fusion, foreign cache objects): torch composition -------

@@ -1,0 +1,125 @@
+"""GPU: quantised-latent decode path (BASELINE configs 3/4 shapes at reduced L) against the oracle's
+fake-quant semantics (project -> quantize_tensor -> attend: svd_linear.py:84-90,124-139), and the
+offline Hadamard fusion (svd_linear.py:156-168)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+
+import oracle
+from tests.golden import inputs as gi
+from tests.test_decode_gpu import _module_from_palu_weights, softmax_pv
+
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("bits,R,gs,H,L", [(4, 128, 4, 32, 1000), (3, 128, 4, 32, 777), (4, 64, 4, 32, 2049),
+                                           (4, 32, 4, 32, 130), (3, 128, 2, 8, 300), (4, 64, 1, 4, 129)])
+def test_abx_q_equals_fp16_kernel_on_dequantised_latents(bits, R, gs, H, L):
+    """Same MFMA pipeline, same fp16 operand values -> bit-identical scores; plus the oracle bound."""
+    from palu_amd import _lib
+    from palu_amd.kernel import quant as q
+    from palu_amd.kernel.abx_rope import abx, prepare_b, rope_inv_freq
+    rng = np.random.default_rng(bits * 100 + R + L)
+    G = H // gs
+    a = torch.from_numpy(rng.standard_normal((H, 1, 128)).astype(np.float16)).to(DEV)
+    b = torch.from_numpy((rng.standard_normal((H, R, 128)) / math.sqrt(R)).astype(np.float16)).to(DEV)
+    x = torch.from_numpy((rng.standard_normal((G, L, R)) * rng.uniform(0.2, 3, (G, L, 1))).astype(np.float16)).to(DEV)
+    codes, meta, deq = q.quantize_pack(x, bits, want_dequant=True)
+    ref = abx(a, b, deq)
+    out = torch.empty(H, 1, L, dtype=torch.float16, device=DEV)
+    frag = prepare_b(b, G)
+    inv = rope_inv_freq(x.device)
+    _lib.check(_lib.lib.palu_abx_rope_q(a.data_ptr(), a.stride(0), a.stride(2), frag.data_ptr(), codes.data_ptr(),
+                                        codes.stride(0), codes.stride(1), meta.data_ptr(), meta.stride(0), meta.stride(1),
+                                        out.data_ptr(), out.stride(0), H, G, L, R, 128, bits, inv.data_ptr(), 0,
+                                        _lib.current_stream()), "abx_q")
+    assert torch.equal(out, ref)
+    o = oracle.abx_scores(a.cpu(), b.cpu(), oracle.quantize_rows(x.cpu().reshape(-1, R), bits)[0].reshape(G, L, R))
+    scale = o.float().abs().max().item()
+    assert (out.cpu().float() - o.float()).abs().max().item() <= 1e-3 * scale
+
+
+@pytest.mark.parametrize("bits,Rv,gs,H,L", [(4, 192, 4, 32, 3001), (3, 384, 4, 32, 1500), (3, 96, 2, 8, 260),
+                                            (4, 64, 1, 4, 129), (4, 384, 4, 32, 9000)])
+def test_softmax_pv_q(bits, Rv, gs, H, L):
+    from palu_amd import _lib
+    from palu_amd.kernel import quant as q
+    rng = np.random.default_rng(bits + Rv + L)
+    G = H // gs
+    scores = torch.from_numpy((rng.standard_normal((H, L)) * 20).astype(np.float16)).to(DEV)
+    v = torch.from_numpy((rng.standard_normal((G, L, Rv)) * rng.uniform(0.2, 3, (G, L, 1))).astype(np.float16)).to(DEV)
+    codes, meta, deq = q.quantize_pack(v, bits, want_dequant=True)
+    ws = torch.empty(_lib.lib.palu_pv_workspace_bytes(H, G, L, Rv), dtype=torch.uint8, device=DEV)
+    ctx = torch.empty(H, Rv, dtype=torch.float16, device=DEV)
+    probs = torch.empty(H, L, dtype=torch.float16, device=DEV)
+    _lib.check(_lib.lib.palu_softmax_pv_q(scores.data_ptr(), scores.stride(0), 0, codes.data_ptr(), codes.stride(0),
+                                          codes.stride(1), meta.data_ptr(), meta.stride(0), meta.stride(1), ctx.data_ptr(),
+                                          probs.data_ptr(), probs.stride(0), ws.data_ptr(), H, G, L, Rv, bits,
+                                          math.sqrt(128.0), _lib.current_stream()), "pv_q")
+    ref_ctx, ref_p = softmax_pv(scores, deq, want_probs=True)                      # fp16 HIP kernel on dequantised V
+    torch.testing.assert_close(ctx, ref_ctx, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(probs, ref_p, rtol=0, atol=0)
+    x = (scores.cpu() / math.sqrt(128.0))
+    p64 = torch.softmax(x.double(), dim=-1)
+    c64 = torch.matmul(p64.reshape(G, gs, L), deq.cpu().double()).reshape(H, Rv)
+    assert (ctx.cpu().double() - c64).abs().max().item() <= 1e-3 * max(1.0, c64.abs().max().item())
+
+
+@pytest.mark.parametrize("bits,rank_k,rank_v,L", [(4, 512, 1536, 1500), (3, 1024, 3072, 700)])
+def test_quantised_decode_step_vs_oracle(bits, rank_k, rank_v, L):
+    """BASELINE config 3 (3-bit, 1024/3072) and 4 (4-bit, 512/1536) shapes, reduced L: module forward on a
+    QuantLatentCache == oracle.decode_step on fake-quantised caches with the new rows fake-quantised."""
+    from palu_amd.kernel.palu_attention import QuantLatentCache
+    hidden, H, D, gs = 4096, 32, 128, 4
+    G = H // gs
+    w, k_lat, v_lat, tok, _ = gi.step_inputs(77 + bits, hidden, H, D, gs, rank_k, rank_v, L, False)
+    m = _module_from_palu_weights(hidden, H, D, gs, rank_k, rank_v, w)
+    cache = QuantLatentCache(bits)
+    kd, vd = cache.update(k_lat.unsqueeze(0).to(DEV), v_lat.unsqueeze(0).to(DEV), 0)
+    Rk, Rv = rank_k // G, rank_v // G
+    kq = oracle.quantize_rows(k_lat.reshape(-1, Rk), bits)[0].reshape(G, L, Rk)
+    vq = oracle.quantize_rows(v_lat.reshape(-1, Rv), bits)[0].reshape(G, L, Rv)
+    assert torch.equal(kd[0].cpu(), kq) and torch.equal(vd[0].cpu(), vq)              # bit-exact fake-quant
+    with torch.no_grad():
+        out, probs, _ = m(tok.reshape(1, 1, hidden).to(DEV), position_ids=torch.arange(L, L + 1),
+                          past_key_value=cache, output_attentions=True)
+    assert cache.get_seq_length(0) == L + 1
+    wd = {"wq": w["wq"].half(), "vt_k": w["vt_k"].half(), "vt_v": w["vt_v"].half(),
+          "b": oracle.build_b_from_u(w["u_k"], gs, D).half(), "wo": w["wo"].half()}
+    o2, p2, k2, v2 = oracle.decode_step(tok, L, wd, kq, vq, latent_bits=bits)
+    torch.testing.assert_close(probs.cpu().reshape(H, L + 1), p2, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(out.cpu().reshape(-1), o2, rtol=1e-3, atol=1e-3)
+    kd2, vd2 = cache.dequantized(0)
+    # the appended row: GEMV rounding may flip a code at a tie; values must agree to one quantisation step
+    step_k = (k2[:, L].float().amax(-1) - k2[:, L].float().amin(-1)) / (2 ** bits - 1)
+    assert ((kd2[0, :, L].cpu().float() - k2[:, L].float()).abs().amax(-1) <= step_k * 1.01 + 1e-3).all()
+
+
+def test_hadamard_fusion_is_output_invariant():
+    """fuse_hadamard() rotates VT / U / B / W_o' offline (svd_linear.py:156-168): same decode output."""
+    from palu_amd.kernel.palu_attention import LatentCache
+    hidden, H, D, gs, rank_k, rank_v, L = 4096, 32, 128, 4, 1024, 3072, 300     # Rk=128 (2^7), Rv=384 (12*32)
+    w, k_lat, v_lat, tok, _ = gi.step_inputs(5, hidden, H, D, gs, rank_k, rank_v, L, False)
+    m = _module_from_palu_weights(hidden, H, D, gs, rank_k, rank_v, w)
+    x = torch.from_numpy(np.random.default_rng(1).standard_normal((1, L, hidden)).astype(np.float16)).to(DEV)
+
+    def run(mod):
+        cache = LatentCache()
+        with torch.no_grad():
+            mod(x, past_key_value=cache, position_ids=torch.arange(L).unsqueeze(0))          # prefill fills the cache
+            out, probs, _ = mod(tok.reshape(1, 1, hidden).to(DEV), position_ids=torch.arange(L, L + 1),
+                                past_key_value=cache, output_attentions=True)
+        return out, probs, cache
+    o0, p0, c0 = run(m)
+    m.fuse_hadamard()
+    o1, p1, c1 = run(m)
+    torch.testing.assert_close(p1, p0, rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(o1, o0, rtol=2e-3, atol=2e-3)
+    k0, k1 = c0.buffers(0)[0][0, :, :L].float(), c1.buffers(0)[0][0, :, :L].float()
+    assert (k0 - k1).abs().max() > 0.05                                                       # latents really rotated
+    torch.testing.assert_close(k0.norm(dim=-1), k1.norm(dim=-1), rtol=2e-2, atol=2e-2)        # by an orthogonal map
