@@ -21,7 +21,7 @@ import sys
 import torch
 from torch import nn
 
-from palu_amd.kernel.palu_attention import DynamicCache, LlamaPaluAttention, build_b
+from palu_amd.kernel.palu_attention import DynamicCache, LlamaPaluAttention, QuantLatentCache, build_b
 
 
 class LlamaLikeConfig:
@@ -70,13 +70,13 @@ def build_attention_palu(args, device="cuda:0", dtype=torch.float16):
     return attn.to(device, dtype), config
 
 
-def step_algorithmic_bytes(config, prompt_len):
+def step_algorithmic_bytes(config, prompt_len, bits=16):
     """latents once + weights once + scores write/read (fp16)."""
     H, G = config.num_attention_heads, config.num_groups
     rk, rv, hid = config.total_rank_k, config.total_rank_v, config.hidden_size
     L = prompt_len + 1
     D = hid // H
-    latents = 2 * L * (rk + rv)
+    latents = 2 * L * (rk + rv) if bits >= 16 else L * (rk + rv) * bits // 8 + 2 * 4 * G * L
     weights = 2 * (hid * hid + rk * hid + rv * hid + hid * H * (rv // G))
     b = 2 * H * (rk // G) * D
     scores = 2 * 2 * H * L
@@ -84,15 +84,28 @@ def step_algorithmic_bytes(config, prompt_len):
 
 
 def profile_tpot(model, cache_size_k, cache_size_v, cache_type=torch.float16, batch_size=1, prompt_len=1024,
-                 repeats=100, cache_graph=False, torch_profile=False, outfile=""):
+                 repeats=100, cache_graph=False, torch_profile=False, outfile="", bits=16):
     logging.info(">>> Profiling TPOT (generation stage)")
     device = next(iter(model.parameters())).device
     cache_k = torch.randn(cache_size_k, dtype=cache_type, device=device)
     cache_v = torch.randn(cache_size_v, dtype=cache_type, device=device)
     hidden_dim = model.config.hidden_size
     warm, reps = 25, repeats
-    past_key_value = DynamicCache(capacity=prompt_len + 2 * (warm + reps) + 64)
-    past_key_value.update(cache_k, cache_v, 0)
+    cap = prompt_len + 2 * (warm + reps) + 64
+    past_key_value = DynamicCache(capacity=cap) if bits >= 16 else QuantLatentCache(bits, capacity=cap)
+    if bits >= 16:
+        past_key_value.update(cache_k, cache_v, 0)
+    else:                                        # quantise the synthetic prompt latents in slabs (bounded temporaries)
+        for s0 in range(0, prompt_len, 8192):
+            past_key_value.reserve(0, cap, cache_k.shape[1], cache_k.shape[3], cache_v.shape[3], device)
+            from palu_amd.kernel.quant import quantize_pack
+            st, n = past_key_value.buffers(0), past_key_value.get_seq_length(0)
+            t = min(8192, prompt_len - s0)
+            for src, cdst, mdst in ((cache_k, "kc", "km"), (cache_v, "vc", "vm")):
+                c, m = quantize_pack(src[:, :, s0:s0 + t].contiguous(), bits)
+                st[cdst][:, :, n:n + t].copy_(c)
+                st[mdst][:, :, n:n + t].copy_(m)
+            past_key_value.advance(0, t)
     del cache_k, cache_v
     position_ids = torch.arange(prompt_len, prompt_len + 1)
     input_token = torch.randn((batch_size, 1, hidden_dim), dtype=torch.float16, device=device)
@@ -153,12 +166,15 @@ def main(args):
     group_dim_v = config.total_rank_v // num_groups
     cache_size_k = (bs, num_groups, args.prompt_len, group_dim_k)
     cache_size_v = (bs, num_groups, args.prompt_len, group_dim_v)
+    if args.hadamard:
+        attention.fuse_hadamard()
     ms = profile_tpot(attention, cache_size_k, cache_size_v, torch.float16, bs, args.prompt_len, args.repeats,
-                      args.cache_graph, args.torch_profile, "tpot_palu_fp16")
+                      args.cache_graph, args.torch_profile, "tpot_palu_fp16" if args.bits >= 16 else f"tpot_palu_int{args.bits}",
+                      bits=args.bits)
     if args.json:
-        nbytes = step_algorithmic_bytes(config, args.prompt_len)
+        nbytes = step_algorithmic_bytes(config, args.prompt_len, args.bits)
         print(json.dumps({"latency_us": ms * 1e3, "prompt_len": args.prompt_len, "rank_k": args.rank_k,
-                          "rank_v": args.rank_v, "group_size": args.group_size, "cache_graph": args.cache_graph,
+                          "rank_v": args.rank_v, "group_size": args.group_size, "cache_graph": args.cache_graph, "bits": args.bits, "hadamard": args.hadamard,
                           "algorithmic_bytes": nbytes, "hbm_GBps": nbytes / (ms * 1e-3) * 1e-9,
                           "hbm_frac_of_8TBps": nbytes / (ms * 1e-3) * 1e-9 / 8000.0}))
 
@@ -175,6 +191,9 @@ if __name__ == "__main__":
                         help="To enable graph capture of the decode step (HIP graph via torch.cuda.CUDAGraph)")
     parser.add_argument("--torch_profile", action="store_true", help="Whether to launch the pytorch profiler.")
     parser.add_argument("--fast_init", action="store_true", help="random low-rank factors instead of 64 SVDs")
+    parser.add_argument("--bits", type=int, default=16, choices=[16, 4, 3],
+                        help="latent KV precision: 16 = fp16 cache, 4/3 = packed codes (--lt_bits of the reference's eval scripts)")
+    parser.add_argument("--hadamard", action="store_true", help="fuse Hadamard rotations into the weights (--lt_hadamard)")
     parser.add_argument("--json", action="store_true", help="also print a JSON record with achieved HBM GB/s")
     args = parser.parse_args()
     logging.basicConfig(level=logging.INFO,
