@@ -188,16 +188,20 @@ struct PvQParams {
   float inv_scale;
 };
 
+// one thread owns a 16-code column chunk (8 bytes at 4 bit, 6 bytes at 3 bit) and walks the rows in PAIRS:
+// (1024+c_A, 1024+c_B) is formed as an fp16 pair by byte permutes and multiplied with the fp16 weight pair
+// (w_A, w_B) of each head by ONE v_dot2_f32_f16 (fp32 accumulate): 2 code-MACs per instruction.
+//   sum_l p_l s_l (c_l - z_l) = sum_l w_l (1024 + c_l)  -  sum_l w_l (1024 + z_l),   w_l = fp16(p_l s_l)
 template <int BITS>
-struct QChunk {
-  unsigned w[BITS];   // 32 codes = BITS dwords
-  unsigned meta;      // (scale, zero) fp16 pair
+struct QRow {
+  unsigned w0, w1;    // the 16 codes (4 bit: 64 bits; 3 bit: the 48 bits start at bit `bsh` of w1:w0)
 };
 
 template <int GS, int BITS>
 __global__ __launch_bounds__(PV_THREADS) void pv_partial_q_kernel(PvQParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* pl = reinterpret_cast<float*>(smem_raw);
+  float* pl = reinterpret_cast<float*>(smem_raw);                 // [GS][rps] logits -> e^(x-m); later the reduce buffer
+  h16* wl = reinterpret_cast<h16*>(pl + (size_t)GS * p.rps);      // [GS][rps] fp16 weights w = e^(x-m) * scale_row
   __shared__ float sh[4];
   const int tid = threadIdx.x;
   const int g = blockIdx.x % p.G;
@@ -207,28 +211,35 @@ __global__ __launch_bounds__(PV_THREADS) void pv_partial_q_kernel(PvQParams p) {
   float* ml = p.ml + ((size_t)(g * p.nsplit + split) * GS) * 2;
   float* part = p.part + (size_t)(g * p.nsplit + split) * GS * p.Rv;
 
-  const int cpr = p.Rv >> 5;            // 32-code chunks per row
-  const int rpp = PV_THREADS / cpr;
+  const int cpr = p.Rv >> 4;            // 16-code chunks per row
+  const int rpp = PV_THREADS / cpr;     // row PAIRS per pass
   const int rg = tid / cpr, cc = tid - rg * cpr;
   const bool streamer = rg < rpp;
-  constexpr int U = 2;
-  const unsigned char* cb = p.codes + (int64_t)g * p.sc_g + (int64_t)l0 * p.sc_l + cc * (4 * BITS);
+  constexpr int NP = 2;                 // row pairs per batch; two batches in flight
+  const int boff = (BITS == 4) ? cc * 8 : ((cc * 6) & ~3);     // dword-aligned byte offset of the chunk
+  const int bsh = (BITS == 4) ? 0 : ((cc * 6) & 3) * 8;        // 3 bit: 0 or 16 bits into the first dword
+  const unsigned char* cb = p.codes + (int64_t)g * p.sc_g + (int64_t)l0 * p.sc_l + boff;
   const h16* mb = p.meta + (int64_t)g * p.sm_g + (int64_t)l0 * p.sm_l;
   const int nlast = max(n - 1, 0);
-  auto load_batch = [&](QChunk<BITS> (&raw)[U], int i) {
+  // adjacent rows (2*pi, 2*pi+1) form a pair: their weights are one aligned fp16x2 in LDS
+  auto load_pair = [&](QRow<BITS> (&raw)[2 * NP], int slot, int pi) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int r = min(i + u * rpp, nlast);
-      const unsigned* src = reinterpret_cast<const unsigned*>(cb + (int64_t)r * p.sc_l);
-#pragma unroll
-      for (int k = 0; k < BITS; ++k) raw[u].w[k] = __builtin_nontemporal_load(src + k);
-      raw[u].meta = *reinterpret_cast<const unsigned*>(mb + (int64_t)r * p.sm_l);
+    for (int e = 0; e < 2; ++e) {
+      const int row = min(2 * pi + e, nlast);
+      const unsigned* src = reinterpret_cast<const unsigned*>(cb + (int64_t)row * p.sc_l);
+      raw[2 * slot + e].w0 = __builtin_nontemporal_load(src);
+      raw[2 * slot + e].w1 = __builtin_nontemporal_load(src + 1);
     }
   };
-  QChunk<BITS> rawA[U], rawB[U];
+  auto load_batch = [&](QRow<BITS> (&raw)[2 * NP], int pi) {
+#pragma unroll
+    for (int u = 0; u < NP; ++u) load_pair(raw, u, pi + u * rpp);
+  };
+  QRow<BITS> rawA[2 * NP], rawB[2 * NP];
   if (streamer) load_batch(rawA, rg);
 
-  float mloc[GS], sloc[GS];
+  // ---- phase A: per head  x -> max -> e^(x-m) -> sum;  w = fp16(e * scale_row) -> LDS;  corr = sum w (1024 + zero_row)
+  float mloc[GS], sloc[GS], corr[GS];
 #pragma unroll
   for (int h = 0; h < GS; ++h) {
     const h16* sc = p.scores + (int64_t)(g * GS + h) * p.ss_h + l0;
@@ -239,15 +250,23 @@ __global__ __launch_bounds__(PV_THREADS) void pv_partial_q_kernel(PvQParams p) {
       mx = fmaxf(mx, x);
     }
     mx = block_max(mx, sh, tid);
-    float sm = 0.f;
-    for (int i = tid; i < n; i += PV_THREADS) {
-      float e = (mx == -INFINITY) ? 0.f : __expf(pl[h * p.rps + i] - mx);
-      pl[h * p.rps + i] = e;
-      sm += e;
+    float sm = 0.f, cr = 0.f;
+    for (int i = tid; i < p.rps; i += PV_THREADS) {
+      h16 wq = (h16)0.f;
+      if (i < n) {
+        const float e = (mx == -INFINITY) ? 0.f : __expf(pl[h * p.rps + i] - mx);
+        sm += e;
+        const h16x2 m2 = __builtin_bit_cast(h16x2, *reinterpret_cast<const unsigned*>(mb + (int64_t)i * p.sm_l));
+        wq = (h16)(e * (float)m2[0]);
+        cr = fmaf((float)wq, 1024.f + (float)m2[1], cr);
+      }
+      wl[h * p.rps + i] = wq;
     }
     sm = block_sum(sm, sh, tid);
+    cr = block_sum(cr, sh, tid);
     mloc[h] = mx;
     sloc[h] = sm;
+    corr[h] = cr;
   }
   if (tid == 0) {
 #pragma unroll
@@ -258,79 +277,102 @@ __global__ __launch_bounds__(PV_THREADS) void pv_partial_q_kernel(PvQParams p) {
   }
   __syncthreads();
 
-  float acc[GS][32];
-  float corr[GS];
+  float acc[GS][16];
 #pragma unroll
-  for (int h = 0; h < GS; ++h) {
-    corr[h] = 0.f;
+  for (int h = 0; h < GS; ++h)
 #pragma unroll
-    for (int j = 0; j < 32; ++j) acc[h][j] = 0.f;
-  }
-  auto consume = [&](const QChunk<BITS> (&raw)[U], int i) {
+    for (int j = 0; j < 16; ++j) acc[h][j] = 0.f;
+
+  // (1024 + c_A, 1024 + c_B) fp16 pairs of the 16 columns of a row pair
+  auto pair_words = [&](const QRow<BITS>& ra, const QRow<BITS>& rb, unsigned (&pw)[16]) {
+    if (BITS == 4) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const unsigned mw = raw[u].meta;
-      const h16x2 m2 = __builtin_bit_cast(h16x2, mw);
-      const float sc = (float)m2[0], zp = (float)m2[1];
-      const bool ok = i + u * rpp < n;
-      const int row = min(i + u * rpp, p.rps - 1);
-      float wgt[GS];
+      for (int d = 0; d < 2; ++d) {
+        const unsigned wa = d ? ra.w1 : ra.w0, wb = d ? rb.w1 : rb.w0;
+        const unsigned ae = wa & 0x0F0F0F0Fu, ao = (wa >> 4) & 0x0F0F0F0Fu;   // even / odd codes as bytes
+        const unsigned be = wb & 0x0F0F0F0Fu, bo = (wb >> 4) & 0x0F0F0F0Fu;
 #pragma unroll
-      for (int h = 0; h < GS; ++h) {
-        wgt[h] = ok ? pl[h * p.rps + row] * sc : 0.f;
-        corr[h] = fmaf(wgt[h], zp, corr[h]);
+        for (int k = 0; k < 4; ++k) {
+          const unsigned sel = 0x0C000C00u | ((4u + k) << 16) | (unsigned)k;   // bytes [A_k, 0, B_k, 0]
+          pw[8 * d + 2 * k] = __builtin_amdgcn_perm(be, ae, sel) | 0x64006400u;
+          pw[8 * d + 2 * k + 1] = __builtin_amdgcn_perm(bo, ao, sel) | 0x64006400u;
+        }
       }
-      // 8 codes per 4*BITS-bit group
-      unsigned grp[4];
-      if (BITS == 4) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) grp[k] = raw[u].w[k];
-      } else {
-        grp[0] = raw[u].w[0];
-        grp[1] = __builtin_amdgcn_alignbit(raw[u].w[1], raw[u].w[0], 24);
-        grp[2] = __builtin_amdgcn_alignbit(raw[u].w[2], raw[u].w[1], 16);
-        grp[3] = raw[u].w[2] >> 8;
+    } else {
+      unsigned ga[2], gb[2];
+      {
+        const unsigned lo = bsh ? __builtin_amdgcn_alignbit(ra.w1, ra.w0, 16) : ra.w0;
+        const unsigned hi = bsh ? (ra.w1 >> 16) : ra.w1;
+        ga[0] = lo;
+        ga[1] = __builtin_amdgcn_alignbit(hi, lo, 24);
+      }
+      {
+        const unsigned lo = bsh ? __builtin_amdgcn_alignbit(rb.w1, rb.w0, 16) : rb.w0;
+        const unsigned hi = bsh ? (rb.w1 >> 16) : rb.w1;
+        gb[0] = lo;
+        gb[1] = __builtin_amdgcn_alignbit(hi, lo, 24);
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
+      for (int d = 0; d < 2; ++d)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float c = (float)((grp[k] >> (BITS * e)) & ((1u << BITS) - 1));
-#pragma unroll
-          for (int h = 0; h < GS; ++h) acc[h][8 * k + e] = fmaf(wgt[h], c, acc[h][8 * k + e]);
+          const unsigned a = ((ga[d] >> (3 * e)) & 7u) | 0x64006400u;
+          const int shl = 16 - 3 * e;                                    // move code e of B to bits 16..18
+          const unsigned bsft = shl >= 0 ? (gb[d] << shl) : (gb[d] >> (-shl));
+          pw[8 * d + e] = (bsft & 0x70000u) | a;
         }
     }
   };
+  auto consume = [&](const QRow<BITS> (&raw)[2 * NP], int pi) {
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int row2 = min(2 * (pi + u * rpp), p.rps - 2);     // rows beyond the range carry weight 0 in wl
+      h16x2 w2[GS];
+#pragma unroll
+      for (int h = 0; h < GS; ++h) {
+        const unsigned wv = *reinterpret_cast<const unsigned*>(wl + h * p.rps + row2);
+        w2[h] = (2 * (pi + u * rpp) < p.rps) ? __builtin_bit_cast(h16x2, wv) : h16x2{(h16)0.f, (h16)0.f};
+      }
+      unsigned pw[16];
+      pair_words(raw[2 * u], raw[2 * u + 1], pw);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const unsigned pj = pw[j];
+        const h16x2 cp = __builtin_bit_cast(h16x2, pj);
+#pragma unroll
+        for (int h = 0; h < GS; ++h) acc[h][j] = __builtin_amdgcn_fdot2(cp, w2[h], acc[h][j], false);
+      }
+    }
+  };
   if (streamer) {
-    const int stride = U * rpp;
-    int i = rg;
+    const int stride = NP * rpp;          // in row pairs
+    int pi = rg;
     for (;;) {
-      load_batch(rawB, i + stride);
-      consume(rawA, i);
-      i += stride;
-      if (i >= n) break;
-      load_batch(rawA, i + stride);
-      consume(rawB, i);
-      i += stride;
-      if (i >= n) break;
+      load_batch(rawB, pi + stride);
+      consume(rawA, pi);
+      pi += stride;
+      if (2 * pi >= n) break;
+      load_batch(rawA, pi + stride);
+      consume(rawB, pi);
+      pi += stride;
+      if (2 * pi >= n) break;
     }
   }
-  // ---- cross-row-group reduction, one head per pass through a [threads][32] LDS buffer
+  // ---- cross-row-group reduction, one head per pass through a [threads][16] LDS buffer
   float* redb = pl;
 #pragma unroll
   for (int h = 0; h < GS; ++h) {
     __syncthreads();
     if (streamer) {
 #pragma unroll
-      for (int j = 0; j < 32; j += 4)
-        *reinterpret_cast<f32x4*>(redb + (size_t)tid * 32 + j) =
-            f32x4{acc[h][j] - corr[h], acc[h][j + 1] - corr[h], acc[h][j + 2] - corr[h], acc[h][j + 3] - corr[h]};
+      for (int j = 0; j < 16; j += 4)
+        *reinterpret_cast<f32x4*>(redb + (size_t)tid * 16 + j) = f32x4{acc[h][j], acc[h][j + 1], acc[h][j + 2], acc[h][j + 3]};
     }
     __syncthreads();
     for (int r = tid; r < p.Rv; r += PV_THREADS) {
-      const int c = r >> 5, j = r & 31;
-      float s = 0.f;
-      for (int q = 0; q < rpp; ++q) s += redb[(size_t)(q * cpr + c) * 32 + j];
+      const int c = r >> 4, j = r & 15;
+      float s = -corr[h];
+      for (int q = 0; q < rpp; ++q) s += redb[(size_t)(q * cpr + c) * 16 + j];
       part[h * p.Rv + r] = s;
     }
   }
@@ -491,7 +533,7 @@ extern "C" int palu_softmax_pv_q(const void* scores, int64_t ss_h, const void* m
   PALU_REQUIRE(bits == 3 || bits == 4, PALU_ERR_UNSUPPORTED, "softmax_pv_q: bits must be 3 or 4");
   const int gs = H / G;
   PALU_REQUIRE(gs == 1 || gs == 2 || gs == 4, PALU_ERR_UNSUPPORTED, "softmax_pv_q: group size %d not supported (1,2,4)", gs);
-  PALU_REQUIRE(Rv % 32 == 0 && Rv / 32 <= PV_THREADS, PALU_ERR_UNSUPPORTED, "softmax_pv_q: Rv must be a multiple of 32");
+  PALU_REQUIRE(Rv % 32 == 0 && Rv / 16 <= PV_THREADS, PALU_ERR_UNSUPPORTED, "softmax_pv_q: Rv must be a multiple of 32, <= 4096");
   PALU_REQUIRE(((uintptr_t)codes & 3) == 0 && sc_g % 4 == 0 && sc_l % 4 == 0 && ((uintptr_t)meta & 3) == 0 &&
                    sm_g % 2 == 0 && sm_l % 2 == 0,
                PALU_ERR_ARG, "softmax_pv_q: packed rows / meta must be 4-byte aligned");
@@ -508,8 +550,8 @@ extern "C" int palu_softmax_pv_q(const void* scores, int64_t ss_h, const void* m
   float* stats = p.ml + (size_t)H * ns * 2;
   p.G = G; p.gs = gs; p.L = L; p.Rv = Rv; p.nsplit = ns; p.rps = rps;
   p.inv_scale = sqrt_d;
-  size_t lds = (size_t)gs * rps * sizeof(float);
-  if (lds < (size_t)PV_THREADS * 32 * sizeof(float)) lds = (size_t)PV_THREADS * 32 * sizeof(float);
+  size_t lds = (size_t)gs * rps * (sizeof(float) + sizeof(h16));
+  if (lds < (size_t)PV_THREADS * 16 * sizeof(float)) lds = (size_t)PV_THREADS * 16 * sizeof(float);
   dim3 grid(G * ns), block(PV_THREADS);
 #define PALU_PVQ(GSV)                                                                            \
   if (bits == 4) hipLaunchKernelGGL((pv_partial_q_kernel<GSV, 4>), grid, block, lds, s, p);      \
