@@ -177,6 +177,17 @@ int palu_decode_step_q(const void* hidden,
                        void* workspace, int Lcap, int H, int G, int D, int hidden_size, int Rk, int Rv,
                        int bits, int cache_len, int pos, palu_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Prefill down-projection (MFMA GEMM): latents = X . VT^T for a whole prompt
+ * (HeadwiseLowRankModule.project_to_latent with q_len = L: kernel/palu_attention.py:59-65,167-168),
+ * written straight into the latent-cache layout:
+ *   out[(n / R) * so_g + (row0 + m) * so_l + n % R] = sum_k x[m, k] * w[n, k]      m < M, n < N
+ * x: [M, K] fp16 (ldx), w = VT: [N, K] fp16 (ldw), K % 64 == 0, N % R == 0, fp32 accumulate, fp16 out.
+ */
+int palu_lowrank_project_gemm(const void* x, int64_t ldx, const void* w, int64_t ldw,
+                              void* out, int64_t so_g, int64_t so_l,
+                              int M, int N, int K, int R, int row0, palu_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

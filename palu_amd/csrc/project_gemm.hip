@@ -1,0 +1,133 @@
+// Prefill down-projection: latents[L, rank] = X[L, hidden] . VT^T  (kernel/palu_attention.py:167-168 with
+// q_len = L; HeadwiseLowRankModule.project_to_latent :59-65) -- the one true dense GEMM of the module, on MFMA.
+//
+// Both operands are K-contiguous (X rows, VT rows), i.e. exactly the MFMA fragment shape (a lane holds 8
+// consecutive k of one row) -- no transposes anywhere.  128x128 output tile per 256-thread workgroup
+// (2x2 waves x 2x2 v_mfma_f32_32x32x16_f16 tiles), BK = 64, register-staged double-buffered LDS tiles with an
+// XOR swizzle (conflict-free ds_read_b128).  The MFMA computes C^T tiles (A = VT rows, B = X rows) so that a
+// lane ends up with 4 consecutive latent columns of one token: 8-byte stores, written straight into the
+// [G, L, R] latent-cache layout (row offset `row0`), so prefill fills the cache without a reshape/copy.
+#include "palu_common.h"
+
+namespace {
+
+constexpr int PG_BM = 128, PG_BN = 128, PG_BK = 64, PG_THREADS = 256;
+
+struct PgParams {
+  const h16* x;  int64_t ldx;       // [M, K]
+  const h16* w;  int64_t ldw;       // [N, K]
+  h16* out;      int64_t so_g, so_l; // out[(n / R) * so_g + (row0 + m) * so_l + n % R]
+  int M, N, K, R, row0;
+};
+
+__device__ __forceinline__ int pg_swz(int row, int c) { return c ^ ((row >> 1) & 7); }   // 128-byte rows, 8 chunks
+
+__global__ __launch_bounds__(PG_THREADS, 2) void project_gemm_kernel(PgParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * PG_BM * PG_BK * 2];   // [buf][A|B][128 rows][64 halfs] = 64 KB
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv >> 1, wn = wv & 1;                 // wave grid: 2 (token) x 2 (latent column)
+  const int m0 = blockIdx.x * PG_BM, n0 = blockIdx.y * PG_BN;
+  constexpr int TILE = PG_BM * PG_BK * 2;              // bytes of one operand tile
+
+  // staging: 128 rows x 8 chunks = 1024 slots per operand, 4 per thread
+  u32x4 ra[4], rb[4];
+  auto gload = [&](int kt) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int slot = tid + PG_THREADS * s, row = slot >> 3, c = pg_swz(row, slot & 7);
+      const int xm = min(m0 + row, p.M - 1), wn_ = min(n0 + row, p.N - 1);
+      ra[s] = *reinterpret_cast<const u32x4*>(p.x + (int64_t)xm * p.ldx + kt * PG_BK + c * 8);
+      rb[s] = *reinterpret_cast<const u32x4*>(p.w + (int64_t)wn_ * p.ldw + kt * PG_BK + c * 8);
+    }
+  };
+  auto sstore = [&](int buf) {
+    char* a = smem + buf * 2 * TILE;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int slot = tid + PG_THREADS * s;
+      *reinterpret_cast<u32x4*>(a + slot * 16) = ra[s];            // X tile
+      *reinterpret_cast<u32x4*>(a + TILE + slot * 16) = rb[s];     // VT tile
+    }
+  };
+
+  f32x16 acc[2][2];   // [latent-column tile][token tile]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int nk = p.K / PG_BK;
+  gload(0);
+  sstore(0);
+  if (nk > 1) gload(1);
+  const int fr = lane & 31, kb = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    if (kt + 1 < nk) sstore((kt + 1) & 1);
+    if (kt + 2 < nk) gload(kt + 2);
+    const char* xs = smem + (kt & 1) * 2 * TILE;
+    const char* ws = xs + TILE;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      h16x8 fx[2], fw[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int rx = wm * 64 + t * 32 + fr, rw = wn * 64 + t * 32 + fr;
+        fx[t] = *reinterpret_cast<const h16x8*>(xs + rx * 128 + pg_swz(rx, 2 * ks + kb) * 16);
+        fw[t] = *reinterpret_cast<const h16x8*>(ws + rw * 128 + pg_swz(rw, 2 * ks + kb) * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fx[j], acc[i][j], 0, 0, 0);
+    }
+  }
+  // C^T tile: column (lane&31) = token, rows = latent columns (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int m = m0 + wm * 64 + j * 32 + fr;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * kb;
+        if (n + 3 < p.N) {
+          const int g = n / p.R, r = n - g * p.R;
+          h16x4 v = {(h16)acc[i][j][4 * q], (h16)acc[i][j][4 * q + 1], (h16)acc[i][j][4 * q + 2], (h16)acc[i][j][4 * q + 3]};
+          *reinterpret_cast<h16x4*>(p.out + (int64_t)g * p.so_g + (int64_t)(p.row0 + m) * p.so_l + r) = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) {
+              const int g = (n + e) / p.R, r = (n + e) - g * p.R;
+              p.out[(int64_t)g * p.so_g + (int64_t)(p.row0 + m) * p.so_l + r] = (h16)acc[i][j][4 * q + e];
+            }
+        }
+      }
+    }
+}
+
+}  // namespace
+
+extern "C" int palu_lowrank_project_gemm(const void* x, int64_t ldx, const void* w, int64_t ldw, void* out, int64_t so_g,
+                                         int64_t so_l, int M, int N, int K, int R, int row0, palu_stream_t stream) {
+  PALU_REQUIRE(x && w && out && M >= 0 && N > 0 && K > 0 && R > 0 && row0 >= 0, PALU_ERR_ARG, "project_gemm: bad arguments");
+  PALU_REQUIRE(K % PG_BK == 0, PALU_ERR_UNSUPPORTED, "project_gemm: K must be a multiple of 64 (got %d)", K);
+  PALU_REQUIRE(N % R == 0 && R % 4 == 0, PALU_ERR_ARG, "project_gemm: N must be a multiple of the group rank R, R %% 4 == 0");
+  PALU_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0, PALU_ERR_ARG,
+               "project_gemm: X / VT rows must be 16-byte aligned");
+  PALU_REQUIRE(so_g % 4 == 0 && so_l % 4 == 0 && ((uintptr_t)out & 7) == 0, PALU_ERR_ARG,
+               "project_gemm: output rows must be 8-byte aligned");
+  if (M == 0) return PALU_OK;
+  PgParams p;
+  p.x = (const h16*)x; p.ldx = ldx; p.w = (const h16*)w; p.ldw = ldw;
+  p.out = (h16*)out; p.so_g = so_g; p.so_l = so_l;
+  p.M = M; p.N = N; p.K = K; p.R = R; p.row0 = row0;
+  dim3 grid((M + PG_BM - 1) / PG_BM, (N + PG_BN - 1) / PG_BN);
+  hipLaunchKernelGGL(project_gemm_kernel, grid, dim3(PG_THREADS), 0, (hipStream_t)stream, p);
+  PALU_LAUNCH_CHECK();
+  return PALU_OK;
+}

@@ -421,6 +421,27 @@ class LlamaPaluAttention(nn.Module):
         cache.advance(li, 1)
         return out, probs
 
+    def _project_into_cache(self, hidden_states, cache: "LatentCache"):
+        """latents = X.VT^T for the whole prompt via palu_lowrank_project_gemm, appended in place (:167-168,193)."""
+        li, G = self.layer_idx, self.num_groups
+        q_len = hidden_states.shape[1]
+        n = cache.get_seq_length(li)
+        dev, dt = hidden_states.device, hidden_states.dtype
+        like_k = torch.empty((1, G, 0, self.group_rank_k), dtype=dt, device=dev)
+        like_v = torch.empty((1, G, 0, self.group_rank_v), dtype=dt, device=dev)
+        cache.reserve(li, n + q_len + cache._headroom, like_k, like_v)
+        kbuf, vbuf = cache.buffers(li)
+        x = hidden_states.reshape(q_len, -1)
+        if x.stride(1) != 1 or x.stride(0) % 8:
+            x = x.contiguous()
+        for w, buf, R in ((self.k_proj.VT.weight, kbuf, self.group_rank_k), (self.v_proj.VT.weight, vbuf, self.group_rank_v)):
+            _lib.check(_lib.lib.palu_lowrank_project_gemm(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0),
+                                                          buf.data_ptr(), buf.stride(1), buf.stride(2), q_len,
+                                                          w.shape[0], w.shape[1], R, n, _lib.current_stream()),
+                       "palu_lowrank_project_gemm")
+        cache.advance(li, q_len)
+        return kbuf[:, :, :n + q_len], vbuf[:, :, :n + q_len]
+
     @torch.no_grad()
     def fuse_hadamard(self):
         """Rotate the latent spaces by Hadamard matrices offline (the `--lt_hadamard` option:
@@ -470,10 +491,15 @@ class LlamaPaluAttention(nn.Module):
 
         # ---- general path (prefill, no_fusion, foreign cache objects): torch composition -------
         query_states = self.q_proj(hidden_states).view(bsz, q_len, H, D).transpose(1, 2)
-        key_h = self.k_proj.project_to_latent(hidden_states).view(bsz, q_len, G, self.group_rank_k).transpose(1, 2)
-        val_h = self.v_proj.project_to_latent(hidden_states).view(bsz, q_len, G, self.group_rank_v).transpose(1, 2)
-        if past_key_value is not None:
-            key_h, val_h = past_key_value.update(key_h, val_h, self.layer_idx)
+        if (isinstance(past_key_value, LatentCache) and bsz == 1 and hidden_states.is_cuda
+                and hidden_states.dtype == torch.float16 and self.k_proj.VT.bias is None):
+            # prefill down-projection on the MFMA GEMM, written straight into the latent cache rows
+            key_h, val_h = self._project_into_cache(hidden_states, past_key_value)
+        else:
+            key_h = self.k_proj.project_to_latent(hidden_states).view(bsz, q_len, G, self.group_rank_k).transpose(1, 2)
+            val_h = self.v_proj.project_to_latent(hidden_states).view(bsz, q_len, G, self.group_rank_v).transpose(1, 2)
+            if past_key_value is not None:
+                key_h, val_h = past_key_value.update(key_h, val_h, self.layer_idx)
         if position_ids is None:
             position_ids = torch.arange(past, kv_seq_len, device=hidden_states.device).unsqueeze(0)
         pos = position_ids.to(hidden_states.device).reshape(-1, q_len)

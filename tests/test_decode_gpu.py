@@ -280,3 +280,23 @@ def test_decode_step_full_size_c2_properties():
     c2, _ = softmax_pv(scores, v2)
     c12, _ = softmax_pv(scores, (v.float() * 0.5 + v2.float() * 0.25).half())
     torch.testing.assert_close(c12.float(), ctx.float() * 0.5 + c2.float() * 0.25, rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("M,N,K,R", [(1000, 1024, 4096, 128), (63, 4096, 4096, 512), (129, 768, 512, 96), (4096, 3072, 4096, 384),
+                                     (1, 256, 4096, 32)])
+def test_lowrank_project_gemm(M, N, K, R):
+    """Prefill down-projection (MFMA GEMM) vs fp64, written into the [G, L, R] cache layout at a row offset."""
+    lib = _lib()
+    rng = np.random.default_rng(M + N)
+    x = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float16)).to(DEV)
+    w = torch.from_numpy((rng.standard_normal((N, K)) / math.sqrt(K)).astype(np.float16)).to(DEV)
+    G, row0, cap = N // R, 5, M + 16
+    cache = torch.zeros(G, cap, R, dtype=torch.float16, device=DEV)
+    lib.check(lib.lib.palu_lowrank_project_gemm(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), cache.data_ptr(),
+                                                cache.stride(0), cache.stride(1), M, N, K, R, row0, _stream()), "gemm")
+    ref = (x.double() @ w.double().t()).reshape(M, G, R).transpose(0, 1)          # [G, M, R]
+    got = cache[:, row0:row0 + M].double()
+    assert (got - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+    assert cache[:, :row0].abs().max() == 0 and cache[:, row0 + M:].abs().max() == 0      # nothing else touched
+    t16 = torch.nn.functional.linear(x, w).reshape(M, G, R).transpose(0, 1)
+    torch.testing.assert_close(cache[:, row0:row0 + M], t16, rtol=2e-3, atol=2e-3)
