@@ -43,7 +43,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in sources():                      # one hipcc per translation unit, in parallel
         obj = os.path.join(LIBDIR, os.path.basename(src) + ".o")
         objs.append(obj)
-        cmd = [hipcc, *CFLAGS, "-c", src, "-o", obj]
+        cmd = [hipcc, *CFLAGS, *os.environ.get("PALU_EXTRA_CFLAGS", "").split(), "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -37,6 +37,9 @@ constexpr int HEAD_DIM = 128;
 #ifndef PALU_ABX_PRIO
 #define PALU_ABX_PRIO 1
 #endif
+#ifndef PALU_ABX_SGB
+#define PALU_ABX_SGB 0
+#endif
 
 struct AbxParams {
   const h16* a;
@@ -679,6 +682,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
   __syncthreads();
   load_xf(smem, 0);
 
+  // optional explicit interleave of one {MFMA block, epilogue} region: 1 MFMA : PALU_ABX_SGB VALU (+ LDS reads)
+  auto interleave = [&]() {
+#if PALU_ABX_SGB > 0
+#pragma unroll
+    for (int i = 0; i < NKS * NMB; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x002, PALU_ABX_SGB, 0);    // VALU
+      if ((i % NMB) == NMB - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one X-fragment ds_read per k-step
+    }
+#endif
+  };
+
   for (int tt = 0; tt < ntile; ++tt) {
     stamp();  // 5+2*tt: arrive at barrier
     if (tt > 0) {
@@ -699,17 +714,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
       load_q(min(tt + 3, ntile - 1));
     }
     epilogue(tt - 1, 3, accB);  // tt == 0: discarded (writes a slot that is rewritten before use)
+    interleave();
     __builtin_amdgcn_sched_barrier(0);  // keep each {MFMA block b+1, epilogue b} pair its own scheduling region
     mfma_block(accB, xs, 1, xs, 2);
     reduce_store(tt - 2);
     epilogue(tt, 0, accA);
+    interleave();
     __builtin_amdgcn_sched_barrier(0);
     if (p.prio_mode == 2 && young) __builtin_amdgcn_s_setprio(0);  // ... the old half catches up in the second
     mfma_block(accA, xs, 2, xs, 3);
     epilogue(tt, 1, accB);
+    interleave();
     __builtin_amdgcn_sched_barrier(0);
     mfma_block(accB, xs, 3, xn, 0);  // prefetches block 0 of the next tile (staged one barrier ago)
     epilogue(tt, 2, accA);
+    interleave();
     __builtin_amdgcn_sched_barrier(0);
   }
   epilogue(ntile - 1, 3, accB);
