@@ -56,7 +56,7 @@ extern "C" int palu_decode_step_f16(const void* hidden, const void* wq, int64_t 
 
 // Same step on a QUANTISED latent cache (3/4-bit codes + per-row (scale, zero); quant.hip layout):
 // qkv GEMV -> quantise+pack the two new latent rows into row `cache_len` -> abx with in-register
-// dequantisation -> softmax.PV on the codes -> o_proj.  7 launches.
+// dequantisation -> softmax.PV on the codes -> o_proj.  6 launches.
 extern "C" int palu_decode_step_q(const void* hidden, const void* wq, int64_t ldq, const void* vtk, int64_t ldk,
                                   const void* vtv, int64_t ldv, const void* bfrag, const void* wo, int64_t ldo,
                                   void* k_codes, int64_t skc_g, int64_t skc_l, void* k_meta, int64_t skm_g, int64_t skm_l,
@@ -80,11 +80,10 @@ extern "C" int palu_decode_step_q(const void* hidden, const void* wq, int64_t ld
   int rc = palu_decode_qkv_f16(wq, ldq, vtk, ldk, vtv, ldv, hidden, q, knew, Rk, 0, vnew, Rv, 0, inv_freq, H, D,
                                hidden_size, G, Rk, Rv, pos, 0, stream);
   if (rc) return rc;
-  rc = palu_quantize_pack(knew, Rk, 0, (char*)k_codes + (int64_t)cache_len * skc_l, skc_g, skc_l,
-                          (h16*)k_meta + (int64_t)cache_len * skm_l, skm_g, skm_l, nullptr, 0, 0, G, 1, Rk, bits, stream);
-  if (rc) return rc;
-  rc = palu_quantize_pack(vnew, Rv, 0, (char*)v_codes + (int64_t)cache_len * svc_l, svc_g, svc_l,
-                          (h16*)v_meta + (int64_t)cache_len * svm_l, svm_g, svm_l, nullptr, 0, 0, G, 1, Rv, bits, stream);
+  rc = palu_quantize_pack_kv(knew, Rk, (char*)k_codes + (int64_t)cache_len * skc_l, skc_g,
+                             (h16*)k_meta + (int64_t)cache_len * skm_l, skm_g, Rk, vnew, Rv,
+                             (char*)v_codes + (int64_t)cache_len * svc_l, svc_g,
+                             (h16*)v_meta + (int64_t)cache_len * svm_l, svm_g, Rv, G, bits, stream);
   if (rc) return rc;
   rc = palu_abx_rope_q(q, D, 1, bfrag, k_codes, skc_g, skc_l, k_meta, skm_g, skm_l, scores, ss_h, H, G, L, Rk, D, bits,
                        inv_freq, 0, stream);

@@ -37,6 +37,11 @@ void palu_set_error(const char* fmt, ...);
 
 int palu_num_cus();   // cached hipDeviceProp multiProcessorCount of the current device
 
+// internal cross-TU helper (quant.hip): both new latent rows of a decode step in one launch
+int palu_quantize_pack_kv(const void* k, int64_t sk_g, void* k_codes, int64_t skc_g, void* k_meta, int64_t skm_g, int Rk,
+                          const void* v, int64_t sv_g, void* v_codes, int64_t svc_g, void* v_meta, int64_t svm_g, int Rv,
+                          int G, int bits, palu_stream_t stream);
+
 static __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -16,20 +16,20 @@ namespace {
 
 static __device__ __forceinline__ float r16(float x) { return (float)(h16)x; }  // round to fp16, keep as float
 
-// one wave per row; R <= 2048
+struct QpTensor {
+  const h16* x;  int64_t sx_g, sx_l;
+  unsigned char* codes; int64_t sc_g, sc_l;
+  h16* meta;     int64_t sm_g, sm_l;
+  h16* deq;      int64_t sd_g, sd_l;
+  int R;
+};
+
+// one wave quantises + packs one (group, row) of R codes
 template <int BITS>
-__global__ __launch_bounds__(256) void quantize_pack_kernel(const h16* __restrict__ x, int64_t sx_g, int64_t sx_l,
-                                                            unsigned char* __restrict__ codes, int64_t sc_g, int64_t sc_l,
-                                                            h16* __restrict__ meta, int64_t sm_g, int64_t sm_l,
-                                                            h16* __restrict__ deq, int64_t sd_g, int64_t sd_l,
-                                                            int G, int nrows, int R) {
-  const int lane = threadIdx.x & 63;
-  const int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (wid >= (int64_t)G * nrows) return;
-  const int g = (int)(wid / nrows), l = (int)(wid % nrows);
-  const h16* row = x + g * sx_g + l * sx_l;
+static __device__ __forceinline__ void quantize_row(const QpTensor& t, int g, int l, int lane) {
+  const int R = t.R;
+  const h16* row = t.x + g * t.sx_g + l * t.sx_l;
   constexpr float QMAX = (float)((1 << BITS) - 1);
-  // each lane owns 32-code words: word wdx covers codes [32*wdx, 32*wdx+32)
   float mx = -INFINITY, mn = INFINITY;
   for (int j = lane; j < R; j += 64) {
     float v = (float)row[j];
@@ -46,12 +46,12 @@ __global__ __launch_bounds__(256) void quantize_pack_kernel(const h16* __restric
   float zero = rintf(r16(-mn / scale));
   zero = fminf(fmaxf(zero, 0.f), QMAX);
   if (lane == 0) {
-    h16* m = meta + g * sm_g + l * sm_l;
+    h16* m = t.meta + g * t.sm_g + l * t.sm_l;
     m[0] = (h16)scale;
     m[1] = (h16)zero;
   }
-  unsigned char* crow = codes + g * sc_g + l * sc_l;
-  h16* drow = deq ? deq + g * sd_g + l * sd_l : nullptr;
+  unsigned char* crow = t.codes + g * t.sc_g + l * t.sc_l;
+  h16* drow = t.deq ? t.deq + g * t.sd_g + l * t.sd_l : nullptr;
   // a lane packs 8 consecutive codes (one 3- or 4-byte unit) per step
   for (int u = lane; u < (R >> 3); u += 64) {
     unsigned bits = 0;
@@ -72,6 +72,20 @@ __global__ __launch_bounds__(256) void quantize_pack_kernel(const h16* __restric
       d[1] = (unsigned char)(bits >> 8);
       d[2] = (unsigned char)(bits >> 16);
     }
+  }
+}
+
+// waves [0, G*nrows) -> tensor a, the next G*nrows_b -> tensor b (the K and V latent rows of one decode step)
+template <int BITS>
+__global__ __launch_bounds__(256) void quantize_pack_kernel(QpTensor a, QpTensor b, int G, int nrows, int nrows_b) {
+  const int lane = threadIdx.x & 63;
+  int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t na = (int64_t)G * nrows;
+  if (wid < na) {
+    quantize_row<BITS>(a, (int)(wid / nrows), (int)(wid % nrows), lane);
+  } else {
+    wid -= na;
+    if (wid < (int64_t)G * nrows_b) quantize_row<BITS>(b, (int)(wid / nrows_b), (int)(wid % nrows_b), lane);
   }
 }
 
@@ -134,6 +148,19 @@ bool quant_shape_ok(int bits, int R) {
 
 extern "C" size_t palu_packed_row_bytes(int R, int bits) { return quant_shape_ok(bits, R) ? (size_t)R * bits / 8 : 0; }
 
+namespace {
+int launch_quantize(const QpTensor& ta, const QpTensor& tb, int G, int nrows, int nrows_b, int bits, hipStream_t s) {
+  const int64_t waves = (int64_t)G * (nrows + nrows_b);
+  dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+  if (bits == 4)
+    hipLaunchKernelGGL(quantize_pack_kernel<4>, grid, block, 0, s, ta, tb, G, nrows, nrows_b);
+  else
+    hipLaunchKernelGGL(quantize_pack_kernel<3>, grid, block, 0, s, ta, tb, G, nrows, nrows_b);
+  PALU_LAUNCH_CHECK();
+  return PALU_OK;
+}
+}  // namespace
+
 extern "C" int palu_quantize_pack(const void* x, int64_t sx_g, int64_t sx_l, void* codes, int64_t sc_g, int64_t sc_l,
                                   void* meta, int64_t sm_g, int64_t sm_l, void* dequant, int64_t sd_g, int64_t sd_l,
                                   int G, int nrows, int R, int bits, palu_stream_t stream) {
@@ -142,19 +169,22 @@ extern "C" int palu_quantize_pack(const void* x, int64_t sx_g, int64_t sx_l, voi
                "quantize_pack: bits must be 3 (R %% 32 == 0) or 4 (R %% 8 == 0), got bits=%d R=%d", bits, R);
   PALU_REQUIRE(bits != 4 || (sc_g % 4 == 0 && sc_l % 4 == 0 && ((uintptr_t)codes & 3) == 0), PALU_ERR_ARG,
                "quantize_pack: 4-bit rows must be 4-byte aligned");
-  PALU_REQUIRE(sm_l >= 2, PALU_ERR_ARG, "quantize_pack: meta rows hold (scale, zero)");
+  PALU_REQUIRE(sm_l >= 2 || nrows <= 1, PALU_ERR_ARG, "quantize_pack: meta rows hold (scale, zero)");
   if (nrows == 0) return PALU_OK;
-  const int64_t waves = (int64_t)G * nrows;
-  dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-  hipStream_t s = (hipStream_t)stream;
-  if (bits == 4)
-    hipLaunchKernelGGL(quantize_pack_kernel<4>, grid, block, 0, s, (const h16*)x, sx_g, sx_l, (unsigned char*)codes, sc_g,
-                       sc_l, (h16*)meta, sm_g, sm_l, (h16*)dequant, sd_g, sd_l, G, nrows, R);
-  else
-    hipLaunchKernelGGL(quantize_pack_kernel<3>, grid, block, 0, s, (const h16*)x, sx_g, sx_l, (unsigned char*)codes, sc_g,
-                       sc_l, (h16*)meta, sm_g, sm_l, (h16*)dequant, sd_g, sd_l, G, nrows, R);
-  PALU_LAUNCH_CHECK();
-  return PALU_OK;
+  QpTensor t = {(const h16*)x, sx_g, sx_l, (unsigned char*)codes, sc_g, sc_l, (h16*)meta, sm_g, sm_l,
+                (h16*)dequant, sd_g, sd_l, R};
+  return launch_quantize(t, t, G, nrows, 0, bits, (hipStream_t)stream);
+}
+
+// internal (decode_step.hip): quantise+pack the new K and V latent rows of one step in ONE launch
+int palu_quantize_pack_kv(const void* k, int64_t sk_g, void* k_codes, int64_t skc_g, void* k_meta, int64_t skm_g, int Rk,
+                          const void* v, int64_t sv_g, void* v_codes, int64_t svc_g, void* v_meta, int64_t svm_g, int Rv,
+                          int G, int bits, palu_stream_t stream) {
+  PALU_REQUIRE(quant_shape_ok(bits, Rk) && quant_shape_ok(bits, Rv), PALU_ERR_UNSUPPORTED,
+               "quantize_pack_kv: unsupported bits=%d Rk=%d Rv=%d", bits, Rk, Rv);
+  QpTensor tk = {(const h16*)k, sk_g, 0, (unsigned char*)k_codes, skc_g, 0, (h16*)k_meta, skm_g, 0, nullptr, 0, 0, Rk};
+  QpTensor tv = {(const h16*)v, sv_g, 0, (unsigned char*)v_codes, svc_g, 0, (h16*)v_meta, svm_g, 0, nullptr, 0, 0, Rv};
+  return launch_quantize(tk, tv, G, 1, 1, bits, (hipStream_t)stream);
 }
 
 extern "C" int palu_unpack_dequant(const void* codes, int64_t sc_g, int64_t sc_l, const void* meta, int64_t sm_g,

@@ -482,8 +482,11 @@ class LlamaPaluAttention(nn.Module):
                 f"Attention mask should be of size {(bsz, 1, q_len, kv_seq_len)}, but is {attention_mask.size()}")
 
         fused_o = self.o_proj.in_features == self.fused_hidden_dim_o
+        hip_step_ok = (self.q_proj.bias is None and self.head_dim == 128
+                       and self.group_size in ((1, 2, 4) if isinstance(past_key_value, QuantLatentCache) else (1, 2, 4, 8)))
         if (q_len == 1 and bsz == 1 and isinstance(past_key_value, (LatentCache, QuantLatentCache)) and fused_o
-                and hidden_states.is_cuda and hidden_states.dtype == torch.float16 and hasattr(self.k_proj, "B")):
+                and hip_step_ok and hidden_states.is_cuda and hidden_states.dtype == torch.float16
+                and hasattr(self.k_proj, "B")):
             pos = kv_seq_len - 1 if position_ids is None else int(position_ids.reshape(-1)[-1])
             step = self._decode_fused_q if isinstance(past_key_value, QuantLatentCache) else self._decode_fused
             out, probs = step(hidden_states, attention_mask, pos, past_key_value, output_attentions)
