@@ -59,6 +59,9 @@ extern "C" int palu_abx_rope_f16(const void* a, int64_t sa_h, int64_t sa_d, cons
   PALU_REQUIRE(((uintptr_t)x & 15) == 0 && sx_g % 8 == 0 && sx_l % 8 == 0 && sx_l >= R, PALU_ERR_ARG,
                "abx: x rows must be 16-byte aligned and contiguous (sx_g=%lld sx_l=%lld R=%d)", (long long)sx_g,
                (long long)sx_l, R);
+  // the fast kernel stages X through a buffer descriptor with 32-bit byte offsets per group slab
+  PALU_REQUIRE(((int64_t)L + 3 * 128) * sx_l * 2 < ((int64_t)1 << 32), PALU_ERR_ARG,
+               "abx: one group's latent slab must stay below 4 GiB (L=%d sx_l=%lld)", L, (long long)sx_l);
   PALU_REQUIRE(((uintptr_t)bfrag & 15) == 0, PALU_ERR_ARG, "abx: bfrag must be 16-byte aligned");
   PALU_REQUIRE((int64_t)pos0 + L < (1 << 24), PALU_ERR_UNSUPPORTED, "abx: positions must stay below 2^24");
   const int64_t ob = ((int64_t)(H - 1) * so_h + L) * 2;

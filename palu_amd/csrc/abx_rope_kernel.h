@@ -27,6 +27,8 @@
 #pragma once
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "palu_common.h"
 
 namespace {
@@ -34,12 +36,6 @@ namespace {
 constexpr int TL = 128;        // rows (cache positions) per tile
 constexpr int NTHREADS = 512;  // 8 waves
 constexpr int HEAD_DIM = 128;
-#ifndef PALU_ABX_PRIO
-#define PALU_ABX_PRIO 1
-#endif
-#ifndef PALU_ABX_SGB
-#define PALU_ABX_SGB 0
-#endif
 
 struct AbxParams {
   const h16* a;
@@ -57,6 +53,7 @@ struct AbxParams {
   unsigned long long* dbg;  // optional per-wave cycle stamps (timing build only)
   unsigned out_bytes;       // extent of `out` for the bounds-checked buffer store
   int prio_mode;            // 0 none, 1 static (waves 4-7), 2 alternating per half tile
+  int exp_flags;            // experiments (timing only): bit0 = waves 4-7 skip the MFMA/epilogue work
   // quantised latents (QBITS > 0): packed codes [G, L, R*bits/8] + (scale, zero) fp16 pairs [G, L, 2]
   const unsigned char* xq;
   int64_t sq_g, sq_l;       // bytes
@@ -70,8 +67,10 @@ inline int abx_nmb(int gs) { return gs >= 3 ? 2 : 1; }
 // ---------------------------------------------------------------------------------------------
 // B [H,R,D] -> MFMA A-operand fragments.
 // u32x4 index = ((((gb*8 + w)*NMB + mb)*NKS + ks)*64 + lane);  lane = m + 32*hi holds row m of the
-// M-block, k = 16*ks + 8*hi .. +7.  Row m  <->  u = m&1 (0: d=i, 1: d=i+64), t = (m>>1)&1 (head
-// 2*mb+t of the block), pair = m>>2 (i = 8*w + pair).  Invalid heads / r >= R are zero.
+// M-block, k = 16*ks + 8*hi .. +7.  Row m  <->  t = m&1 (head 2*mb+t of the block), u = (m>>1)&1 (0: d=i,
+// 1: d=i+64), pair = m>>2 (i = 8*w + pair): after the MFMA a lane holds, per pair, the register quad
+// (k_i[h0], k_i[h1], k_{i+64}[h0], k_{i+64}[h1]) -- head pairs adjacent, ready for packed-fp32 math.
+// Invalid heads / r >= R are zero.
 __global__ void abx_prepare_b_kernel(const h16* __restrict__ b, int64_t sb_h, int64_t sb_r, int64_t sb_d,
                                      int H, int G, int R, int nmb, int hb_per_g, int nks,
                                      u32x4* __restrict__ out, int64_t total) {
@@ -85,7 +84,7 @@ __global__ void abx_prepare_b_kernel(const h16* __restrict__ b, int64_t sb_h, in
   int gb = (int)t;
   int g = gb / hb_per_g, hb = gb % hb_per_g;
   int m = lane & 31, hi = lane >> 5;
-  int u = m & 1, tt = (m >> 1) & 1, pair = m >> 2;
+  int tt = m & 1, u = (m >> 1) & 1, pair = m >> 2;
   int gs = H / G;
   int hloc = hb * (2 * nmb) + 2 * mb + tt;
   bool valid = hloc < gs;
@@ -282,7 +281,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_generic_kernel(AbxParams
       for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          float k1 = ac[mb][4 * j + 2 * t], k2 = ac[mb][4 * j + 2 * t + 1];
+          float k1 = ac[mb][4 * j + t], k2 = ac[mb][4 * j + 2 + t];
           int s = 2 * mb + t;
           float t1 = fmaf(q2[s][j], k2, q1[s][j] * k1);
           float t2 = fmaf(-q1[s][j], k2, q2[s][j] * k1);
@@ -374,7 +373,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
   constexpr int NRING = 3;                // X tiles resident in LDS
   constexpr int RED_STRIDE = 8 * 4 * TL;  // floats per red buffer: [8 waves][4 slots][TL]
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  float* red = reinterpret_cast<float*>(smem + NRING * Geo::TILE_BYTES);  // [3][8][4][TL]
+  // red[3][8 waves][4 heads][TL] partial sums follow the tile ring; LDS is addressed by 32-bit offsets
+  // (address-space-3 pointers built from integers) so that every access is lane-constant + immediate
+  const unsigned smem_lds = (unsigned)reinterpret_cast<uintptr_t>(smem);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -402,30 +403,38 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
 
   const h16* xg = p.x + (int64_t)g * p.sx_g;
 
-  // ---- staging by LDS-DMA (global_load_lds_dwordx4): wave w, piece k fills the 64 consecutive 16-byte
-  //      LDS slots [512k + 64w, +64) of a tile; the XOR swizzle is applied to the per-lane SOURCE
-  //      address (the DMA destination is lane-linear).  Hidden from the compiler (inline asm), so the
-  //      completion wait is ours: s_waitcnt vmcnt(0) before the barrier that publishes the tile.
+  // ---- staging by LDS-DMA (buffer_load_dwordx4 ... lds): wave w, piece k fills the 64 consecutive 16-byte
+  //      LDS slots [512k + 64w, +64) of a tile, i.e. rows [k*RPP, (k+1)*RPP) of the tile.  The XOR swizzle is
+  //      applied to the per-lane SOURCE offset (the DMA destination is lane-linear) and does not depend on k,
+  //      so the lane offset is ONE constant VGPR and tile/piece select is a scalar offset: no vector ALU work
+  //      per piece.  Rows past the end of the slab are out of range of the descriptor (read as zero / dropped;
+  //      their scores are never stored).  Hidden from the compiler (inline asm), so the completion wait is
+  //      ours: s_waitcnt vmcnt(0) before the barrier that publishes the tile.
+  constexpr int RPP = NTHREADS / Geo::CPR;                      // rows per piece
+  u32x4 xrs;
+  {
+    const unsigned long long xb = reinterpret_cast<unsigned long long>(xg);
+    xrs[0] = __builtin_amdgcn_readfirstlane((unsigned)xb);
+    xrs[1] = __builtin_amdgcn_readfirstlane((unsigned)(xb >> 32));
+    xrs[2] = __builtin_amdgcn_readfirstlane((unsigned)(((int64_t)(p.L - 1) * p.sx_l + 16 * NKS) * 2));
+    xrs[3] = 0x00020000u;
+  }
+  const unsigned dma_voff = (unsigned)((tid / Geo::CPR) * p.sx_l * 2 + Geo::swz(tid / Geo::CPR, tid % Geo::CPR) * 16);
+  const unsigned row_bytes = __builtin_amdgcn_readfirstlane((unsigned)(p.sx_l * 2));
+  auto dma_piece = [&](int tt, int slot, int k) {
+    const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)((tile0 + tt) * TL + k * RPP) * row_bytes);
+    const unsigned dst = (unsigned)(slot * Geo::TILE_BYTES + (NTHREADS * k + 64 * w) * 16);
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds"
+        :
+        : "s"(dst), "v"(dma_voff), "s"(xrs), "s"(soff)
+        : "memory");
+  };
   auto dma_tile = [&](int tt, int slot) {
-    const int row0 = (tile0 + tt) * TL;
 #pragma unroll
-    for (int k = 0; k < Geo::SPT; ++k) {
-      const int s = tid + NTHREADS * k;
-      const int row = s / Geo::CPR, pp = s % Geo::CPR;
-      const int l = min(row0 + row, p.L - 1);
-      const h16* src = xg + (int64_t)l * p.sx_l + Geo::swz(row, pp) * 8;
-      const unsigned dst = (unsigned)(slot * Geo::TILE_BYTES + (NTHREADS * k + 64 * w) * 16);
-      unsigned keep;
-      asm volatile(
-          "s_mov_b32 %0, m0\n\t"
-          "s_mov_b32 m0, %2\n\t"
-          "s_nop 0\n\t"
-          "global_load_lds_dwordx4 %1, off\n\t"
-          "s_mov_b32 m0, %0"
-          : "=&s"(keep)
-          : "v"(src), "s"(dst)
-          : "memory");
-    }
+    for (int k = 0; k < Geo::SPT; ++k) dma_piece(tt, slot, k);
   };
   auto dma_wait = [&]() {
     if (QBITS == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -516,18 +525,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
     sincos_exact_product(lf, fr[j], &sn[j], &cs[j]);
     sincos_exact_product(32.0f, fr[j], &rs[j], &rc[j]);
   }
-
   stamp();  // 2: rope init done
   // ---- query: either folded into the fragments (FOLD) or kept per (pair, head) for the epilogue
   float q1[FOLD ? 1 : HPW][4], q2[FOLD ? 1 : HPW][4];
   if (FOLD) {
-    // A-fragment lane = row m of the M-block: u = m&1, t = (m>>1)&1, pair = m>>2.
+    // A-fragment lane = row m of the M-block: t = m&1, u = (m>>1)&1, pair = m>>2.
     //   row u=0 (B[:,i])    <- P = q_i B[:,i] + q_{i+64} B[:,i+64]
     //   row u=1 (B[:,i+64]) <- Q = q_{i+64} B[:,i] - q_i B[:,i+64]
-    // i.e. new = c_own*own + q_{i+64}*partner with c_own = +/-q_i; partner row = lane^1 (DPP).
+    // i.e. new = c_own*own + q_{i+64}*partner with c_own = +/-q_i; partner row = lane^2 (DPP).
     // v_dot2_f32_f16: both products exact in fp32, one rounding to fp16 at the end.
     const int m = lane & 31;
-    const int u = m & 1, t = (m >> 1) & 1, pair = m >> 2;
+    const int t = m & 1, u = (m >> 1) & 1, pair = m >> 2;
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb) {
       int hloc = hb * HPW + 2 * mb + t;
@@ -546,7 +554,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           unsigned ow = own[e];
-          unsigned par = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ow, 0xB1, 0xF, 0xF, false);  // lane^1
+          unsigned par = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ow, 0x4E, 0xF, 0xF, false);  // lane^2 (quad_perm 2,3,0,1)
           unsigned lo2 = __builtin_amdgcn_perm(par, ow, 0x05040100u);  // (own.lo, par.lo)
           unsigned hi2 = __builtin_amdgcn_perm(par, ow, 0x07060302u);  // (own.hi, par.hi)
           float r0 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, lo2), coef, 0.f, false);
@@ -580,12 +588,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
   // out-of-range offset that the hardware drops, so the store needs no branch inside the MFMA stream
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
 
-  auto reduce_store = [&](int tt) {
+  // cross-wave reduction of tile tt (partials in red[rslot]) and the fp16 store
+  auto reduce_store = [&](int tt, int rslot) {
     const int slot = tid >> 7, pos = tid & 127;
-    const float* r = red + (size_t)((tt + 3) % 3) * RED_STRIDE + (slot & 3) * TL + pos;
+    unsigned r = smem_lds + (unsigned)(NRING * Geo::TILE_BYTES) +
+                 (unsigned)((rslot * RED_STRIDE + (slot & 3) * TL + pos) * sizeof(float));
+    asm volatile("" : "+v"(r));                 // keep the wave strides in the immediates
     float s = 0.f;
 #pragma unroll
-    for (int ww = 0; ww < 8; ++ww) s += r[ww * 4 * TL];
+    for (int ww = 0; ww < 8; ++ww)
+      s += *(const __attribute__((address_space(3))) float*)(uintptr_t)(r + (unsigned)(ww * 4 * TL * sizeof(float)));
     const int l = (tile0 + tt) * TL + pos;
     const int hloc = hb * HPW + slot;
     const bool ok = tt >= 0 && slot < HPW && l < p.L && hloc < p.gs;
@@ -596,72 +608,136 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
   // X fragments are prefetched XD k-steps ahead through a ring of XD registers-sets: the fragment of
   // k-step ks lives in xf[ks % XD] and is refilled with the fragment XD k-steps later (possibly of the
   // next block) right after its MFMAs have issued -> LDS latency never sits in front of an MFMA.
+  // LDS byte address of the fragment (tile slot, block blk, k-step ks) = fa[ks] + blk*32*RB: the swizzle key
+  // (row >> SH) & MASK does not depend on blk, so fa[ks] is one lane-constant VGPR per k-step that only moves
+  // by the (scalar) ring-slot distance once per tile; blk rides in the instruction's immediate offset.
   constexpr int XD = NKS < 4 ? NKS : 4;
   h16x8 xf[XD];
-  auto read_frag = [&](const char* xs, int blk, int ks) {
-    const int row = blk * 32 + n;
-    return *reinterpret_cast<const h16x8*>(xs + row * Geo::RB + Geo::swz(row, 2 * ks + hi) * 16);
-  };
-  auto load_xf = [&](const char* xs, int blk) {
+  unsigned fa[NKS];
 #pragma unroll
-    for (int ks = 0; ks < XD; ++ks) xf[ks] = read_frag(xs, blk, ks);
+  for (int ks = 0; ks < NKS; ++ks) fa[ks] = smem_lds + (unsigned)(n * Geo::RB + Geo::swz(n, 2 * ks + hi) * 16);
+  auto read_frag = [&](int i, int blk) {
+    return *(const __attribute__((address_space(3))) h16x8*)(uintptr_t)(fa[i] + (unsigned)(blk * 32 * Geo::RB));
   };
-  // MFMAs of one 32-row block (this tile `xs`, block `blk`); (nxs, nblk) = the block that follows
-  auto mfma_block = [&](f32x16 (&ac)[NMB], const char* xs, int blk, const char* nxs, int nblk) {
+  // partial sums: after the half-swap below, lane (n, hi) holds head 2mb + hi of position n
+  const unsigned red_lane = smem_lds + (unsigned)(NRING * Geo::TILE_BYTES) +
+                            (unsigned)(((w * 4 + hi) * TL + n) * sizeof(float));
+
+  // RoPE state of the epilogue lives in fr/rc/rs/cs/sn/lf (above).
+  // ---- hand-interleaved region: the NKS*NMB MFMAs of block blk of the current tile and the epilogue of the
+  //      PREVIOUS block (accumulators acP, written to red[erslot] as block eblk) are emitted alternately -- one
+  //      epilogue chunk (4 VALU ops: coefficients of a pair | the pair's 2 FMAs x 2 heads of an M-block | state
+  //      advance) per MFMA gap -- and pinned with sched_barrier(0): left alone, hipcc clusters 8 MFMAs then ~60
+  //      VALU, and a wave's matrix and vector time simply add up (measured: 49 % MFMA issue for a lone wave).
+  //      The SIMD issues about one instruction per 4-5 cycles whatever its type, so instruction COUNT is what
+  //      bounds this kernel: addresses are lane constants + immediates, staging offsets are scalar.
+  //      KIND 0 also carries the LDS-DMA pieces of tile stt into ring slot sslot (or the quantised staging),
+  //      KIND 1 the reduce/store of tile stt (partials in red[sslot]); LAST = block 3: the fragment prefetch
+  //      crosses into block 0 of the next tile (ring distance nd bytes); KIND 3 = drain (epilogue only).
+  auto region = [&](auto kind_c, auto last_c, f32x16 (&acN)[NMB], int blk, int erslot, int eblk,
+                    const f32x16 (&acP)[NMB], int stt, int sslot, unsigned nd) {
+    constexpr int KIND = decltype(kind_c)::value;
+    constexpr bool LAST = decltype(last_c)::value;
+    constexpr int GAPS = NKS * NMB;
+    // chunks per pair j: [ang, lo, cc, ss] | per M-block: 2 FMAs x 2 heads | [advance cos, sin by 32 positions].
+    // (Packed fp32 -- v_pk_fma_f32 over head pairs -- was measured and is an anti-lever beside MFMAs on gfx950:
+    //  75.5 vs 69 us; hipcc itself unpacks half of them again in the MFMA shadow.)
+    constexpr int CPP = 2 + NMB;
+    constexpr int NC = 4 * CPP;
+    constexpr int CPG = (NC + GAPS - 1) / GAPS;
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) ac[mb][e] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-#pragma unroll
-      for (int mb = 0; mb < NMB; ++mb)
-        ac[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[mb][ks], xf[ks % XD], ac[mb], 0, 0, 0);
-      xf[ks % XD] = (ks + XD < NKS) ? read_frag(xs, blk, ks + XD) : read_frag(nxs, nblk, ks + XD - NKS);
-    }
-  };
-
-  auto epilogue = [&](int tt, int blk, const f32x16 (&ac)[NMB]) {
+      for (int e = 0; e < 16; ++e) acN[mb][e] = 0.f;
     float part[HPW];
 #pragma unroll
     for (int s = 0; s < HPW; ++s) part[s] = 0.f;
+    float cc = 0.f, ss = 0.f;
+    auto chunk = [&](int c) {
+      const int j = c / CPP, t = c % CPP;
+      if (t == 0) {
+        // cos/sin at the oracle's fp32-rounded angle fl(l*f): exact angle = ang + lo (first order in lo;
+        // the dropped term lo^2/2 is < 3.1e-5 for positions < 2^18)
+        const float ang = lf * fr[j];
+        const float lo = fmaf(lf, fr[j], -ang);
+        cc = fmaf(lo, sn[j], cs[j]);
+        ss = fmaf(-lo, cs[j], sn[j]);
+        asm volatile("" : "+v"(cc), "+v"(ss));
+      } else if (t <= NMB) {
+        const int mb = t - 1;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      // cos/sin at the oracle's fp32-rounded angle ang = fl(l*f): exact angle = ang + lo, |lo| <= ulp(ang)/2
-      // (first order in lo; the dropped term lo^2/2 is < 3.1e-5 for positions < 2^18)
-      float ang = lf * fr[j];
-      float lo = fmaf(lf, fr[j], -ang);
-      float cc = fmaf(lo, sn[j], cs[j]);
-      float ss = fmaf(-lo, cs[j], sn[j]);
-#pragma unroll
-      for (int mb = 0; mb < NMB; ++mb)
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          float k1 = ac[mb][4 * j + 2 * t], k2 = ac[mb][4 * j + 2 * t + 1];
-          int s = 2 * mb + t;
+        for (int h2 = 0; h2 < 2; ++h2) {
+          const float k1 = acP[mb][4 * j + h2], k2 = acP[mb][4 * j + 2 + h2];
+          const int s = 2 * mb + h2;
           if (FOLD) {
             part[s] = fmaf(cc, k1, fmaf(ss, k2, part[s]));
           } else {
-            float t1 = fmaf(q2[s][j], k2, q1[s][j] * k1);
-            float t2 = fmaf(-q1[s][j], k2, q2[s][j] * k1);
+            const float t1 = fmaf(q2[s][j], k2, q1[s][j] * k1);
+            const float t2 = fmaf(-q1[s][j], k2, q2[s][j] * k1);
             part[s] = fmaf(cc, t1, fmaf(ss, t2, part[s]));
           }
+          asm volatile("" : "+v"(part[s]));
         }
-      float c2 = fmaf(-sn[j], rs[j], cs[j] * rc[j]);  // advance the exact-angle state by 32 positions
-      float s2 = fmaf(cs[j], rs[j], sn[j] * rc[j]);
-      cs[j] = c2;
-      sn[j] = s2;
+      } else {
+        // advance the exact-angle state by 32 positions: (c, s) <- (c*rc - s*rs, s*rc + c*rs)
+        const float c2 = fmaf(-sn[j], rs[j], cs[j] * rc[j]);
+        sn[j] = fmaf(cs[j], rs[j], sn[j] * rc[j]);
+        cs[j] = c2;
+        asm volatile("" : "+v"(cs[j]), "+v"(sn[j]));
+      }
+    };
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb) {
+        const int gap = ks * NMB + mb;
+        if (KIND != 3) {
+          acN[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[mb][ks], xf[ks % XD], acN[mb], 0, 0, 0);
+          asm volatile("" : "+v"(acN[mb]));    // empty volatile asm = ordering pin (arithmetic floats across sched_barrier)
+        }
+#pragma unroll
+        for (int q = 0; q < CPG; ++q)
+          if (gap * CPG + q < NC) chunk(gap * CPG + q);
+        if (KIND != 3 && mb == NMB - 1) {
+          // refill the ring entry just consumed with the fragment XD k-steps ahead
+          const int r = ks + XD;
+          if (r < NKS) {
+            xf[ks % XD] = read_frag(r, blk);
+            if (LAST) {                        // fa[r] has served its last read of this tile: move it to the next slot
+              fa[r] += nd;
+              asm volatile("" : "+v"(fa[r]));
+            }
+          } else {
+            if (LAST) {
+              fa[r - NKS] += nd;
+              asm volatile("" : "+v"(fa[r - NKS]));
+              xf[ks % XD] = read_frag(r - NKS, 0);
+            } else {
+              xf[ks % XD] = read_frag(r - NKS, blk + 1);
+            }
+          }
+        }
+        if (KIND == 0 && QBITS == 0 && gap % (2 * NMB) == 1 && gap / (2 * NMB) < Geo::SPT)
+          dma_piece(stt, sslot, gap / (2 * NMB));
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     lf += 32.0f;
-    float* rdst = red + (size_t)((tt + 3) % 3) * RED_STRIDE + (size_t)w * (4 * TL) + blk * 32 + n;
+    // lanes n and n+32 hold complementary pairs of the same position: one half-swap per head PAIR leaves head
+    // 2mb in the low half and head 2mb+1 in the high half, so one add and one store cover two heads
+    const unsigned rdst = red_lane + (unsigned)((erslot * RED_STRIDE + eblk * 32) * sizeof(float));
 #pragma unroll
-    for (int s = 0; s < HPW; ++s) {
-      // lanes n and n+32 hold complementary pairs: swap halves in-register; both halves then hold
-      // the same sum and write the same word (benign duplicate store, keeps the block branch-free)
-      unsigned pv = __float_as_uint(part[s]);
-      auto sw = __builtin_amdgcn_permlane32_swap(pv, pv, false, false);
-      rdst[s * TL] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    for (int mb = 0; mb < NMB; ++mb) {
+      auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(part[2 * mb]), __float_as_uint(part[2 * mb + 1]), false, false);
+      *(__attribute__((address_space(3))) float*)(uintptr_t)(rdst + (unsigned)(mb * 2 * TL * sizeof(float))) =
+          __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
+    if (KIND == 0 && QBITS != 0) {
+      store_q(sslot);                         // registers hold tile min(stt, ntile-1)
+      load_q(min(stt + 1, ntile - 1));
+    }
+    if (KIND == 1) reduce_store(stt, sslot);
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   f32x16 accA[NMB], accB[NMB];
@@ -680,20 +756,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
   dma_wait();
   stamp();  // 4: first tiles landed
   __syncthreads();
-  load_xf(smem, 0);
-
-  // optional explicit interleave of one {MFMA block, epilogue} region: 1 MFMA : PALU_ABX_SGB VALU (+ LDS reads)
-  auto interleave = [&]() {
-#if PALU_ABX_SGB > 0
 #pragma unroll
-    for (int i = 0; i < NKS * NMB; ++i) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);               // MFMA
-      __builtin_amdgcn_sched_group_barrier(0x002, PALU_ABX_SGB, 0);    // VALU
-      if ((i % NMB) == NMB - 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one X-fragment ds_read per k-step
-    }
-#endif
-  };
+  for (int ks = 0; ks < XD; ++ks) xf[ks] = read_frag(ks, 0);
 
+  using K0 = std::integral_constant<int, 0>;
+  using K1 = std::integral_constant<int, 1>;
+  using K2 = std::integral_constant<int, 2>;
+  using K3 = std::integral_constant<int, 3>;
+  using NotLast = std::false_type;
+  using Last = std::true_type;
+  // ring slots: tile tt sits in slot tt % 3 (LDS ring and red[] alike); kept as three rotating scalars
+  int s_cur = 0, s_nxt = 1, s_prv = 2;     // tt % 3, (tt + 1) % 3, (tt + 2) % 3 == (tt - 1) % 3
   for (int tt = 0; tt < ntile; ++tt) {
     stamp();  // 5+2*tt: arrive at barrier
     if (tt > 0) {
@@ -702,41 +775,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
     }
     stamp();  // 6+2*tt: leave barrier
     if (p.prio_mode == 2 && young) __builtin_amdgcn_s_setprio(1);  // young half leads the first half tile
-    // one straight-line region per tile: MFMAs of block b+1, RoPE epilogue of block b, staging of tile
-    // tt+2 into the ring, prefetch of tile tt+3, cross-wave reduction + store of tile tt-2
-    const char* xs = smem + (tt % NRING) * Geo::TILE_BYTES;
-    const char* xn = smem + ((tt + 1) % NRING) * Geo::TILE_BYTES;
-    mfma_block(accA, xs, 0, xs, 1);
-    if (QBITS == 0) {
-      dma_tile(min(tt + 2, ntile - 1), (tt + 2) % NRING);
-    } else {
-      store_q((tt + 2) % NRING);              // registers hold tile min(tt+2, ntile-1)
-      load_q(min(tt + 3, ntile - 1));
-    }
-    epilogue(tt - 1, 3, accB);  // tt == 0: discarded (writes a slot that is rewritten before use)
-    interleave();
-    __builtin_amdgcn_sched_barrier(0);  // keep each {MFMA block b+1, epilogue b} pair its own scheduling region
-    mfma_block(accB, xs, 1, xs, 2);
-    reduce_store(tt - 2);
-    epilogue(tt, 0, accA);
-    interleave();
-    __builtin_amdgcn_sched_barrier(0);
+    // one straight-line region per block: MFMAs of block b+1, RoPE epilogue of block b, staging of tile
+    // tt+2 into the ring, cross-wave reduction + store of tile tt-2
+    if (TIMING && (p.exp_flags & 1) && young) continue;   // experiment: one computing wave per SIMD
+    const unsigned nd = (unsigned)((s_nxt - s_cur) * Geo::TILE_BYTES);
+    region(K0{}, NotLast{}, accA, 0, s_prv, 3, accB, min(tt + 2, ntile - 1), s_prv, 0u);   // tt == 0: epilogue result discarded
+    region(K1{}, NotLast{}, accB, 1, s_cur, 0, accA, tt - 2, s_nxt, 0u);
     if (p.prio_mode == 2 && young) __builtin_amdgcn_s_setprio(0);  // ... the old half catches up in the second
-    mfma_block(accA, xs, 2, xs, 3);
-    epilogue(tt, 1, accB);
-    interleave();
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_block(accB, xs, 3, xn, 0);  // prefetches block 0 of the next tile (staged one barrier ago)
-    epilogue(tt, 2, accA);
-    interleave();
-    __builtin_amdgcn_sched_barrier(0);
+    region(K2{}, NotLast{}, accA, 2, s_cur, 1, accB, 0, 0, 0u);
+    region(K2{}, Last{}, accB, 3, s_cur, 2, accA, 0, 0, nd);       // prefetches block 0 of the next tile
+    const int t3 = s_prv;
+    s_prv = s_cur;
+    s_cur = s_nxt;
+    s_nxt = t3;
   }
-  epilogue(ntile - 1, 3, accB);
+  region(K3{}, NotLast{}, accA, 0, s_prv, 3, accB, 0, 0, 0u);      // epilogue of the very last block
   stamp();
   dma_wait();
   __syncthreads();
-  reduce_store(ntile - 2);
-  reduce_store(ntile - 1);
+  reduce_store(ntile - 2, s_nxt);   // (ntile - 2) % 3 == (ntile + 1) % 3
+  reduce_store(ntile - 1, s_prv);
   stamp();
 }
 
@@ -790,6 +848,10 @@ inline int abx_fill_params(AbxParams& p, const AbxPlan& pl, int H, int G, int L,
   p.nkc = pl.nkc;
   p.dbg = nullptr;
   p.prio_mode = abx_prio_mode();
+  {
+    const char* e = getenv("PALU_ABX_EXP");
+    p.exp_flags = e ? atoi(e) : 0;
+  }
   const int ngb = G * pl.hb;
   int nch = palu_num_cus() / ngb;   // one 8-wave workgroup per CU
   if (nch < 1) nch = 1;

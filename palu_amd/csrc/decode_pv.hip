@@ -9,6 +9,8 @@
 //   pv_combine : merges the splits, normalises, rounds once to fp16
 //   probs      : optional attention weights (output_attentions=True), fp16 like :238
 // x = fp16(fp16(score)/sqrt(D)) [+ mask], the rounding points of the reference's fp16 tensors.
+#include <stdlib.h>
+
 #include "palu_common.h"
 
 namespace {
@@ -75,7 +77,11 @@ __global__ __launch_bounds__(PV_THREADS) void pv_partial_kernel(PvParams p) {
   auto load_batch = [&](u32x4 (&raw)[U], int i) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
+#ifdef PALU_PV_PLAIN_LOADS
+      raw[u] = *reinterpret_cast<const u32x4*>(vb + (int64_t)min(i + u * rpp, nlast) * p.sv_l);
+#else
       raw[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (int64_t)min(i + u * rpp, nlast) * p.sv_l));
+#endif
   };
   u32x4 rawA[U], rawB[U];
   if (streamer) load_batch(rawA, rg);   // in flight while the softmax statistics are computed
@@ -451,12 +457,21 @@ __global__ void probs_kernel(const h16* scores, int64_t ss_h, const h16* mask, c
 }
 
 int pv_rows_per_split(int G, int L) {
-  // ~4 workgroups per CU in flight; 64-row granularity; at most 1024 rows (LDS) and at least 128
-  long long target = 4LL * palu_num_cus();
-  long long rps = ((long long)L * G + target - 1) / target;
-  rps = (rps + 63) / 64 * 64;
+  // ~PALU_PV_WGS_PER_CU (default 4) workgroups per CU in flight; 64-row granularity; at most 1024 rows (LDS), at least 128
+  static int per_cu = 0;
+  if (per_cu == 0) {
+    const char* e = getenv("PALU_PV_WGS_PER_CU");
+    per_cu = e ? atoi(e) : 4;
+    if (per_cu < 1) per_cu = 1;
+  }
+  // whole multiples of the CU count: every CU gets the same number of workgroups (no straggler round)
+  const int cus = palu_num_cus();
+  long long nsplit = ((long long)per_cu * cus + G - 1) / G;
+  if (nsplit < 1) nsplit = 1;
+  long long rps = (L + nsplit - 1) / nsplit;
+  rps = (rps + 7) / 8 * 8;
   if (rps < 128) rps = 128;
-  if (rps > 1024) rps = 1024;
+  if (rps > 2048) rps = 2048;
   return (int)rps;
 }
 
