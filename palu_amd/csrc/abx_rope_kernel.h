@@ -800,7 +800,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
 
 
 template <typename K>
-int launch_kernel(K kern, int smem, bool* attr_done, const AbxParams& p, int nwg, hipStream_t stream) {
+int launch_kernel(K kern, int smem, bool* attr_done, const AbxParams& p, int nwg, hipStream_t stream,
+                  int nthreads = NTHREADS) {
   if (!*attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -810,7 +811,7 @@ int launch_kernel(K kern, int smem, bool* attr_done, const AbxParams& p, int nwg
     }
     *attr_done = true;
   }
-  hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), smem, stream, p);
+  hipLaunchKernelGGL(kern, dim3(nwg), dim3(nthreads), smem, stream, p);
   PALU_LAUNCH_CHECK();
   return PALU_OK;
 }

@@ -29,6 +29,8 @@ for it in range(3):
                   torch.cuda.current_stream().cuda_stream), "timed")
     torch.cuda.synchronize()
 d = dbg.cpu().numpy().reshape(-1, 8, 64)[:nwg.value]
+nwv = int((d[0, :, 0] != 0).sum())          # 8 waves, or 4 for the one-wave-per-SIMD kernel (PALU_ABX_W4=1)
+d = d[:, :nwv]
 nst = int((d[0, 0] != 0).sum())
 print("nwg", nwg.value, "stamps", nst)
 # stamps: 0 start, 1 prologue done, 2 first tiles issued, then per tile (arrive, leave), last epilogue, end
@@ -43,11 +45,19 @@ rel = sub - sub[:, :1, :1]
 ntile = (nst - 7) // 2
 names = ["start", "B issued", "rope init", "fold", "dma landed"]
 for i, nm in enumerate(names):
-    print(f"{nm:12s} w0 {rel[:, 0, i].mean():8.0f}  w3 {rel[:, 3, i].mean():8.0f} w4 {rel[:, 4, i].mean():8.0f} w7 {rel[:, 7, i].mean():8.0f}")
+    print(f"{nm:12s} " + "  ".join(f"w{k} {rel[:, k, i].mean():8.0f}" for k in sorted({0, 3, nwv // 2, nwv - 1})))
 L0 = 6   # first leave
 print("first leave:", rel[:, :, L0].mean())
 per = [(rel[:, :, L0 + 2 * t] - rel[:, :, L0 + 2 * (t - 1)]).mean() for t in range(1, ntile)]
 print("tile period (leave->leave) mean over waves:", np.round(per))
 wait = [(rel[:, :, L0 + 2 * t] - rel[:, :, L0 - 1 + 2 * t]) for t in range(1, ntile)]
-print("barrier wait: waves0-3 mean", np.mean([w_[:, :4].mean() for w_ in wait]), " waves4-7 mean", np.mean([w_[:, 4:].mean() for w_ in wait]))
+print("barrier wait: first half of the waves mean", np.mean([w_[:, :nwv // 2].mean() for w_ in wait]), " second half mean", np.mean([w_[:, nwv // 2:].mean() for w_ in wait]))
+import time
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for it in range(20):
+    fn(a.data_ptr(), a.stride(0), a.stride(2), frag.data_ptr(), x.data_ptr(), x.stride(0), x.stride(1),
+       out.data_ptr(), out.stride(0), H, G, L, R, inv.data_ptr(), 0, dbg.data_ptr(), C.byref(nwg),
+       torch.cuda.current_stream().cuda_stream)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
+print(f"wall {dt*1e6:.1f} us/call (timing build, back-to-back) -> {rel[:, :, nst - 1].max(axis=1).mean() / dt * 1e-9:.2f} ticks/ns")
 print("tail (last leave -> end):", (rel[:, :, nst - 1] - rel[:, :, L0 + 2 * (ntile - 1)]).mean(), " total", rel[:, :, nst - 1].max(axis=1).mean())
