@@ -46,6 +46,8 @@ ntile = (nst - 7) // 2
 names = ["start", "B issued", "rope init", "fold", "dma landed"]
 for i, nm in enumerate(names):
     print(f"{nm:12s} " + "  ".join(f"w{k} {rel[:, k, i].mean():8.0f}" for k in sorted({0, 3, nwv // 2, nwv - 1})))
+for i, nm in enumerate(names + ["arrive0", "leave0"]):
+    print(f"{nm:12s} per-wave mean " + " ".join(f"{rel[:, k, i].mean():7.0f}" for k in range(nwv)) + f"   slowest wave of a WG: mean {rel[:, :, i].max(axis=1).mean():.0f} max {rel[:, :, i].max():.0f}")
 L0 = 6   # first leave
 print("first leave:", rel[:, :, L0].mean())
 per = [(rel[:, :, L0 + 2 * t] - rel[:, :, L0 + 2 * (t - 1)]).mean() for t in range(1, ntile)]
