@@ -188,6 +188,26 @@ int palu_lowrank_project_gemm(const void* x, int64_t ldx, const void* w, int64_t
                               void* out, int64_t so_g, int64_t so_l,
                               int M, int N, int K, int R, int row0, palu_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Prefill attention over the latent value cache: the q_len > 1 branch of
+ * LlamaPaluAttention.forward (kernel/palu_attention.py:196-206 scores, :229-238 mask + softmax,
+ * :246-255 latent P.V and head concat), flash-style -- the [Tq x Tk] score matrix of :205 is never
+ * materialised:
+ *   out[t, h*Rv + c] = sum_j softmax_j(q[h,t,:].k[h,j,:] * scale, j <= past + t if causal) * V_lat[h/gs, j, c]
+ * q:  [H, Tq, D] RoPE'd queries (element strides sq_h, sq_t; D contiguous), row t = position past + t
+ * k:  [H, Tk, D] reconstructed + RoPE'd keys (sk_h, sk_t)
+ * vt: [G, Rv, Tk] latent values TRANSPOSED (kv contiguous; strides sv_g, sv_c), each row zero-padded
+ *     to a multiple of 64 positions (sv_c >= round_up(Tk, 64)) -- a transient prefill workspace
+ * out:[Tq, H*Rv] fp16 (row stride so_t) = the operand of the fused o_proj (:257)
+ * causal != 0: the standard causal mask of the HF caller (additive -inf above the diagonal);
+ * causal == 0: no mask (what :229 does when attention_mask is None).  fp32 online softmax.
+ * D must be 128, Rv % 32 == 0.
+ */
+int palu_prefill_attn_f16(const void* q, int64_t sq_h, int64_t sq_t, const void* k, int64_t sk_h, int64_t sk_t,
+                          const void* vt, int64_t sv_g, int64_t sv_c, void* out, int64_t so_t, int H, int G,
+                          int D, int Tq, int Tk, int Rv, int past, int causal, float scale,
+                          palu_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

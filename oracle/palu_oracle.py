@@ -18,7 +18,7 @@ import torch
 
 __all__ = [
     "rope_inv_freq", "rope_cos_sin", "rope_rotate", "abx_scores", "abx_scores_f64",
-    "build_b_from_u", "fuse_uv_into_wo", "decode_step", "quantize_rows",
+    "build_b_from_u", "fuse_uv_into_wo", "decode_step", "prefill", "quantize_rows",
     "pack_codes", "unpack_codes", "packed_row_bytes", "dequant_codes",
     "fwht", "had12", "apply_hadamard", "fuse_hadamard_into_weights",
 ]
@@ -120,6 +120,51 @@ def fuse_uv_into_wo(wo: torch.Tensor, uv_weights, group_size: int, head_dim: int
             cols.append(wo[:, h * head_dim:(h + 1) * head_dim] @ u[j * head_dim:(j + 1) * head_dim, :])
             h += 1
     return torch.cat(cols, dim=1)
+
+
+# ------------------------------------------------------------------- prefill (q_len > 1)
+def prefill(hidden: torch.Tensor, weights: Dict[str, torch.Tensor], attention_mask: Optional[torch.Tensor] = None,
+            theta: float = 10000.0):
+    """Prompt pass of the low-rank attention module (batch 1, empty cache), fp16 tensors on CPU.
+
+    hidden [T, hidden] fp16; weights: wq [H*D,hidden], vt_k [G*Rk,hidden], vt_v [G*Rv,hidden], u_k: list of G
+    tensors [gs*D, Rk], wo [hidden, H*Rv] (U_v already folded in); attention_mask: additive [T, T] or None.
+    Returns (attn_output [T, hidden] fp16, attn_weights [H, T, T] fp16, k_lat [G,T,Rk], v_lat [G,T,Rv]).
+
+    Follows kernel/palu_attention.py:147-263, prompt branch :196-206:
+      projections :164-174; key reconstruction through U (HeadwiseLowRankModule.reconstruct :67-77) :199-201;
+      HF-4.37.2 RoPE on q and k in the activation dtype :204-205; q.k^T / sqrt(D) :206; mask :229-234;
+      softmax fp32 -> fp16 :238; latent P.V with the [G, gs*q, kv] reshape :246-251; o_proj :257.
+    """
+    wq, vt_k, vt_v, u_k, wo = (weights[k] for k in ("wq", "vt_k", "vt_v", "u_k", "wo"))
+    T = hidden.shape[0]
+    G = len(u_k)
+    Rk = u_k[0].shape[1]
+    D = 128 if "head_dim" not in weights else int(weights["head_dim"])
+    gs = u_k[0].shape[0] // D
+    H = G * gs
+    Rv = vt_v.shape[0] // G
+    lin = torch.nn.functional.linear
+    q = lin(hidden, wq).reshape(T, H, D).transpose(0, 1)                       # [H,T,D]
+    k_lat = lin(hidden, vt_k).reshape(T, G, Rk).transpose(0, 1).contiguous()   # [G,T,Rk]
+    v_lat = lin(hidden, vt_v).reshape(T, G, Rv).transpose(0, 1).contiguous()   # [G,T,Rv]
+    keys = torch.cat([lin(k_lat[g], u_k[g]) for g in range(G)], dim=-1)        # [T, H*D]  (:67-77)
+    keys = keys.reshape(T, H, D).transpose(0, 1)                               # [H,T,D]
+    cos, sin = rope_cos_sin(T, D, theta)
+    cos, sin = cos.to(q.dtype), sin.to(q.dtype)
+
+    def rot(x):
+        return x * cos + torch.cat((-x[..., D // 2:], x[..., :D // 2]), dim=-1) * sin
+
+    q, keys = rot(q), rot(keys)
+    scores = torch.matmul(q, keys.transpose(1, 2)) / math.sqrt(D)             # [H,T,T]
+    if attention_mask is not None:
+        scores = scores + attention_mask.reshape(1, T, T)
+    probs = torch.softmax(scores, dim=-1, dtype=torch.float32).to(q.dtype)
+    ctx = torch.matmul(probs.reshape(G, gs * T, T), v_lat)                     # [G, gs*T, Rv]
+    ctx = ctx.reshape(H, T, Rv).transpose(0, 1).reshape(T, H * Rv)
+    out = lin(ctx, wo)
+    return out, probs, k_lat, v_lat
 
 
 # ------------------------------------------------------------------- decode step

@@ -1,0 +1,299 @@
+// Prefill attention over the latent value cache (the q_len > 1 branch, kernel/palu_attention.py:196-257):
+//   out[t, h*Rv + c] = sum_j softmax_j( q~[h,t,:] . k~[h,j,:] * scale  [j <= past + t if causal] ) * V_lat[g, j, c]
+// as a flash-style MFMA kernel: the [Tq x Tk] score matrix is never materialised (the reference builds it in
+// full, palu_attention.py:205,238), P.V runs in the latent space (Rv columns per head, shared by the gs heads of a
+// group, :246-251), softmax statistics are fp32 and online.
+//
+// Operand plan (everything "k-contiguous", so no LDS transposes):
+//   S^T = K~ . Q~^T      A = K~ rows (kv), B = Q~ rows (t)            -> C layout: lane = query t, 16 kv per block
+//   O^T = V^T . P^T      A = V^T rows (latent column c, kv contiguous), B = P^T = the lane's own S^T registers
+// so the softmax statistics, the rescale of O and the final 1/l are all lane-local (lane = query).  The rows of
+// the K~ A-fragment are read in the order "bits 2 and 3 of the row swapped", which makes the 8 registers of a
+// k-step hold 8 CONSECUTIVE kv positions -- exactly what the V^T A-fragment supplies with one ds_read_b128.
+// V^T ([G][Rv][Tk], kv contiguous, zero-padded to a multiple of 64) is a transient prefill workspace written by
+// the host side; the latent cache itself keeps the decode layout.
+//
+// One 256-thread workgroup = 128 queries (32 per wave) x one head x one chunk of 32*NCB latent columns; K~/V^T
+// tiles of 64 kv go through a double-buffered LDS image (XOR-swizzled 16-byte chunks, register-staged).
+#include "palu_common.h"
+
+namespace {
+
+constexpr int PF_THREADS = 256;
+constexpr int PF_BM = 128;   // queries per workgroup
+constexpr int PF_BN = 64;    // kv positions per tile
+
+struct PfParams {
+  const h16* q;
+  const h16* k;
+  const h16* vt;
+  h16* out;
+  int64_t sq_h, sq_t, sk_h, sk_t, sv_g, sv_c, so_t;
+  int H, G, gs, Tq, Tk, Rv, past, causal;
+  float scale_log2;   // scale * log2(e)
+  int nqt;
+};
+
+template <int NCB>
+__global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(PfParams p) {
+  constexpr int KS_BYTES = PF_BN * 256;            // K~ tile: 64 rows x 128 fp16
+  constexpr int VS_BYTES = 32 * NCB * 128;         // V^T tile: 32*NCB rows (columns c) x 64 kv
+  constexpr int VLD = NCB;                         // 16-byte chunks of the V^T tile per thread
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ks_base = smem;
+  char* vs_base = smem + 2 * KS_BYTES;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = tid >> 6;
+  const int n = lane & 31, hi = lane >> 5;
+  const int qt = p.nqt - 1 - (int)blockIdx.x;      // heavy (late) query tiles first
+  const int h = blockIdx.y;
+  const int g = h / p.gs;
+  const int c0 = blockIdx.z * 32 * NCB;
+
+  const int qrow = qt * PF_BM + w * 32 + n;
+  const bool qvalid = qrow < p.Tq;
+  const int qpos = p.past + qrow;
+
+  // Q~ fragments (B operand of S^T): lane (t, hi) holds Q~[t][16ks + 8hi .. +7]
+  h16x8 qf[8];
+  {
+    const h16* qp = p.q + (int64_t)h * p.sq_h + (int64_t)(qvalid ? qrow : 0) * p.sq_t + 8 * hi;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(qp + 16 * ks);
+      if (!qvalid) v = u32x4{0, 0, 0, 0};
+      qf[ks] = __builtin_bit_cast(h16x8, v);
+    }
+  }
+
+  // number of kv tiles this workgroup needs
+  int kv_end = p.Tk;
+  if (p.causal) {
+    const int last_q = min(p.Tq, (qt + 1) * PF_BM) - 1;
+    kv_end = min(p.Tk, p.past + last_q + 1);
+  }
+  const int njt = (kv_end + PF_BN - 1) / PF_BN;
+
+  // ---- staging: global -> registers -> LDS (swizzled 16-byte chunks)
+  const h16* kg = p.k + (int64_t)h * p.sk_h;
+  const h16* vg = p.vt + (int64_t)g * p.sv_g + (int64_t)c0 * p.sv_c;
+  u32x4 kreg[4], vreg[VLD];
+  auto load_k = [&](int jt) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int s = tid + PF_THREADS * i;
+      const int row = s >> 4, ch = s & 15;
+      const int j = min(jt * PF_BN + row, p.Tk - 1);         // rows past the end repeat the last one (masked below)
+      kreg[i] = *reinterpret_cast<const u32x4*>(kg + (int64_t)j * p.sk_t + ch * 8);
+    }
+  };
+  auto load_v = [&](int jt) {
+#pragma unroll
+    for (int i = 0; i < VLD; ++i) {
+      const int s = tid + PF_THREADS * i;
+      const int row = s >> 3, ch = s & 7;
+      vreg[i] = *reinterpret_cast<const u32x4*>(vg + (int64_t)row * p.sv_c + jt * PF_BN + ch * 8);   // zero-padded rows
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* ks = ks_base + buf * KS_BYTES;
+    char* vs = vs_base + buf * VS_BYTES;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int s = tid + PF_THREADS * i;
+      const int row = s >> 4, ch = s & 15;
+      *reinterpret_cast<u32x4*>(ks + row * 256 + ((ch ^ (row & 15)) << 4)) = kreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VLD; ++i) {
+      const int s = tid + PF_THREADS * i;
+      const int row = s >> 3, ch = s & 7;
+      *reinterpret_cast<u32x4*>(vs + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = vreg[i];
+    }
+  };
+
+  f32x16 acc_o[NCB];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc_o[cb][e] = 0.f;
+  float m_run = -INFINITY;   // running max of the raw scores (scale > 0 is applied inside the exponent)
+  float l_run = 0.f;         // this lane's half of the running sum (the halves share m_run)
+
+  // K~ A-fragment row of this lane: bits 2 and 3 of the MFMA row swapped (see header)
+  const int krow = (n & 0x13) | ((n & 4) << 1) | ((n & 8) >> 1);
+
+  if (njt > 0) {
+    load_k(0);
+    load_v(0);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  for (int jt = 0; jt < njt; ++jt) {
+    const int buf = jt & 1;
+    const char* ks = ks_base + buf * KS_BYTES;
+    const char* vs = vs_base + buf * VS_BYTES;
+
+    // ---- S^T = K~ . Q~^T : two 32-kv row blocks
+    f32x16 sacc[2];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sacc[rb][e] = 0.f;
+      const int row = rb * 32 + krow;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const h16x8 kf = *reinterpret_cast<const h16x8*>(ks + row * 256 + (((2 * kk + hi) ^ (row & 15)) << 4));
+        sacc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], sacc[rb], 0, 0, 0);
+      }
+    }
+    // register r of block rb in lane (t, hi) is kv = jt*64 + 32rb + 16(r>>3) + 8hi + (r&7)
+    const int j0 = jt * PF_BN + 8 * hi;
+    const bool need_mask = (jt * PF_BN + PF_BN > p.Tk) || (p.causal && jt * PF_BN + PF_BN - 1 > p.past + qt * PF_BM + w * 32);
+    if (need_mask) {
+      const int lim = p.causal ? min(p.Tk - 1, qpos) : p.Tk - 1;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = j0 + 32 * rb + 16 * (r >> 3) + (r & 7);
+          if (j > lim) sacc[rb][r] = -INFINITY;
+        }
+    }
+    float mloc = sacc[0][0];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sacc[rb][r]);
+    {
+      const unsigned mb = __float_as_uint(mloc);
+      auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);   // both halves of query t see both maxima
+      mloc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    const float m_new = fmaxf(m_run, mloc);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;                // fully masked so far (padding rows)
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * p.scale_log2);             // m_run = -inf -> 0
+    const float moff = -m_use * p.scale_log2;
+    float lsum = 0.f;
+    h16x8 pf[4];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        h16x8 pk;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[rb][8 * s2 + e], p.scale_log2, moff));
+          lsum += pv;
+          pk[e] = (h16)pv;
+        }
+        pf[2 * rb + s2] = pk;
+      }
+    l_run = fmaf(l_run, alpha, lsum);
+    m_run = m_new;
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {                 // wave-uniform: rescale only when a max moved
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc_o[cb][e] *= alpha;
+    }
+
+    // next tile: issued once the score registers are dead (keeps the kernel at 2 workgroups per CU), landed in LDS
+    // after the P.V MFMAs
+    asm volatile("" ::: "memory");
+    if (jt + 1 < njt) {
+      load_k(jt + 1);
+      load_v(jt + 1);
+    }
+
+    // ---- O^T += V^T . P^T
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const int row = cb * 32 + n;
+        const h16x8 vf = *reinterpret_cast<const h16x8*>(vs + row * 128 + (((2 * s + hi) ^ ((row >> 1) & 7)) << 4));
+        acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], acc_o[cb], 0, 0, 0);
+      }
+
+    if (jt + 1 < njt) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: 1/l (both halves), fp16 store; lane (t, hi) register r of block cb is column 32cb + (r&3) + 8(r>>2) + 4hi
+  {
+    const unsigned lb = __float_as_uint(l_run);
+    auto sw = __builtin_amdgcn_permlane32_swap(lb, lb, false, false);
+    const float l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (qvalid) {
+      h16* op = p.out + (int64_t)qrow * p.so_t + (int64_t)h * p.Rv + c0 + 4 * hi;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r2 = 0; r2 < 4; ++r2) {
+          h16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (h16)(acc_o[cb][4 * r2 + e] * inv);
+          *reinterpret_cast<h16x4*>(op + 32 * cb + 8 * r2) = o;
+        }
+    }
+  }
+}
+
+template <int NCB>
+int launch_prefill(const PfParams& p, hipStream_t stream) {
+  constexpr int smem = 2 * (PF_BN * 256 + 32 * NCB * 128);
+  static bool attr_done = false;
+  auto kern = prefill_attn_kernel<NCB>;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) {
+      palu_set_error("hipFuncSetAttribute(%d B LDS) failed: %s", smem, hipGetErrorString(e));
+      return PALU_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  dim3 grid(p.nqt, p.H, p.Rv / (32 * NCB));
+  hipLaunchKernelGGL(kern, grid, dim3(PF_THREADS), smem, stream, p);
+  PALU_LAUNCH_CHECK();
+  return PALU_OK;
+}
+
+}  // namespace
+
+extern "C" int palu_prefill_attn_f16(const void* q, int64_t sq_h, int64_t sq_t, const void* k, int64_t sk_h, int64_t sk_t,
+                                     const void* vt, int64_t sv_g, int64_t sv_c, void* out, int64_t so_t, int H, int G,
+                                     int D, int Tq, int Tk, int Rv, int past, int causal, float scale,
+                                     palu_stream_t stream) {
+  PALU_REQUIRE(q && k && vt && out, PALU_ERR_ARG, "prefill_attn: null pointer");
+  PALU_REQUIRE(H > 0 && G > 0 && H % G == 0, PALU_ERR_ARG, "prefill_attn: bad heads/groups H=%d G=%d", H, G);
+  PALU_REQUIRE(D == 128, PALU_ERR_UNSUPPORTED, "prefill_attn: head_dim must be 128 (got %d)", D);
+  PALU_REQUIRE(Tq >= 0 && Tk >= 0 && past >= 0, PALU_ERR_ARG, "prefill_attn: negative length");
+  if (Tq == 0) return PALU_OK;
+  PALU_REQUIRE(Tk > 0, PALU_ERR_ARG, "prefill_attn: no keys");
+  PALU_REQUIRE(Rv > 0 && Rv % 32 == 0, PALU_ERR_UNSUPPORTED, "prefill_attn: latent value rank per group must be a multiple of 32 (got %d)", Rv);
+  PALU_REQUIRE(scale > 0.f, PALU_ERR_ARG, "prefill_attn: scale must be positive");
+  PALU_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) & 15) == 0 && sq_h % 8 == 0 && sq_t % 8 == 0 &&
+                   sk_h % 8 == 0 && sk_t % 8 == 0 && sv_g % 8 == 0 && sv_c % 8 == 0 && ((uintptr_t)out & 7) == 0 &&
+                   so_t % 4 == 0,
+               PALU_ERR_ARG, "prefill_attn: rows must be 16-byte aligned (out 8-byte)");
+  const int tk_pad = (Tk + PF_BN - 1) / PF_BN * PF_BN;
+  PALU_REQUIRE(sv_c >= tk_pad, PALU_ERR_ARG,
+               "prefill_attn: vt rows must be zero-padded to a multiple of %d kv positions (sv_c=%lld < %d)", PF_BN,
+               (long long)sv_c, tk_pad);
+  PfParams p;
+  p.q = (const h16*)q; p.k = (const h16*)k; p.vt = (const h16*)vt; p.out = (h16*)out;
+  p.sq_h = sq_h; p.sq_t = sq_t; p.sk_h = sk_h; p.sk_t = sk_t; p.sv_g = sv_g; p.sv_c = sv_c; p.so_t = so_t;
+  p.H = H; p.G = G; p.gs = H / G; p.Tq = Tq; p.Tk = Tk; p.Rv = Rv; p.past = past; p.causal = causal ? 1 : 0;
+  p.scale_log2 = scale * 1.4426950408889634f;
+  p.nqt = (Tq + PF_BM - 1) / PF_BM;
+  hipStream_t s = (hipStream_t)stream;
+  if (Rv % 192 == 0) return launch_prefill<6>(p, s);
+  if (Rv % 96 == 0) return launch_prefill<3>(p, s);
+  if (Rv % 64 == 0) return launch_prefill<2>(p, s);
+  return launch_prefill<1>(p, s);
+}

@@ -442,6 +442,45 @@ class LlamaPaluAttention(nn.Module):
         cache.advance(li, q_len)
         return kbuf[:, :, :n + q_len], vbuf[:, :, :n + q_len]
 
+    def _mask_is_causal(self, attention_mask, q_len, past):
+        """True iff the additive mask is the standard causal one (0 on/below the diagonal shifted by `past`,
+        <= -1e4 above it) -- the only mask the flash prefill kernel understands."""
+        m = attention_mask.reshape(q_len, past + q_len)
+        j = torch.arange(past + q_len, device=m.device).unsqueeze(0)
+        i = torch.arange(q_len, device=m.device).unsqueeze(1) + past
+        above = j > i
+        return bool(((m <= -1e4) == above).all()) and bool((m.masked_fill(above, 0) == 0).all())
+
+    def _prefill_flash(self, hidden_states, pos, cache: "LatentCache", causal: bool):
+        """Prompt branch (:196-257) on the flash-style HIP kernel: scores are never materialised.
+
+        q and the latents are projected (latents straight into the cache rows), keys are rebuilt once as
+        K~ = RoPE(X_k . B) [H, kv, D] (a transient workspace: O(kv), not O(kv^2)), the latent values are handed to
+        the kernel transposed ([G, Rv, kv], zero-padded to 64) and P.V stays in the latent space."""
+        H, G, D, gs = self.num_heads, self.num_groups, self.head_dim, self.group_size
+        q_len = hidden_states.shape[1]
+        past = cache.get_seq_length(self.layer_idx)
+        dev, dt = hidden_states.device, hidden_states.dtype
+        q = self.q_proj(hidden_states).view(q_len, H, D).transpose(0, 1)                  # [H,T,D]
+        key_h, val_h = self._project_into_cache(hidden_states, cache)                     # [1,G,kv,R] views
+        kv = past + q_len
+        cos, sin = self._rope_tables(pos.reshape(-1), dt)
+        q = (q * cos.view(1, q_len, D) + _rotate_half(q) * sin.view(1, q_len, D)).contiguous()
+        kc, ks = self._rope_tables(torch.arange(kv, device=dev), dt)
+        b = self.k_proj.B.view(G, gs, self.group_rank_k, D)
+        keys = torch.matmul(key_h[0].unsqueeze(1), b).view(H, kv, D)                       # K = X_k . B  (:199-201)
+        keys = (keys * kc.view(1, kv, D) + _rotate_half(keys) * ks.view(1, kv, D)).contiguous()
+        kv_pad = (kv + 63) // 64 * 64
+        vt = torch.zeros((G, self.group_rank_v, kv_pad), dtype=dt, device=dev)
+        vt[:, :, :kv].copy_(val_h[0].transpose(1, 2))
+        ctx = torch.empty((q_len, H * self.group_rank_v), dtype=dt, device=dev)
+        _lib.check(_lib.lib.palu_prefill_attn_f16(q.data_ptr(), q.stride(0), q.stride(1), keys.data_ptr(), keys.stride(0),
+                                                  keys.stride(1), vt.data_ptr(), vt.stride(0), vt.stride(1),
+                                                  ctx.data_ptr(), ctx.stride(0), H, G, D, q_len, kv, self.group_rank_v,
+                                                  past, 1 if causal else 0, 1.0 / math.sqrt(D), _lib.current_stream()),
+                   "palu_prefill_attn_f16")
+        return self.o_proj(ctx).view(1, q_len, -1)
+
     @torch.no_grad()
     def fuse_hadamard(self):
         """Rotate the latent spaces by Hadamard matrices offline (the `--lt_hadamard` option:
@@ -492,7 +531,26 @@ class LlamaPaluAttention(nn.Module):
             out, probs = step(hidden_states, attention_mask, pos, past_key_value, output_attentions)
             return out, probs, past_key_value
 
-        # ---- general path (prefill, no_fusion, foreign cache objects): torch composition -------
+        # ---- prompt pass on the flash-style HIP kernel (no [q, kv] score matrix) -----------------
+        if (q_len > 1 and bsz == 1 and isinstance(past_key_value, LatentCache) and fused_o and not output_attentions
+                and hidden_states.is_cuda and hidden_states.dtype == torch.float16 and self.head_dim == 128
+                and self.group_rank_v % 32 == 0 and self.k_proj.VT.bias is None and hasattr(self.k_proj, "B")
+                and self.o_proj.in_features == self.fused_hidden_dim_o):
+            is_causal = kwargs.get("is_causal", None)
+            if attention_mask is None:
+                causal = bool(is_causal)            # the reference applies no mask at all when none is passed (:229)
+                ok = True
+            else:
+                ok = bool(is_causal) if is_causal is not None else self._mask_is_causal(attention_mask, q_len, past)
+                causal = True
+            if ok:
+                if position_ids is None:
+                    position_ids = torch.arange(past, kv_seq_len, device=hidden_states.device).unsqueeze(0)
+                pos = position_ids.to(hidden_states.device).reshape(-1, q_len)
+                out = self._prefill_flash(hidden_states, pos, past_key_value, causal)
+                return out, None, past_key_value
+
+        # ---- general path (no_fusion, foreign cache objects, arbitrary masks, output_attentions): torch composition
         query_states = self.q_proj(hidden_states).view(bsz, q_len, H, D).transpose(1, 2)
         if (isinstance(past_key_value, LatentCache) and bsz == 1 and hidden_states.is_cuda
                 and hidden_states.dtype == torch.float16 and self.k_proj.VT.bias is None):

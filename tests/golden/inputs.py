@@ -92,6 +92,30 @@ def step_inputs(seed, hidden, H, D, gs, rank_k, rank_v, L, with_mask):
     return w, k_lat, v_lat, tok, mask
 
 
+# ---------------------------------------------------------------- prefill cases
+# (tag, seed, hidden, H, D, gs, rank_k, rank_v, T, causal_mask)
+PREFILL_CASES = [
+    ("pf_small_gs2_t48_causal", 20, 512, 4, 128, 2, 64, 128, 48, True),
+    ("pf_small_gs2_t70_nomask", 21, 512, 4, 128, 2, 64, 128, 70, False),
+    ("pf_c1_h32_t130_causal", 22, 4096, 32, 128, 4, 256, 768, 130, True),     # BASELINE configs[0] ranks, ragged T
+]
+
+
+def causal_mask(T, dtype=torch.float16):
+    """The additive 4-D mask HF 4.37.2 hands to the attention module: finfo.min above the diagonal."""
+    m = torch.zeros(T, T, dtype=dtype)
+    m.masked_fill_(torch.triu(torch.ones(T, T, dtype=torch.bool), diagonal=1), torch.finfo(dtype).min)
+    return m
+
+
+def prefill_inputs(seed, hidden, H, D, gs, rank_k, rank_v, T, causal):
+    """Weights as in step_inputs (the caches/token drawn there are discarded) + a randn prompt [T, hidden]."""
+    w, _, _, _, _ = step_inputs(seed, hidden, H, D, gs, rank_k, rank_v, 1, False)
+    rng = np.random.default_rng(5000 + seed)
+    prompt = _f16(rng, (T, hidden))
+    return w, prompt, (causal_mask(T) if causal else None)
+
+
 # ---------------------------------------------------------------- quantiser cases
 QUANT_R = [32, 64, 128, 384]
 QUANT_ROWS = 24

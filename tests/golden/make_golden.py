@@ -204,6 +204,32 @@ def gen_steps(ml, pa):
     _save("g3_decode_step", **out)
 
 
+def gen_prefill(ml, pa):
+    print("G7 prefill (kernel/palu_attention.py:147-263, prompt branch :196-206)")
+    out = {}
+    for tag, seed, hidden, H, D, gs, rank_k, rank_v, T, causal in gi.PREFILL_CASES:
+        w, prompt, mask = gi.prefill_inputs(seed, hidden, H, D, gs, rank_k, rank_v, T, causal)
+        m, cfg = _ref_module_from_palu_weights(ml, pa, hidden, H, D, gs, rank_k, rank_v, w)
+        cache = _Cache437()
+        am = None if mask is None else mask.reshape(1, 1, T, T)
+        with torch.no_grad():
+            o, p, _ = m(prompt.reshape(1, T, hidden), attention_mask=am, position_ids=torch.arange(T).unsqueeze(0),
+                        past_key_value=cache, output_attentions=True)
+        wd = {"wq": w["wq"].half(), "vt_k": w["vt_k"].half(), "vt_v": w["vt_v"].half(),
+              "u_k": [u.half() for u in w["u_k"]], "wo": w["wo"].half()}
+        o2, p2, k2, v2 = oracle.prefill(prompt, wd, mask)
+        print(f"  {tag}: |out-oracle| {(o[0].float() - o2.float()).abs().max():.3e} "
+              f"|P-oracle| {(p[0].float() - p2.float()).abs().max():.3e} rms(out) {o.float().pow(2).mean().sqrt():.3e}")
+        assert torch.equal(cache.k[0], k2) and torch.equal(cache.v[0], v2)
+        out[tag + "/attn_output"] = _np(o[0])
+        out[tag + "/attn_weights"] = _np(p[0])
+        out[tag + "/k_lat"] = _np(cache.k[0])
+        out[tag + "/v_lat"] = _np(cache.v[0])
+        flat = [w["wq"], w["vt_k"], w["vt_v"], w["wo"], *w["u_k"], prompt]
+        out[tag + "/digest"] = np.array(gi.digest(*flat))
+    _save("g7_prefill", **out)
+
+
 def gen_reftest(ml, pa):
     """The scenario of kernel/test_palu_attention.py:158-195 (full rank 4096/4096, prefill 63
     tokens into the cache, decode 1) run through from_attention (per-group SVD)."""
@@ -346,6 +372,8 @@ def main():
         gen_quant(rq)
     if not only or "hadamard" in only:
         gen_hadamard(rh, rs)
+    if not only or "prefill" in only:
+        gen_prefill(ml, pa)
     if not only or "reftest" in only:
         gen_reftest(ml, pa)
 

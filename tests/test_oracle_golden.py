@@ -71,6 +71,22 @@ def test_decode_step_matches_reference(golden_dir, case):
     assert abs(probs.float().sum(-1) - 1).max() < 2e-2          # fp16 rows still sum to ~1
 
 
+@pytest.mark.parametrize("case", gi.PREFILL_CASES, ids=[c[0] for c in gi.PREFILL_CASES])
+def test_prefill_matches_reference(golden_dir, case):
+    tag, seed, hidden, H, D, gs, rank_k, rank_v, T, causal = case
+    g = _load(golden_dir, "g7_prefill")
+    w, prompt, mask = gi.prefill_inputs(seed, hidden, H, D, gs, rank_k, rank_v, T, causal)
+    flat = [w["wq"], w["vt_k"], w["vt_v"], w["wo"], *w["u_k"], prompt]
+    assert gi.digest(*flat) == str(g[tag + "/digest"])
+    wd = {"wq": w["wq"].half(), "vt_k": w["vt_k"].half(), "vt_v": w["vt_v"].half(),
+          "u_k": [u.half() for u in w["u_k"]], "wo": w["wo"].half()}
+    out, probs, k_lat, v_lat = oracle.prefill(prompt, wd, mask)
+    torch.testing.assert_close(out, torch.from_numpy(g[tag + "/attn_output"]), rtol=1e-3, atol=1e-4)
+    torch.testing.assert_close(probs, torch.from_numpy(g[tag + "/attn_weights"]), rtol=1e-3, atol=1e-5)
+    np.testing.assert_array_equal(k_lat.numpy(), g[tag + "/k_lat"])
+    np.testing.assert_array_equal(v_lat.numpy(), g[tag + "/v_lat"])
+
+
 def test_quantizer_bit_exact(golden_dir):
     g = _load(golden_dir, "g5_quant")
     n = 0

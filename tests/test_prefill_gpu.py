@@ -1,0 +1,178 @@
+"""GPU parity of the flash-style prefill attention kernel (palu_prefill_attn_f16) and of the prompt pass through
+LlamaPaluAttention.forward against the golden vectors generated from the reference (tests/golden/g7_prefill.npz),
+the CPU oracle, and -- for the kernel alone at sizes the oracle cannot hold -- a plain fp32 torch restatement of
+softmax(q.k^T * scale [+causal]) . V.  Criterion P1 of SURVEY.md 8(c): assert_close(rtol=1e-3, atol=1e-3)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle
+from tests.golden import inputs as gi
+from tests.test_decode_gpu import _module_from_palu_weights
+
+DEV = "cuda"
+
+
+def _lib():
+    from palu_amd import _lib
+    return _lib
+
+
+def prefill_attn(q, k, v_lat, past, causal, scale=None):
+    """q [H,Tq,D], k [H,Tk,D], v_lat [G,Tk,Rv] fp16 cuda -> ctx [Tq, H*Rv] through the C ABI."""
+    lib = _lib()
+    H, Tq, D = q.shape
+    Tk = k.shape[1]
+    G, _, Rv = v_lat.shape
+    pad = (Tk + 63) // 64 * 64
+    vt = torch.zeros(G, Rv, pad, dtype=torch.float16, device=DEV)
+    vt[:, :, :Tk].copy_(v_lat.transpose(1, 2))
+    out = torch.empty(Tq, H * Rv, dtype=torch.float16, device=DEV)
+    lib.check(lib.lib.palu_prefill_attn_f16(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1),
+                                            vt.data_ptr(), vt.stride(0), vt.stride(1), out.data_ptr(), out.stride(0),
+                                            H, G, D, Tq, Tk, Rv, past, 1 if causal else 0,
+                                            1.0 / math.sqrt(D) if scale is None else scale,
+                                            torch.cuda.current_stream().cuda_stream), "prefill_attn")
+    return out
+
+
+def ref_attn_f32(q, k, v_lat, past, causal, scale):
+    H, Tq, D = q.shape
+    Tk = k.shape[1]
+    G, _, Rv = v_lat.shape
+    s = torch.matmul(q.float(), k.float().transpose(1, 2)) * scale
+    if causal:
+        i = torch.arange(Tq, device=q.device).unsqueeze(1) + past
+        j = torch.arange(Tk, device=q.device).unsqueeze(0)
+        s = s.masked_fill((j > i).unsqueeze(0), float("-inf"))
+    p = torch.softmax(s, dim=-1)
+    ctx = torch.matmul(p.reshape(G, (H // G) * Tq, Tk), v_lat.float()).reshape(H, Tq, Rv)
+    return ctx.transpose(0, 1).reshape(Tq, H * Rv)
+
+
+@pytest.mark.parametrize("H,gs,Tq,Tk,Rv,causal", [
+    (4, 2, 48, 48, 64, True), (4, 2, 70, 70, 64, False), (8, 4, 130, 130, 96, True), (8, 4, 257, 257, 192, True),
+    (32, 4, 300, 300, 384, True), (4, 1, 1, 200, 32, False), (8, 4, 129, 1000, 384, True), (8, 2, 640, 640, 128, True),
+    (4, 4, 128, 192, 384, False)])
+def test_prefill_kernel_vs_fp32(H, gs, Tq, Tk, Rv, causal):
+    rng = np.random.default_rng(H * 1000 + Tq + Tk + Rv)
+    G = H // gs
+    past = Tk - Tq
+    q = torch.from_numpy(rng.standard_normal((H, Tq, 128)).astype(np.float16)).to(DEV)
+    k = torch.from_numpy(rng.standard_normal((H, Tk, 128)).astype(np.float16)).to(DEV)
+    v = torch.from_numpy(rng.standard_normal((G, Tk, Rv)).astype(np.float16)).to(DEV)
+    scale = 1.0 / math.sqrt(128.0)
+    out = prefill_attn(q, k, v, past, causal)
+    ref = ref_attn_f32(q, k, v, past, causal, scale)
+    # tolerance of the north star: 1e-3 relative to the output scale (P is rounded to fp16 inside the kernel like :238)
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 2e-3 * max(1.0, ref.abs().max().item()), err
+    assert torch.isfinite(out.float()).all()
+
+
+def test_prefill_kernel_strided_and_peaked():
+    """Non-contiguous q/k (head-interleaved [T, H, D] storage) and a peaked distribution (large logits)."""
+    rng = np.random.default_rng(7)
+    H, gs, T, Rv = 8, 4, 200, 96
+    qs = torch.from_numpy((rng.standard_normal((T, H, 128)) * 4).astype(np.float16)).to(DEV)
+    ks = torch.from_numpy((rng.standard_normal((T, H, 128)) * 4).astype(np.float16)).to(DEV)
+    v = torch.from_numpy(rng.standard_normal((H // gs, T, Rv)).astype(np.float16)).to(DEV)
+    q, k = qs.transpose(0, 1), ks.transpose(0, 1)
+    out = prefill_attn(q, k, v, 0, True)
+    ref = ref_attn_f32(q, k, v, 0, True, 1.0 / math.sqrt(128.0))
+    assert (out.float() - ref).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_prefill_kernel_rejects_bad_args():
+    lib = _lib()
+    q = torch.zeros(4, 8, 128, dtype=torch.float16, device=DEV)
+    v = torch.zeros(2, 64, 64, dtype=torch.float16, device=DEV)
+    out = torch.zeros(8, 4 * 64, dtype=torch.float16, device=DEV)
+    rc = lib.lib.palu_prefill_attn_f16(q.data_ptr(), q.stride(0), q.stride(1), q.data_ptr(), q.stride(0), q.stride(1),
+                                       v.data_ptr(), v.stride(0), 8, out.data_ptr(), out.stride(0), 4, 2, 128, 8, 8, 64,
+                                       0, 1, 0.1, 0)
+    assert rc != 0 and b"zero-padded" in lib.lib.palu_last_error()
+    rc = lib.lib.palu_prefill_attn_f16(q.data_ptr(), q.stride(0), q.stride(1), q.data_ptr(), q.stride(0), q.stride(1),
+                                       v.data_ptr(), v.stride(0), 64, out.data_ptr(), out.stride(0), 4, 2, 64, 8, 8, 64,
+                                       0, 1, 0.1, 0)
+    assert rc != 0 and b"head_dim" in lib.lib.palu_last_error()
+
+
+@pytest.mark.parametrize("case", gi.PREFILL_CASES, ids=[c[0] for c in gi.PREFILL_CASES])
+def test_prefill_module_golden(golden_dir, case):
+    """Prompt pass through LlamaPaluAttention.forward (flash kernel) vs the reference's own outputs."""
+    from palu_amd.kernel.palu_attention import LatentCache
+    tag, seed, hidden, H, D, gs, rank_k, rank_v, T, causal = case
+    g = np.load(os.path.join(golden_dir, "g7_prefill.npz"))
+    w, prompt, mask = gi.prefill_inputs(seed, hidden, H, D, gs, rank_k, rank_v, T, causal)
+    flat = [w["wq"], w["vt_k"], w["vt_v"], w["wo"], *w["u_k"], prompt]
+    assert gi.digest(*flat) == str(g[tag + "/digest"])
+    m = _module_from_palu_weights(hidden, H, D, gs, rank_k, rank_v, w)
+    cache = LatentCache()
+    am = None if mask is None else mask.reshape(1, 1, T, T).to(DEV)
+    with torch.no_grad():
+        out, probs, _ = m(prompt.reshape(1, T, hidden).to(DEV), attention_mask=am,
+                          position_ids=torch.arange(T).unsqueeze(0), past_key_value=cache)
+    assert probs is None and cache.get_seq_length(0) == T
+    torch.testing.assert_close(out[0].cpu(), torch.from_numpy(g[tag + "/attn_output"]), rtol=1e-3, atol=1e-3)
+    kbuf, vbuf = cache.buffers(0)
+    torch.testing.assert_close(kbuf[0, :, :T].cpu(), torch.from_numpy(g[tag + "/k_lat"]), rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(vbuf[0, :, :T].cpu(), torch.from_numpy(g[tag + "/v_lat"]), rtol=1e-3, atol=1e-3)
+    # the general (torch-composition) path of the same module agrees as well, incl. the attention weights
+    cache2 = LatentCache()
+    with torch.no_grad():
+        out2, probs2, _ = m(prompt.reshape(1, T, hidden).to(DEV), attention_mask=am,
+                            position_ids=torch.arange(T).unsqueeze(0), past_key_value=cache2, output_attentions=True)
+    torch.testing.assert_close(out2[0].cpu(), torch.from_numpy(g[tag + "/attn_output"]), rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(probs2[0].cpu(), torch.from_numpy(g[tag + "/attn_weights"]), rtol=1e-3, atol=1e-3)
+
+
+def test_prefill_chunked_equals_whole_and_feeds_decode():
+    """Causal prompt in two chunks (second chunk sees `past` rows) == one pass; the cache it leaves behind drives the
+    fused decode step to the same answer as the oracle's decode on the oracle's prefill latents."""
+    from palu_amd.kernel.palu_attention import LatentCache
+    tag, seed, hidden, H, D, gs, rank_k, rank_v, T, _ = gi.PREFILL_CASES[0]
+    w, prompt, mask = gi.prefill_inputs(seed, hidden, H, D, gs, rank_k, rank_v, T, True)
+    m = _module_from_palu_weights(hidden, H, D, gs, rank_k, rank_v, w)
+    x = prompt.reshape(1, T, hidden).to(DEV)
+    c1, c2 = LatentCache(), LatentCache()
+    with torch.no_grad():
+        whole, _, _ = m(x, past_key_value=c1, is_causal=True)
+        t1 = 20
+        a, _, _ = m(x[:, :t1], past_key_value=c2, is_causal=True)
+        b, _, _ = m(x[:, t1:], past_key_value=c2, is_causal=True, position_ids=torch.arange(t1, T).unsqueeze(0))
+    torch.testing.assert_close(torch.cat((a, b), dim=1), whole, rtol=1e-3, atol=1e-3)
+    # reference semantics of the whole pass
+    wd = {"wq": w["wq"].half(), "vt_k": w["vt_k"].half(), "vt_v": w["vt_v"].half(),
+          "u_k": [u.half() for u in w["u_k"]], "wo": w["wo"].half()}
+    o_ref, _, k_ref, v_ref = oracle.prefill(prompt, wd, mask)
+    torch.testing.assert_close(whole[0].cpu(), o_ref, rtol=1e-3, atol=1e-3)
+    # decode one token on top of the chunked cache
+    rng = np.random.default_rng(77)
+    tok = torch.from_numpy(rng.standard_normal(hidden).astype(np.float16))
+    with torch.no_grad():
+        d, _, _ = m(tok.reshape(1, 1, hidden).to(DEV), past_key_value=c2, position_ids=torch.tensor([[T]]))
+    wd2 = dict(wd, b=oracle.build_b_from_u(w["u_k"], gs, D).half())
+    d_ref, _, _, _ = oracle.decode_step(tok, T, wd2, k_ref, v_ref)
+    torch.testing.assert_close(d.reshape(-1).cpu(), d_ref, rtol=1e-3, atol=1e-3)
+
+
+def test_prefill_long_prompt_properties():
+    """8k-token causal prompt at the C2 ranks (no oracle at this size): finite, and causal prefix invariance --
+    the first 1000 output rows do not depend on the tokens that follow."""
+    from palu_amd.kernel.palu_attention import LatentCache
+    hidden, H, D, gs, rank_k, rank_v = 4096, 32, 128, 4, 1024, 3072
+    w, _, _, _, _ = gi.step_inputs(5, hidden, H, D, gs, rank_k, rank_v, 1, False)
+    m = _module_from_palu_weights(hidden, H, D, gs, rank_k, rank_v, w)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 8192, hidden, generator=g).half().to(DEV)
+    with torch.no_grad():
+        full, _, _ = m(x, past_key_value=LatentCache(), is_causal=True)
+        head, _, _ = m(x[:, :1000], past_key_value=LatentCache(), is_causal=True)
+    assert torch.isfinite(full.float()).all()
+    torch.testing.assert_close(full[:, :1000], head, rtol=1e-3, atol=1e-3)
