@@ -15,6 +15,8 @@
 //
 // One 256-thread workgroup = 128 queries (32 per wave) x one head x one chunk of 32*NCB latent columns; K~/V^T
 // tiles of 64 kv go through a double-buffered LDS image (XOR-swizzled 16-byte chunks, register-staged).
+#include <cstdlib>
+
 #include "palu_common.h"
 
 namespace {
@@ -244,6 +246,246 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(PfParams p)
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Pair variant for wide latent values (Rv = 64*NCBH, e.g. 384): 8 waves; waves w and w+4 share 32 queries.
+// Each computes S^T for ONE 32-kv half of the tile and owns ONE half of the latent columns; the two exchange
+// the half-tile maxima and their fp16 P fragments through LDS, so q.k^T is computed once (the 4-wave kernel
+// above would run twice over the keys, once per 192-column chunk) and the softmax VALU work per wave halves.
+constexpr int PFP_THREADS = 512;
+
+template <int NCBH>
+__global__ __launch_bounds__(PFP_THREADS, 1) void prefill_attn_pair_kernel(PfParams p) {
+  constexpr int RV = 64 * NCBH;
+  constexpr int KS_BYTES = PF_BN * 256;
+  constexpr int VS_BYTES = RV * 128;
+  constexpr int KLD = 2;                              // 16-byte chunks per thread: K~ tile
+  constexpr int VLD = RV * 8 / PFP_THREADS;           // V^T tile
+  static_assert(RV * 8 % PFP_THREADS == 0, "V^T tile must split evenly over the workgroup");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ks_base = smem;
+  char* vs_base = smem + 2 * KS_BYTES;
+  float* mx = reinterpret_cast<float*>(vs_base + 2 * VS_BYTES);          // [4 qblk][2 half][32]
+  char* px = reinterpret_cast<char*>(mx) + 4 * 2 * 32 * sizeof(float);   // [4 qblk][2 half][2 ksteps][64 lanes][16 B]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qblk = w & 3, half = w >> 2;
+  const int n = lane & 31, hi = lane >> 5;
+  const int qt = p.nqt - 1 - (int)blockIdx.x;
+  const int h = blockIdx.y;
+  const int g = h / p.gs;
+  const int c0 = half * 32 * NCBH;
+
+  const int qrow = qt * PF_BM + qblk * 32 + n;
+  const bool qvalid = qrow < p.Tq;
+  const int qpos = p.past + qrow;
+
+  h16x8 qf[8];
+  {
+    const h16* qp = p.q + (int64_t)h * p.sq_h + (int64_t)(qvalid ? qrow : 0) * p.sq_t + 8 * hi;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(qp + 16 * ks);
+      if (!qvalid) v = u32x4{0, 0, 0, 0};
+      qf[ks] = __builtin_bit_cast(h16x8, v);
+    }
+  }
+
+  int kv_end = p.Tk;
+  if (p.causal) {
+    const int last_q = min(p.Tq, (qt + 1) * PF_BM) - 1;
+    kv_end = min(p.Tk, p.past + last_q + 1);
+  }
+  const int njt = (kv_end + PF_BN - 1) / PF_BN;
+
+  const h16* kg = p.k + (int64_t)h * p.sk_h;
+  const h16* vg = p.vt + (int64_t)g * p.sv_g;
+  u32x4 kreg[KLD], vreg[VLD];
+  auto load_k = [&](int jt) {
+#pragma unroll
+    for (int i = 0; i < KLD; ++i) {
+      const int s = tid + PFP_THREADS * i;
+      const int row = s >> 4, ch = s & 15;
+      const int j = min(jt * PF_BN + row, p.Tk - 1);
+      kreg[i] = *reinterpret_cast<const u32x4*>(kg + (int64_t)j * p.sk_t + ch * 8);
+    }
+  };
+  auto load_v = [&](int jt) {
+#pragma unroll
+    for (int i = 0; i < VLD; ++i) {
+      const int s = tid + PFP_THREADS * i;
+      const int row = s >> 3, ch = s & 7;
+      vreg[i] = *reinterpret_cast<const u32x4*>(vg + (int64_t)row * p.sv_c + jt * PF_BN + ch * 8);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* ks = ks_base + buf * KS_BYTES;
+    char* vs = vs_base + buf * VS_BYTES;
+#pragma unroll
+    for (int i = 0; i < KLD; ++i) {
+      const int s = tid + PFP_THREADS * i;
+      const int row = s >> 4, ch = s & 15;
+      *reinterpret_cast<u32x4*>(ks + row * 256 + ((ch ^ (row & 15)) << 4)) = kreg[i];
+    }
+#pragma unroll
+    for (int i = 0; i < VLD; ++i) {
+      const int s = tid + PFP_THREADS * i;
+      const int row = s >> 3, ch = s & 7;
+      *reinterpret_cast<u32x4*>(vs + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = vreg[i];
+    }
+  };
+
+  f32x16 acc_o[NCBH];
+#pragma unroll
+  for (int cb = 0; cb < NCBH; ++cb)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc_o[cb][e] = 0.f;
+  float m_run = -INFINITY;
+  float l_run = 0.f;   // this lane's share: its hi-half of this wave's kv half
+
+  const int krow = half * 32 + ((n & 0x13) | ((n & 4) << 1) | ((n & 8) >> 1));
+  float* mx_own = mx + (qblk * 2 + half) * 32 + n;
+  const float* mx_par = mx + (qblk * 2 + (half ^ 1)) * 32 + n;
+  char* px_own = px + ((qblk * 2 + half) * 2) * 1024 + lane * 16;
+  const char* px_par = px + ((qblk * 2 + (half ^ 1)) * 2) * 1024 + lane * 16;
+
+  if (njt > 0) {
+    load_k(0);
+    load_v(0);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  for (int jt = 0; jt < njt; ++jt) {
+    const int buf = jt & 1;
+    const char* ks = ks_base + buf * KS_BYTES;
+    const char* vs = vs_base + buf * VS_BYTES;
+
+    // ---- this wave's half of S^T: 32 kv rows x 32 queries
+    f32x16 sacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const h16x8 kf = *reinterpret_cast<const h16x8*>(ks + krow * 256 + (((2 * kk + hi) ^ (krow & 15)) << 4));
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], sacc, 0, 0, 0);
+    }
+    // register r in lane (t, hi) is kv = jt*64 + 32*half + 16(r>>3) + 8hi + (r&7)
+    const int j0 = jt * PF_BN + 32 * half + 8 * hi;
+    const bool need_mask = (jt * PF_BN + PF_BN > p.Tk) || (p.causal && jt * PF_BN + PF_BN - 1 > p.past + qt * PF_BM + qblk * 32);
+    if (need_mask) {
+      const int lim = p.causal ? min(p.Tk - 1, qpos) : p.Tk - 1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int j = j0 + 16 * (r >> 3) + (r & 7);
+        if (j > lim) sacc[r] = -INFINITY;
+      }
+    }
+    float mloc = sacc[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, sacc[r]);
+    {
+      const unsigned mb = __float_as_uint(mloc);
+      auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+      mloc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    *mx_own = mloc;                                   // lanes t and t+32 write the same word
+    asm volatile("" ::: "memory");
+    if (jt + 1 < njt) {                               // next tile's global loads fly during the exchange and P.V
+      load_k(jt + 1);
+      load_v(jt + 1);
+    }
+    __syncthreads();                                  // A: half-tile maxima visible
+    const float m_new = fmaxf(m_run, fmaxf(mloc, *mx_par));
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * p.scale_log2);
+    const float moff = -m_use * p.scale_log2;
+    float lsum = 0.f;
+    h16x8 pf[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      h16x8 pk;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[8 * s2 + e], p.scale_log2, moff));
+        lsum += pv;
+        pk[e] = (h16)pv;
+      }
+      pf[s2] = pk;
+      *reinterpret_cast<h16x8*>(px_own + s2 * 1024) = pk;
+    }
+    l_run = fmaf(l_run, alpha, lsum);
+    m_run = m_new;
+    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+      for (int cb = 0; cb < NCBH; ++cb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc_o[cb][e] *= alpha;
+    }
+    __syncthreads();                                  // B: P fragments visible
+    pf[2] = *reinterpret_cast<const h16x8*>(px_par);
+    pf[3] = *reinterpret_cast<const h16x8*>(px_par + 1024);
+
+    // ---- O^T += V^T . P^T over the 4 k-steps of the tile (own half: k-steps 2*half, 2*half+1)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int ksabs = (s < 2) ? 2 * half + s : 2 * (half ^ 1) + (s - 2);
+#pragma unroll
+      for (int cb = 0; cb < NCBH; ++cb) {
+        const int row = c0 + cb * 32 + n;
+        const h16x8 vf = *reinterpret_cast<const h16x8*>(vs + row * 128 + (((2 * ksabs + hi) ^ ((row >> 1) & 7)) << 4));
+        acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], acc_o[cb], 0, 0, 0);
+      }
+    }
+
+    if (jt + 1 < njt) store_tile(buf ^ 1);
+    __syncthreads();                                  // C: next tile staged; exchange slots free again
+  }
+
+  // ---- epilogue: total l = both hi halves of both waves of the pair
+  {
+    const unsigned lb = __float_as_uint(l_run);
+    auto sw = __builtin_amdgcn_permlane32_swap(lb, lb, false, false);
+    const float l_half = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    *mx_own = l_half;
+    __syncthreads();
+    const float l_tot = l_half + *mx_par;
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (qvalid) {
+      h16* op = p.out + (int64_t)qrow * p.so_t + (int64_t)h * p.Rv + c0 + 4 * hi;
+#pragma unroll
+      for (int cb = 0; cb < NCBH; ++cb)
+#pragma unroll
+        for (int r2 = 0; r2 < 4; ++r2) {
+          h16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (h16)(acc_o[cb][4 * r2 + e] * inv);
+          *reinterpret_cast<h16x4*>(op + 32 * cb + 8 * r2) = o;
+        }
+    }
+  }
+}
+
+template <int NCBH>
+int launch_prefill_pair(const PfParams& p, hipStream_t stream) {
+  constexpr int smem = 2 * (PF_BN * 256 + 64 * NCBH * 128) + 4 * 2 * 32 * (int)sizeof(float) + 4 * 2 * 2 * 1024;
+  static bool attr_done = false;
+  auto kern = prefill_attn_pair_kernel<NCBH>;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) {
+      palu_set_error("hipFuncSetAttribute(%d B LDS) failed: %s", smem, hipGetErrorString(e));
+      return PALU_ERR_LAUNCH;
+    }
+    attr_done = true;
+  }
+  dim3 grid(p.nqt, p.H, 1);
+  hipLaunchKernelGGL(kern, grid, dim3(PFP_THREADS), smem, stream, p);
+  PALU_LAUNCH_CHECK();
+  return PALU_OK;
+}
+
 template <int NCB>
 int launch_prefill(const PfParams& p, hipStream_t stream) {
   constexpr int smem = 2 * (PF_BN * 256 + 32 * NCB * 128);
@@ -292,6 +534,13 @@ extern "C" int palu_prefill_attn_f16(const void* q, int64_t sq_h, int64_t sq_t, 
   p.scale_log2 = scale * 1.4426950408889634f;
   p.nqt = (Tq + PF_BM - 1) / PF_BM;
   hipStream_t s = (hipStream_t)stream;
+  static int use_pair = -1;
+  if (use_pair < 0) {
+    const char* e = getenv("PALU_PREFILL_PAIR");
+    use_pair = e ? atoi(e) : 1;
+  }
+  if (use_pair && Rv == 384) return launch_prefill_pair<6>(p, s);
+  if (use_pair && Rv == 256) return launch_prefill_pair<4>(p, s);
   if (Rv % 192 == 0) return launch_prefill<6>(p, s);
   if (Rv % 96 == 0) return launch_prefill<3>(p, s);
   if (Rv % 64 == 0) return launch_prefill<2>(p, s);
