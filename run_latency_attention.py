@@ -155,6 +155,27 @@ def profile_tpot(model, cache_size_k, cache_size_v, cache_type=torch.float16, ba
     return dur / reps
 
 
+def profile_ttft(model, prompt_len, repeats=5):
+    """Prompt pass (q_len = prompt_len, empty cache) through the flash-style prefill kernel: time to first token
+    of ONE attention module.  Additive to the reference harness, which only profiles TPOT."""
+    device = next(iter(model.parameters())).device
+    x = torch.randn((1, prompt_len, model.config.hidden_size), dtype=torch.float16, device=device)
+    with torch.no_grad():
+        for _ in range(2):
+            model(x, past_key_value=DynamicCache(capacity=prompt_len + 64), is_causal=True)
+        torch.cuda.synchronize()
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        caches = [DynamicCache(capacity=prompt_len + 64) for _ in range(repeats)]
+        start.record()
+        for c in caches:
+            model(x, past_key_value=c, is_causal=True)
+        end.record()
+        torch.cuda.synchronize()
+    ms = start.elapsed_time(end) / repeats
+    logging.info(f"Finished, prompt_len: {prompt_len}, prefill latency: {ms:.2f} milliseconds")
+    return ms
+
+
 def main(args):
     if not args.palu:
         raise SystemExit("only --palu is implemented in this build (the dense baseline is out of scope)")
@@ -168,6 +189,14 @@ def main(args):
     cache_size_v = (bs, num_groups, args.prompt_len, group_dim_v)
     if args.hadamard:
         attention.fuse_hadamard()
+    if args.ttft:
+        ms = profile_ttft(attention, args.prompt_len, max(1, min(args.repeats, 5)))
+        if args.json:
+            H, D, Rv = config.num_attention_heads, config.hidden_size // config.num_attention_heads, group_dim_v
+            flops = H * (args.prompt_len ** 2 / 2) * (D + Rv) * 2
+            print(json.dumps({"prefill_ms": ms, "prompt_len": args.prompt_len, "rank_k": args.rank_k, "rank_v": args.rank_v,
+                              "attention_TFLOPs_causal": flops / (ms * 1e-3) * 1e-12}))
+        return
     ms = profile_tpot(attention, cache_size_k, cache_size_v, torch.float16, bs, args.prompt_len, args.repeats,
                       args.cache_graph, args.torch_profile, "tpot_palu_fp16" if args.bits >= 16 else f"tpot_palu_int{args.bits}",
                       bits=args.bits)
@@ -194,6 +223,7 @@ if __name__ == "__main__":
     parser.add_argument("--bits", type=int, default=16, choices=[16, 4, 3],
                         help="latent KV precision: 16 = fp16 cache, 4/3 = packed codes (--lt_bits of the reference's eval scripts)")
     parser.add_argument("--hadamard", action="store_true", help="fuse Hadamard rotations into the weights (--lt_hadamard)")
+    parser.add_argument("--ttft", action="store_true", help="profile the prompt pass (prefill) instead of the decode step")
     parser.add_argument("--json", action="store_true", help="also print a JSON record with achieved HBM GB/s")
     args = parser.parse_args()
     logging.basicConfig(level=logging.INFO,
