@@ -124,7 +124,7 @@ def fuse_uv_into_wo(wo: torch.Tensor, uv_weights, group_size: int, head_dim: int
 
 # ------------------------------------------------------------------- prefill (q_len > 1)
 def prefill(hidden: torch.Tensor, weights: Dict[str, torch.Tensor], attention_mask: Optional[torch.Tensor] = None,
-            theta: float = 10000.0):
+            theta: float = 10000.0, latent_bits: int = 16):
     """Prompt pass of the low-rank attention module (batch 1, empty cache), fp16 tensors on CPU.
 
     hidden [T, hidden] fp16; weights: wq [H*D,hidden], vt_k [G*Rk,hidden], vt_v [G*Rv,hidden], u_k: list of G
@@ -148,6 +148,11 @@ def prefill(hidden: torch.Tensor, weights: Dict[str, torch.Tensor], attention_ma
     q = lin(hidden, wq).reshape(T, H, D).transpose(0, 1)                       # [H,T,D]
     k_lat = lin(hidden, vt_k).reshape(T, G, Rk).transpose(0, 1).contiguous()   # [G,T,Rk]
     v_lat = lin(hidden, vt_v).reshape(T, G, Rv).transpose(0, 1).contiguous()   # [G,T,Rv]
+    if latent_bits < 16:
+        # accuracy-path semantics: fake-quantise each (token, group) latent row before it is used
+        # (palu/model/modules/svd_linear.py:84-90,124-139)
+        k_lat = quantize_rows(k_lat.reshape(G * T, Rk), latent_bits)[0].reshape(G, T, Rk)
+        v_lat = quantize_rows(v_lat.reshape(G * T, Rv), latent_bits)[0].reshape(G, T, Rv)
     keys = torch.cat([lin(k_lat[g], u_k[g]) for g in range(G)], dim=-1)        # [T, H*D]  (:67-77)
     keys = keys.reshape(T, H, D).transpose(0, 1)                               # [H,T,D]
     cos, sin = rope_cos_sin(T, D, theta)

@@ -451,7 +451,7 @@ class LlamaPaluAttention(nn.Module):
         above = j > i
         return bool(((m <= -1e4) == above).all()) and bool((m.masked_fill(above, 0) == 0).all())
 
-    def _prefill_flash(self, hidden_states, pos, cache: "LatentCache", causal: bool):
+    def _prefill_flash(self, hidden_states, pos, cache, causal: bool):
         """Prompt branch (:196-257) on the flash-style HIP kernel: scores are never materialised.
 
         q and the latents are projected (latents straight into the cache rows), keys are rebuilt once as
@@ -462,7 +462,14 @@ class LlamaPaluAttention(nn.Module):
         past = cache.get_seq_length(self.layer_idx)
         dev, dt = hidden_states.device, hidden_states.dtype
         q = self.q_proj(hidden_states).view(q_len, H, D).transpose(0, 1)                  # [H,T,D]
-        key_h, val_h = self._project_into_cache(hidden_states, cache)                     # [1,G,kv,R] views
+        if isinstance(cache, LatentCache):
+            key_h, val_h = self._project_into_cache(hidden_states, cache)                 # [1,G,kv,R] views
+        else:
+            # packed 3/4-bit cache: quantise + pack the new rows, attend over the de-quantised values
+            # (the accuracy path's fake-quant semantics, svd_linear.py:84-90,124-139)
+            key_h = self.k_proj.project_to_latent(hidden_states).view(1, q_len, G, self.group_rank_k).transpose(1, 2)
+            val_h = self.v_proj.project_to_latent(hidden_states).view(1, q_len, G, self.group_rank_v).transpose(1, 2)
+            key_h, val_h = cache.update(key_h, val_h, self.layer_idx)
         kv = past + q_len
         cos, sin = self._rope_tables(pos.reshape(-1), dt)
         q = (q * cos.view(1, q_len, D) + _rotate_half(q) * sin.view(1, q_len, D)).contiguous()
@@ -532,7 +539,8 @@ class LlamaPaluAttention(nn.Module):
             return out, probs, past_key_value
 
         # ---- prompt pass on the flash-style HIP kernel (no [q, kv] score matrix) -----------------
-        if (q_len > 1 and bsz == 1 and isinstance(past_key_value, LatentCache) and fused_o and not output_attentions
+        if (q_len > 1 and bsz == 1 and isinstance(past_key_value, (LatentCache, QuantLatentCache)) and fused_o
+                and not output_attentions
                 and hidden_states.is_cuda and hidden_states.dtype == torch.float16 and self.head_dim == 128
                 and self.group_rank_v % 32 == 0 and self.k_proj.VT.bias is None and hasattr(self.k_proj, "B")
                 and self.o_proj.in_features == self.fused_hidden_dim_o):

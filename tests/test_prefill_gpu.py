@@ -176,3 +176,32 @@ def test_prefill_long_prompt_properties():
         head, _, _ = m(x[:, :1000], past_key_value=LatentCache(), is_causal=True)
     assert torch.isfinite(full.float()).all()
     torch.testing.assert_close(full[:, :1000], head, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("bits,rank_k,rank_v", [(4, 64, 128), (3, 256, 256)])   # 3-bit decode needs R_k = 128
+def test_prefill_quantised_cache(bits, rank_k, rank_v):
+    """Prompt pass into a packed 3/4-bit latent cache: the flash path attends over the de-quantised rows like the
+    accuracy path (oracle.prefill(latent_bits=...)); the packed cache then serves the fused quantised decode step."""
+    from palu_amd.kernel.palu_attention import QuantLatentCache
+    tag, seed, hidden, H, D, gs, _, _, T, _ = gi.PREFILL_CASES[0]
+    w, prompt, mask = gi.prefill_inputs(seed, hidden, H, D, gs, rank_k, rank_v, T, True)
+    m = _module_from_palu_weights(hidden, H, D, gs, rank_k, rank_v, w)
+    cache = QuantLatentCache(bits)
+    with torch.no_grad():
+        out, _, _ = m(prompt.reshape(1, T, hidden).to(DEV), past_key_value=cache, is_causal=True)
+    wd = {"wq": w["wq"].half(), "vt_k": w["vt_k"].half(), "vt_v": w["vt_v"].half(),
+          "u_k": [u.half() for u in w["u_k"]], "wo": w["wo"].half()}
+    o_ref, _, k_ref, v_ref = oracle.prefill(prompt, wd, mask, latent_bits=bits)
+    # latents come from a different GEMM (MFMA vs CPU) so a row may land in the neighbouring quantisation bin:
+    # compare against the output scale, not element-wise at 1e-3
+    err = (out[0].cpu().float() - o_ref.float()).abs().max().item()
+    assert err <= 2e-2 * o_ref.float().abs().max().item(), err
+    assert cache.get_seq_length(0) == T
+    rng = np.random.default_rng(78)
+    tok = torch.from_numpy(rng.standard_normal(hidden).astype(np.float16))
+    with torch.no_grad():
+        d, _, _ = m(tok.reshape(1, 1, hidden).to(DEV), past_key_value=cache, position_ids=torch.tensor([[T]]))
+    wd2 = dict(wd, b=oracle.build_b_from_u(w["u_k"], gs, D).half())
+    d_ref, _, _, _ = oracle.decode_step(tok, T, wd2, k_ref, v_ref, latent_bits=bits)
+    err = (d.reshape(-1).cpu().float() - d_ref.float()).abs().max().item()
+    assert err <= 2e-2 * d_ref.float().abs().max().item(), err
