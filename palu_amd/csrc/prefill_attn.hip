@@ -299,41 +299,39 @@ __global__ __launch_bounds__(PFP_THREADS, 1) void prefill_attn_pair_kernel(PfPar
   }
   const int njt = (kv_end + PF_BN - 1) / PF_BN;
 
+  // ---- staging: buffer loads (lane-constant offset + scalar tile offset: no per-tile address arithmetic; K~ rows
+  //      past the end fall outside the descriptor and read as zero -- they are masked anyway)
   const h16* kg = p.k + (int64_t)h * p.sk_h;
   const h16* vg = p.vt + (int64_t)g * p.sv_g;
+  const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<h16*>(kg), 0, (int)(((int64_t)(p.Tk - 1) * p.sk_t + 128) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<h16*>(vg), 0, (int)(((int64_t)(RV - 1) * p.sv_c + (int64_t)((p.Tk + PF_BN - 1) / PF_BN) * PF_BN) * 2), 0x00020000);
+  // this thread's chunks: chunk i sits 32 (K~) / 64 (V^T) rows below chunk 0 -- the swizzle key does not change, so
+  // one lane offset each for global and LDS; the row step rides in the scalar offset / the immediate
+  const int krow0 = tid >> 4, kch = tid & 15, vrow0 = tid >> 3, vch = tid & 7;
+  const unsigned kvo = (unsigned)((krow0 * p.sk_t + kch * 8) * 2);
+  const unsigned vvo = (unsigned)((vrow0 * p.sv_c + vch * 8) * 2);
+  const unsigned kso = (unsigned)(krow0 * 256 + ((kch ^ (krow0 & 15)) << 4));
+  const unsigned vso = (unsigned)(2 * KS_BYTES + vrow0 * 128 + ((vch ^ ((vrow0 >> 1) & 7)) << 4));
+  const unsigned ktile_bytes = __builtin_amdgcn_readfirstlane((unsigned)(PF_BN * p.sk_t * 2));
+  const unsigned kstep_bytes = __builtin_amdgcn_readfirstlane((unsigned)(32 * p.sk_t * 2));
+  const unsigned vstep_bytes = __builtin_amdgcn_readfirstlane((unsigned)(64 * p.sv_c * 2));
   u32x4 kreg[KLD], vreg[VLD];
-  auto load_k = [&](int jt) {
+  auto load_tile = [&](int jt) {
+    const unsigned ks_off = (unsigned)jt * ktile_bytes, vs_off = (unsigned)jt * (PF_BN * 2);
 #pragma unroll
-    for (int i = 0; i < KLD; ++i) {
-      const int s = tid + PFP_THREADS * i;
-      const int row = s >> 4, ch = s & 15;
-      const int j = min(jt * PF_BN + row, p.Tk - 1);
-      kreg[i] = *reinterpret_cast<const u32x4*>(kg + (int64_t)j * p.sk_t + ch * 8);
-    }
-  };
-  auto load_v = [&](int jt) {
+    for (int i = 0; i < KLD; ++i)
+      kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, kvo, ks_off + i * kstep_bytes, 0));
 #pragma unroll
-    for (int i = 0; i < VLD; ++i) {
-      const int s = tid + PFP_THREADS * i;
-      const int row = s >> 3, ch = s & 7;
-      vreg[i] = *reinterpret_cast<const u32x4*>(vg + (int64_t)row * p.sv_c + jt * PF_BN + ch * 8);
-    }
+    for (int i = 0; i < VLD; ++i)
+      vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, vvo, vs_off + i * vstep_bytes, 0));
   };
   auto store_tile = [&](int buf) {
-    char* ks = ks_base + buf * KS_BYTES;
-    char* vs = vs_base + buf * VS_BYTES;
 #pragma unroll
-    for (int i = 0; i < KLD; ++i) {
-      const int s = tid + PFP_THREADS * i;
-      const int row = s >> 4, ch = s & 15;
-      *reinterpret_cast<u32x4*>(ks + row * 256 + ((ch ^ (row & 15)) << 4)) = kreg[i];
-    }
+    for (int i = 0; i < KLD; ++i) *reinterpret_cast<u32x4*>(smem + buf * KS_BYTES + kso + i * 32 * 256) = kreg[i];
 #pragma unroll
-    for (int i = 0; i < VLD; ++i) {
-      const int s = tid + PFP_THREADS * i;
-      const int row = s >> 3, ch = s & 7;
-      *reinterpret_cast<u32x4*>(vs + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4)) = vreg[i];
-    }
+    for (int i = 0; i < VLD; ++i) *reinterpret_cast<u32x4*>(smem + buf * VS_BYTES + vso + i * 64 * 128) = vreg[i];
   };
 
   f32x16 acc_o[NCBH];
@@ -344,33 +342,50 @@ __global__ __launch_bounds__(PFP_THREADS, 1) void prefill_attn_pair_kernel(PfPar
   float m_run = -INFINITY;
   float l_run = 0.f;   // this lane's share: its hi-half of this wave's kv half
 
+  // lane-constant LDS byte offsets of the fragments (tile buffer and column block ride in the immediates)
   const int krow = half * 32 + ((n & 0x13) | ((n & 4) << 1) | ((n & 8) >> 1));
+  unsigned ka[8], va[4];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) ka[kk] = (unsigned)(krow * 256 + (((2 * kk + hi) ^ (krow & 15)) << 4));
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const int ksabs = (s < 2) ? 2 * half + s : 2 * (half ^ 1) + (s - 2);     // own k-steps first, then the partner's
+    va[s] = (unsigned)(2 * KS_BYTES + (c0 + n) * 128 + (((2 * ksabs + hi) ^ ((n >> 1) & 7)) << 4));
+  }
   float* mx_own = mx + (qblk * 2 + half) * 32 + n;
   const float* mx_par = mx + (qblk * 2 + (half ^ 1)) * 32 + n;
   char* px_own = px + ((qblk * 2 + half) * 2) * 1024 + lane * 16;
   const char* px_par = px + ((qblk * 2 + (half ^ 1)) * 2) * 1024 + lane * 16;
 
   if (njt > 0) {
-    load_k(0);
-    load_v(0);
+    load_tile(0);
     store_tile(0);
   }
   __syncthreads();
 
   for (int jt = 0; jt < njt; ++jt) {
     const int buf = jt & 1;
-    const char* ks = ks_base + buf * KS_BYTES;
-    const char* vs = vs_base + buf * VS_BYTES;
+    const char* kt = smem + buf * KS_BYTES;
+    const char* vt = smem + buf * VS_BYTES;
+    auto vfrag = [&](int s, int cb) { return *reinterpret_cast<const h16x8*>(vt + va[s] + cb * 32 * 128); };
 
-    // ---- this wave's half of S^T: 32 kv rows x 32 queries
+    // ---- this wave's half of S^T: 32 kv rows x 32 queries; all 8 K~ fragments are requested up front
+    h16x8 kf[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) kf[kk] = *reinterpret_cast<const h16x8*>(kt + ka[kk]);
+    if (jt + 1 < njt) load_tile(jt + 1);              // next tile's global loads fly during the whole iteration
+    __builtin_amdgcn_sched_barrier(0);
     f32x16 sacc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-      const h16x8 kf = *reinterpret_cast<const h16x8*>(ks + krow * 256 + (((2 * kk + hi) ^ (krow & 15)) << 4));
-      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], sacc, 0, 0, 0);
-    }
+    for (int kk = 0; kk < 8; ++kk) sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk], qf[kk], sacc, 0, 0, 0);
+    // V^T fragments of the first k-step are requested while the score MFMAs drain
+    h16x8 vf[2][NCBH];
+#pragma unroll
+    for (int cb = 0; cb < NCBH; ++cb) vf[0][cb] = vfrag(0, cb);
+    __builtin_amdgcn_sched_barrier(0);
+
     // register r in lane (t, hi) is kv = jt*64 + 32*half + 16(r>>3) + 8hi + (r&7)
     const int j0 = jt * PF_BN + 32 * half + 8 * hi;
     const bool need_mask = (jt * PF_BN + PF_BN > p.Tk) || (p.causal && jt * PF_BN + PF_BN - 1 > p.past + qt * PF_BM + qblk * 32);
@@ -391,11 +406,6 @@ __global__ __launch_bounds__(PFP_THREADS, 1) void prefill_attn_pair_kernel(PfPar
       mloc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
     }
     *mx_own = mloc;                                   // lanes t and t+32 write the same word
-    asm volatile("" ::: "memory");
-    if (jt + 1 < njt) {                               // next tile's global loads fly during the exchange and P.V
-      load_k(jt + 1);
-      load_v(jt + 1);
-    }
     __syncthreads();                                  // A: half-tile maxima visible
     const float m_new = fmaxf(m_run, fmaxf(mloc, *mx_par));
     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
@@ -427,16 +437,17 @@ __global__ __launch_bounds__(PFP_THREADS, 1) void prefill_attn_pair_kernel(PfPar
     pf[2] = *reinterpret_cast<const h16x8*>(px_par);
     pf[3] = *reinterpret_cast<const h16x8*>(px_par + 1024);
 
-    // ---- O^T += V^T . P^T over the 4 k-steps of the tile (own half: k-steps 2*half, 2*half+1)
+    // ---- O^T += V^T . P^T over the 4 k-steps (own two first); fragments double-buffered one k-step ahead
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const int ksabs = (s < 2) ? 2 * half + s : 2 * (half ^ 1) + (s - 2);
+      if (s + 1 < 4) {
 #pragma unroll
-      for (int cb = 0; cb < NCBH; ++cb) {
-        const int row = c0 + cb * 32 + n;
-        const h16x8 vf = *reinterpret_cast<const h16x8*>(vs + row * 128 + (((2 * ksabs + hi) ^ ((row >> 1) & 7)) << 4));
-        acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], acc_o[cb], 0, 0, 0);
+        for (int cb = 0; cb < NCBH; ++cb) vf[(s + 1) & 1][cb] = vfrag(s + 1, cb);
       }
+#pragma unroll
+      for (int cb = 0; cb < NCBH; ++cb)
+        acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[s & 1][cb], pf[s], acc_o[cb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
     }
 
     if (jt + 1 < njt) store_tile(buf ^ 1);
