@@ -299,40 +299,52 @@ __global__ __launch_bounds__(PFP_THREADS, 1) void prefill_attn_pair_kernel(PfPar
   }
   const int njt = (kv_end + PF_BN - 1) / PF_BN;
 
-  // ---- staging: buffer loads (lane-constant offset + scalar tile offset: no per-tile address arithmetic; K~ rows
-  //      past the end fall outside the descriptor and read as zero -- they are masked anyway)
+  // ---- staging by LDS-DMA (buffer_load_dwordx4 ... lds, see abx_rope_kernel.h): a wave-instruction fills 64
+  //      consecutive 16-byte LDS slots (4 K~ rows / 8 V^T rows); the XOR swizzle sits in the per-lane SOURCE offset,
+  //      which does not depend on the piece (pieces of a wave are 8 apart), the tile/piece select is scalar.  K~ rows
+  //      past the end are outside the descriptor (masked below whatever they read as); V^T is zero-padded by contract.
   const h16* kg = p.k + (int64_t)h * p.sk_h;
   const h16* vg = p.vt + (int64_t)g * p.sv_g;
-  const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<h16*>(kg), 0, (int)(((int64_t)(p.Tk - 1) * p.sk_t + 128) * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<h16*>(vg), 0, (int)(((int64_t)(RV - 1) * p.sv_c + (int64_t)((p.Tk + PF_BN - 1) / PF_BN) * PF_BN) * 2), 0x00020000);
-  // this thread's chunks: chunk i sits 32 (K~) / 64 (V^T) rows below chunk 0 -- the swizzle key does not change, so
-  // one lane offset each for global and LDS; the row step rides in the scalar offset / the immediate
-  const int krow0 = tid >> 4, kch = tid & 15, vrow0 = tid >> 3, vch = tid & 7;
-  const unsigned kvo = (unsigned)((krow0 * p.sk_t + kch * 8) * 2);
-  const unsigned vvo = (unsigned)((vrow0 * p.sv_c + vch * 8) * 2);
-  const unsigned kso = (unsigned)(krow0 * 256 + ((kch ^ (krow0 & 15)) << 4));
-  const unsigned vso = (unsigned)(2 * KS_BYTES + vrow0 * 128 + ((vch ^ ((vrow0 >> 1) & 7)) << 4));
+  auto make_rsrc = [](const void* base, int64_t bytes) {
+    u32x4 r;
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    r[2] = __builtin_amdgcn_readfirstlane((unsigned)bytes);
+    r[3] = 0x00020000u;
+    return r;
+  };
+  const u32x4 krs = make_rsrc(kg, ((int64_t)(p.Tk - 1) * p.sk_t + 128) * 2);
+  const u32x4 vrs = make_rsrc(vg, ((int64_t)(RV - 1) * p.sv_c + (int64_t)((p.Tk + PF_BN - 1) / PF_BN) * PF_BN) * 2);
+  const int krow_l = 4 * w + (lane >> 4), vrow_l = 8 * w + (lane >> 3);
+  const unsigned kvo = (unsigned)((krow_l * p.sk_t + (((lane & 15) ^ (krow_l & 15)) << 3)) * 2);
+  const unsigned vvo = (unsigned)((vrow_l * p.sv_c + (((lane & 7) ^ ((vrow_l >> 1) & 7)) << 3)) * 2);
   const unsigned ktile_bytes = __builtin_amdgcn_readfirstlane((unsigned)(PF_BN * p.sk_t * 2));
   const unsigned kstep_bytes = __builtin_amdgcn_readfirstlane((unsigned)(32 * p.sk_t * 2));
   const unsigned vstep_bytes = __builtin_amdgcn_readfirstlane((unsigned)(64 * p.sv_c * 2));
-  u32x4 kreg[KLD], vreg[VLD];
-  auto load_tile = [&](int jt) {
-    const unsigned ks_off = (unsigned)jt * ktile_bytes, vs_off = (unsigned)jt * (PF_BN * 2);
+  const unsigned smem_lds = (unsigned)reinterpret_cast<uintptr_t>(smem);
+  auto dma = [&](unsigned dst, unsigned voff, const u32x4& rs, unsigned soff) {
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds"
+        :
+        : "s"(dst), "v"(voff), "s"(rs), "s"(soff)
+        : "memory");
+  };
+  auto dma_k = [&](int jt, int buf) {
 #pragma unroll
     for (int i = 0; i < KLD; ++i)
-      kreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, kvo, ks_off + i * kstep_bytes, 0));
+      dma(__builtin_amdgcn_readfirstlane(smem_lds + buf * KS_BYTES + (w + 8 * i) * 1024), kvo, krs,
+          __builtin_amdgcn_readfirstlane((unsigned)jt * ktile_bytes + i * kstep_bytes));
+  };
+  auto dma_v = [&](int jt, int buf) {
 #pragma unroll
     for (int i = 0; i < VLD; ++i)
-      vreg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, vvo, vs_off + i * vstep_bytes, 0));
+      dma(__builtin_amdgcn_readfirstlane(smem_lds + 2 * KS_BYTES + buf * VS_BYTES + (w + 8 * i) * 1024), vvo, vrs,
+          __builtin_amdgcn_readfirstlane((unsigned)jt * (PF_BN * 2) + i * vstep_bytes));
   };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < KLD; ++i) *reinterpret_cast<u32x4*>(smem + buf * KS_BYTES + kso + i * 32 * 256) = kreg[i];
-#pragma unroll
-    for (int i = 0; i < VLD; ++i) *reinterpret_cast<u32x4*>(smem + buf * VS_BYTES + vso + i * 64 * 128) = vreg[i];
-  };
+  auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
   f32x16 acc_o[NCBH];
 #pragma unroll
@@ -357,35 +369,18 @@ __global__ __launch_bounds__(PFP_THREADS, 1) void prefill_attn_pair_kernel(PfPar
   char* px_own = px + ((qblk * 2 + half) * 2) * 1024 + lane * 16;
   const char* px_par = px + ((qblk * 2 + (half ^ 1)) * 2) * 1024 + lane * 16;
 
-  if (njt > 0) {
-    load_tile(0);
-    store_tile(0);
-  }
-  __syncthreads();
-
-  for (int jt = 0; jt < njt; ++jt) {
-    const int buf = jt & 1;
-    const char* kt = smem + buf * KS_BYTES;
-    const char* vt = smem + buf * VS_BYTES;
-    auto vfrag = [&](int s, int cb) { return *reinterpret_cast<const h16x8*>(vt + va[s] + cb * 32 * 128); };
-
-    // ---- this wave's half of S^T: 32 kv rows x 32 queries; all 8 K~ fragments are requested up front
+  // score MFMAs of tile jt (K~ in buffer jt&1), masked, plus this wave's half-tile maximum (both hi halves)
+  auto scores = [&](int jt, f32x16& sacc) {
+    const char* kt = smem + (jt & 1) * KS_BYTES;
     h16x8 kf[8];
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) kf[kk] = *reinterpret_cast<const h16x8*>(kt + ka[kk]);
-    if (jt + 1 < njt) load_tile(jt + 1);              // next tile's global loads fly during the whole iteration
-    __builtin_amdgcn_sched_barrier(0);
-    f32x16 sacc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kk], qf[kk], sacc, 0, 0, 0);
-    // V^T fragments of the first k-step are requested while the score MFMAs drain
-    h16x8 vf[2][NCBH];
-#pragma unroll
-    for (int cb = 0; cb < NCBH; ++cb) vf[0][cb] = vfrag(0, cb);
-    __builtin_amdgcn_sched_barrier(0);
-
+  };
+  auto mask_max = [&](int jt, f32x16& sacc) {
     // register r in lane (t, hi) is kv = jt*64 + 32*half + 16(r>>3) + 8hi + (r&7)
     const int j0 = jt * PF_BN + 32 * half + 8 * hi;
     const bool need_mask = (jt * PF_BN + PF_BN > p.Tk) || (p.causal && jt * PF_BN + PF_BN - 1 > p.past + qt * PF_BM + qblk * 32);
@@ -400,14 +395,41 @@ __global__ __launch_bounds__(PFP_THREADS, 1) void prefill_attn_pair_kernel(PfPar
     float mloc = sacc[0];
 #pragma unroll
     for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, sacc[r]);
-    {
-      const unsigned mb = __float_as_uint(mloc);
-      auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
-      mloc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-    }
-    *mx_own = mloc;                                   // lanes t and t+32 write the same word
-    __syncthreads();                                  // A: half-tile maxima visible
-    const float m_new = fmaxf(m_run, fmaxf(mloc, *mx_par));
+    const unsigned mb = __float_as_uint(mloc);
+    auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);
+    return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+  };
+
+  // ---- software pipeline: iteration jt runs the score MFMAs of tile jt+1 underneath the softmax of tile jt.
+  //      K~ tile j lives in buffer j&1 (read during iteration j-1), V^T tile j in buffer j&1 (read during iteration j).
+  f32x16 s_cur, s_nxt;
+  float mloc_cur = -INFINITY;
+  if (njt > 0) {
+    dma_k(0, 0);
+    dma_v(0, 0);
+    if (njt > 1) dma_k(1, 1);
+    dma_wait();
+  }
+  __syncthreads();
+  if (njt > 0) {
+    scores(0, s_cur);
+    mloc_cur = mask_max(0, s_cur);
+    *mx_own = mloc_cur;
+  }
+  __syncthreads();
+
+  for (int jt = 0; jt < njt; ++jt) {
+    const char* vt = smem + (jt & 1) * VS_BYTES;
+    auto vfrag = [&](int s, int cb) { return *reinterpret_cast<const h16x8*>(vt + va[s] + cb * 32 * 128); };
+    // buffers free since the barrier that ended iteration jt-1: K~ buffer jt&1 (tile jt was consumed last iteration),
+    // V^T buffer (jt+1)&1 (tile jt-1)
+    if (jt + 2 < njt) dma_k(jt + 2, jt & 1);
+    if (jt + 1 < njt) dma_v(jt + 1, (jt + 1) & 1);
+    const float m_par = *mx_par;                       // written before the last barrier
+    if (jt + 1 < njt) scores(jt + 1, s_nxt);           // matrix pipe works on the next tile ...
+    __builtin_amdgcn_sched_barrier(0);
+    // ... while the vector ALU turns tile jt's scores into probabilities
+    const float m_new = fmaxf(m_run, fmaxf(mloc_cur, m_par));
     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
     const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * p.scale_log2);
     const float moff = -m_use * p.scale_log2;
@@ -418,7 +440,7 @@ __global__ __launch_bounds__(PFP_THREADS, 1) void prefill_attn_pair_kernel(PfPar
       h16x8 pk;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[8 * s2 + e], p.scale_log2, moff));
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s_cur[8 * s2 + e], p.scale_log2, moff));
         lsum += pv;
         pk[e] = (h16)pv;
       }
@@ -433,6 +455,9 @@ __global__ __launch_bounds__(PFP_THREADS, 1) void prefill_attn_pair_kernel(PfPar
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc_o[cb][e] *= alpha;
     }
+    h16x8 vf[2][NCBH];
+#pragma unroll
+    for (int cb = 0; cb < NCBH; ++cb) vf[0][cb] = vfrag(0, cb);
     __syncthreads();                                  // B: P fragments visible
     pf[2] = *reinterpret_cast<const h16x8*>(px_par);
     pf[3] = *reinterpret_cast<const h16x8*>(px_par + 1024);
@@ -450,8 +475,14 @@ __global__ __launch_bounds__(PFP_THREADS, 1) void prefill_attn_pair_kernel(PfPar
       __builtin_amdgcn_sched_barrier(0);
     }
 
-    if (jt + 1 < njt) store_tile(buf ^ 1);
-    __syncthreads();                                  // C: next tile staged; exchange slots free again
+    // next tile's half-tile maximum goes out before the barrier that also publishes the staged tiles
+    if (jt + 1 < njt) {
+      mloc_cur = mask_max(jt + 1, s_nxt);
+      *mx_own = mloc_cur;
+      s_cur = s_nxt;
+    }
+    dma_wait();
+    __syncthreads();                                  // A/C: maxima + staged tiles visible, exchange slots free
   }
 
   // ---- epilogue: total l = both hi halves of both waves of the pair
@@ -534,6 +565,8 @@ extern "C" int palu_prefill_attn_f16(const void* q, int64_t sq_h, int64_t sq_t, 
                    sk_h % 8 == 0 && sk_t % 8 == 0 && sv_g % 8 == 0 && sv_c % 8 == 0 && ((uintptr_t)out & 7) == 0 &&
                    so_t % 4 == 0,
                PALU_ERR_ARG, "prefill_attn: rows must be 16-byte aligned (out 8-byte)");
+  PALU_REQUIRE(((int64_t)Tk + PF_BN) * sk_t * 2 < ((int64_t)1 << 32) && (int64_t)Rv * sv_c * 2 < ((int64_t)1 << 32),
+               PALU_ERR_UNSUPPORTED, "prefill_attn: one head's keys / one group's values must stay below 4 GiB");
   const int tk_pad = (Tk + PF_BN - 1) / PF_BN * PF_BN;
   PALU_REQUIRE(sv_c >= tk_pad, PALU_ERR_ARG,
                "prefill_attn: vt rows must be zero-padded to a multiple of %d kv positions (sv_c=%lld < %d)", PF_BN,
