@@ -583,8 +583,16 @@ extern "C" int palu_prefill_attn_f16(const void* q, int64_t sq_h, int64_t sq_t, 
     const char* e = getenv("PALU_PREFILL_PAIR");
     use_pair = e ? atoi(e) : 1;
   }
-  if (use_pair && Rv == 384) return launch_prefill_pair<6>(p, s);
-  if (use_pair && Rv == 256) return launch_prefill_pair<4>(p, s);
+  if (use_pair && Rv % 64 == 0 && Rv <= 384) {          // two waves per 32 queries, each half of the latent columns
+    switch (Rv / 64) {
+      case 1: return launch_prefill_pair<1>(p, s);
+      case 2: return launch_prefill_pair<2>(p, s);
+      case 3: return launch_prefill_pair<3>(p, s);
+      case 4: return launch_prefill_pair<4>(p, s);
+      case 5: return launch_prefill_pair<5>(p, s);
+      default: return launch_prefill_pair<6>(p, s);
+    }
+  }
   if (Rv % 192 == 0) return launch_prefill<6>(p, s);
   if (Rv % 96 == 0) return launch_prefill<3>(p, s);
   if (Rv % 64 == 0) return launch_prefill<2>(p, s);

@@ -58,7 +58,8 @@ def ref_attn_f32(q, k, v_lat, past, causal, scale):
 @pytest.mark.parametrize("H,gs,Tq,Tk,Rv,causal", [
     (4, 2, 48, 48, 64, True), (4, 2, 70, 70, 64, False), (8, 4, 130, 130, 96, True), (8, 4, 257, 257, 192, True),
     (32, 4, 300, 300, 384, True), (4, 1, 1, 200, 32, False), (8, 4, 129, 1000, 384, True), (8, 2, 640, 640, 128, True),
-    (4, 4, 128, 192, 384, False), (8, 4, 333, 333, 256, True), (32, 4, 1100, 1100, 384, True)])
+    (4, 4, 128, 192, 384, False), (8, 4, 333, 333, 256, True), (32, 4, 1100, 1100, 384, True),
+    (8, 4, 200, 200, 320, True), (8, 2, 500, 700, 448, True), (4, 2, 77, 77, 160, False)])
 def test_prefill_kernel_vs_fp32(H, gs, Tq, Tk, Rv, causal):
     rng = np.random.default_rng(H * 1000 + Tq + Tk + Rv)
     G = H // gs
