@@ -189,6 +189,15 @@ int palu_lowrank_project_gemm(const void* x, int64_t ldx, const void* w, int64_t
                               int M, int N, int K, int R, int row0, palu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * In-place rotary embedding of x [H, T, D] fp16 (strides sx_h, sx_t; D contiguous), row t at position
+ * pos0 + t, with the rounding points of the reference's prompt branch (HF 4.37.2 rotary_emb +
+ * apply_rotary_pos_emb as called at kernel/palu_attention.py:204-205): fp32 cos/sin table cast to fp16,
+ * x*cos + rotate_half(x)*sin evaluated in fp16.  inv_freq: D/2 fp32 values (palu_rope_inv_freq_host).
+ */
+int palu_rope_f16(void* x, int64_t sx_h, int64_t sx_t, int H, int T, int D, int pos0, const float* inv_freq,
+                  palu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Prefill attention over the latent value cache: the q_len > 1 branch of
  * LlamaPaluAttention.forward (kernel/palu_attention.py:196-206 scores, :229-238 mask + softmax,
  * :246-255 latent P.V and head concat), flash-style -- the [Tq x Tk] score matrix of :205 is never

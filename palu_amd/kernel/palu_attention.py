@@ -461,7 +461,7 @@ class LlamaPaluAttention(nn.Module):
         q_len = hidden_states.shape[1]
         past = cache.get_seq_length(self.layer_idx)
         dev, dt = hidden_states.device, hidden_states.dtype
-        q = self.q_proj(hidden_states).view(q_len, H, D).transpose(0, 1)                  # [H,T,D]
+        q = self.q_proj(hidden_states).view(q_len, H, D).transpose(0, 1)                  # [H,T,D] view of [T, H*D]
         if isinstance(cache, LatentCache):
             key_h, val_h = self._project_into_cache(hidden_states, cache)                 # [1,G,kv,R] views
         else:
@@ -471,12 +471,35 @@ class LlamaPaluAttention(nn.Module):
             val_h = self.v_proj.project_to_latent(hidden_states).view(1, q_len, G, self.group_rank_v).transpose(1, 2)
             key_h, val_h = cache.update(key_h, val_h, self.layer_idx)
         kv = past + q_len
-        cos, sin = self._rope_tables(pos.reshape(-1), dt)
-        q = (q * cos.view(1, q_len, D) + _rotate_half(q) * sin.view(1, q_len, D)).contiguous()
-        kc, ks = self._rope_tables(torch.arange(kv, device=dev), dt)
-        b = self.k_proj.B.view(G, gs, self.group_rank_k, D)
-        keys = torch.matmul(key_h[0].unsqueeze(1), b).view(H, kv, D)                       # K = X_k . B  (:199-201)
-        keys = (keys * kc.view(1, kv, D) + _rotate_half(keys) * ks.view(1, kv, D)).contiguous()
+        inv = rope_inv_freq(dev, D, self.rope_theta)
+        stream = _lib.current_stream()
+        p0 = int(pos.reshape(-1)[0])
+        contiguous_pos = bool((pos.reshape(-1) == torch.arange(p0, p0 + q_len, device=pos.device)).all())
+        if contiguous_pos and q.stride(2) == 1:
+            _lib.check(_lib.lib.palu_rope_f16(q.data_ptr(), q.stride(0), q.stride(1), H, q_len, D, p0, inv.data_ptr(), stream),
+                       "palu_rope_f16")
+        else:
+            cos, sin = self._rope_tables(pos.reshape(-1), dt)
+            q = (q * cos.view(1, q_len, D) + _rotate_half(q) * sin.view(1, q_len, D)).contiguous()
+        # K~ = RoPE(X_k . B): per group the reconstruct GEMM X_g . U_g^T (:67-77, :199-201) lands head-major in the
+        # [H, kv, D] workspace, then the rotation runs in place
+        u_ok = (self.group_rank_k % 64 == 0 and all(u.weight.dtype == dt and u.weight.is_contiguous() and u.bias is None
+                                                    for u in self.k_proj.U_list))
+        if u_ok:
+            keys = torch.empty((H, kv, D), dtype=dt, device=dev)
+            xk = key_h[0]
+            for gi_, u in enumerate(self.k_proj.U_list):
+                xg = xk[gi_]
+                _lib.check(_lib.lib.palu_lowrank_project_gemm(xg.data_ptr(), xg.stride(0), u.weight.data_ptr(), u.weight.stride(0),
+                                                              keys[gi_ * gs].data_ptr(), keys.stride(0), keys.stride(1), kv,
+                                                              gs * D, self.group_rank_k, D, 0, stream), "palu_lowrank_project_gemm")
+            _lib.check(_lib.lib.palu_rope_f16(keys.data_ptr(), keys.stride(0), keys.stride(1), H, kv, D, 0, inv.data_ptr(), stream),
+                       "palu_rope_f16")
+        else:
+            kc, ks = self._rope_tables(torch.arange(kv, device=dev), dt)
+            b = self.k_proj.B.view(G, gs, self.group_rank_k, D)
+            keys = torch.matmul(key_h[0].unsqueeze(1), b).view(H, kv, D)                   # K = X_k . B  (:199-201)
+            keys = (keys * kc.view(1, kv, D) + _rotate_half(keys) * ks.view(1, kv, D)).contiguous()
         kv_pad = (kv + 63) // 64 * 64
         vt = torch.zeros((G, self.group_rank_v, kv_pad), dtype=dt, device=dev)
         vt[:, :, :kv].copy_(val_h[0].transpose(1, 2))
@@ -484,7 +507,7 @@ class LlamaPaluAttention(nn.Module):
         _lib.check(_lib.lib.palu_prefill_attn_f16(q.data_ptr(), q.stride(0), q.stride(1), keys.data_ptr(), keys.stride(0),
                                                   keys.stride(1), vt.data_ptr(), vt.stride(0), vt.stride(1),
                                                   ctx.data_ptr(), ctx.stride(0), H, G, D, q_len, kv, self.group_rank_v,
-                                                  past, 1 if causal else 0, 1.0 / math.sqrt(D), _lib.current_stream()),
+                                                  past, 1 if causal else 0, 1.0 / math.sqrt(D), stream),
                    "palu_prefill_attn_f16")
         return self.o_proj(ctx).view(1, q_len, -1)
 

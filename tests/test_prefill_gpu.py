@@ -206,3 +206,27 @@ def test_prefill_quantised_cache(bits, rank_k, rank_v):
     d_ref, _, _, _ = oracle.decode_step(tok, T, wd2, k_ref, v_ref, latent_bits=bits)
     err = (d.reshape(-1).cpu().float() - d_ref.float()).abs().max().item()
     assert err <= 2e-2 * d_ref.float().abs().max().item(), err
+
+
+@pytest.mark.parametrize("H,T,pos0,strided", [(4, 130, 0, False), (32, 257, 1000, True), (8, 64, 65000, False)])
+def test_rope_inplace_matches_reference_rounding(H, T, pos0, strided):
+    """palu_rope_f16 == the fp16 tensor-op sequence of the prompt branch (oracle.rope_cos_sin cast to fp16,
+    x*cos + rotate_half(x)*sin evaluated in fp16): identical up to the last fp16 bit of a few table entries."""
+    from palu_amd.kernel.abx_rope import rope_inv_freq
+    lib = _lib()
+    rng = np.random.default_rng(T + pos0)
+    if strided:
+        base = torch.from_numpy(rng.standard_normal((T, H, 128)).astype(np.float16))
+        x_cpu = base.transpose(0, 1)
+    else:
+        x_cpu = torch.from_numpy(rng.standard_normal((H, T, 128)).astype(np.float16))
+    cos, sin = oracle.rope_cos_sin(pos0 + T, 128, 10000.0, start=pos0)
+    cos, sin = cos.half(), sin.half()
+    ref = x_cpu * cos + torch.cat((-x_cpu[..., 64:], x_cpu[..., :64]), dim=-1) * sin
+    xg = (base.to(DEV).transpose(0, 1) if strided else x_cpu.to(DEV))
+    inv = rope_inv_freq(torch.device(DEV), 128, 10000.0)
+    lib.check(lib.lib.palu_rope_f16(xg.data_ptr(), xg.stride(0), xg.stride(1), H, T, 128, pos0, inv.data_ptr(),
+                                    torch.cuda.current_stream().cuda_stream), "rope")
+    got = xg.cpu()
+    torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-3)
+    assert (got != ref).float().mean().item() < 0.02          # the odd fp16 ulp from cos/sin of large angles
