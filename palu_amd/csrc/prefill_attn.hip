@@ -16,6 +16,7 @@
 // One 256-thread workgroup = 128 queries (32 per wave) x one head x one chunk of 32*NCB latent columns; K~/V^T
 // tiles of 64 kv go through a double-buffered LDS image (XOR-swizzled 16-byte chunks, register-staged).
 #include <cstdlib>
+#include <type_traits>
 
 #include "palu_common.h"
 
@@ -400,10 +401,12 @@ __global__ __launch_bounds__(PFP_THREADS, 1) void prefill_attn_pair_kernel(PfPar
     return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
   };
 
-  // ---- software pipeline: iteration jt runs the score MFMAs of tile jt+1 underneath the softmax of tile jt.
-  //      K~ tile j lives in buffer j&1 (read during iteration j-1), V^T tile j in buffer j&1 (read during iteration j).
+  // ---- software pipeline, two tiles deep: iteration jt interleaves the P.V MFMAs of tile jt-1 with the softmax
+  //      VALU work of tile jt (one exp/convert slice per MFMA gap), then runs the score MFMAs of tile jt+1.
+  //      K~ tile j lives in buffer j&1 (read in iteration j-1), V^T tile j in buffer j&1 (read in iteration j+1).
   f32x16 s_cur, s_nxt;
   float mloc_cur = -INFINITY;
+  h16x8 pf_prev[4];                                     // P^T fragments of the previous tile (own two, partner's two)
   if (njt > 0) {
     dma_k(0, 0);
     dma_v(0, 0);
@@ -418,71 +421,79 @@ __global__ __launch_bounds__(PFP_THREADS, 1) void prefill_attn_pair_kernel(PfPar
   }
   __syncthreads();
 
-  for (int jt = 0; jt < njt; ++jt) {
-    const char* vt = smem + (jt & 1) * VS_BYTES;
+  constexpr int GAPS = 4 * NCBH;
+  constexpr int EPG = (16 + GAPS - 1) / GAPS;           // softmax elements per MFMA gap
+  for (int jt = 0; jt <= njt; ++jt) {                   // iteration njt only drains the last tile's P.V
+    const bool have_sm = jt < njt;                      // a tile to turn into probabilities
+    const bool have_pv = jt > 0;                        // a previous tile to multiply with V
+    const char* vt = smem + ((jt + 1) & 1) * VS_BYTES;  // V^T tile jt-1
     auto vfrag = [&](int s, int cb) { return *reinterpret_cast<const h16x8*>(vt + va[s] + cb * 32 * 128); };
-    // buffers free since the barrier that ended iteration jt-1: K~ buffer jt&1 (tile jt was consumed last iteration),
-    // V^T buffer (jt+1)&1 (tile jt-1)
-    if (jt + 2 < njt) dma_k(jt + 2, jt & 1);
-    if (jt + 1 < njt) dma_v(jt + 1, (jt + 1) & 1);
-    const float m_par = *mx_par;                       // written before the last barrier
-    if (jt + 1 < njt) scores(jt + 1, s_nxt);           // matrix pipe works on the next tile ...
-    __builtin_amdgcn_sched_barrier(0);
-    // ... while the vector ALU turns tile jt's scores into probabilities
-    const float m_new = fmaxf(m_run, fmaxf(mloc_cur, m_par));
-    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_use) * p.scale_log2);
-    const float moff = -m_use * p.scale_log2;
-    float lsum = 0.f;
-    h16x8 pf[4];
+    if (jt + 2 < njt) dma_k(jt + 2, jt & 1);            // K~ buffer jt&1: tile jt was consumed in iteration jt-1
+    float m_new = m_run, alpha = 1.0f, moff = 0.f, lsum = 0.f;
+    if (have_sm) {
+      m_new = fmaxf(m_run, fmaxf(mloc_cur, *mx_par));   // partner's maximum: written before the last barrier
+      const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+      alpha = __builtin_amdgcn_exp2f((m_run - m_use) * p.scale_log2);
+      moff = -m_use * p.scale_log2;
+    }
+    h16x8 pk[2];
+    auto softmax_slice = [&](int e) {                   // element e of this lane's 16 scores of tile jt
+      const float pv = __builtin_amdgcn_exp2f(fmaf(s_cur[e], p.scale_log2, moff));
+      lsum += pv;
+      pk[e >> 3][e & 7] = (h16)pv;
+      if ((e & 7) == 7) *reinterpret_cast<h16x8*>(px_own + (e >> 3) * 1024) = pk[e >> 3];
+    };
+    if (have_pv) {
+      h16x8 vf[2][NCBH];
 #pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-      h16x8 pk;
+      for (int cb = 0; cb < NCBH; ++cb) vf[0][cb] = vfrag(0, cb);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float pv = __builtin_amdgcn_exp2f(fmaf(s_cur[8 * s2 + e], p.scale_log2, moff));
-        lsum += pv;
-        pk[e] = (h16)pv;
+      for (int s = 0; s < 4; ++s) {
+        if (s + 1 < 4) {
+#pragma unroll
+          for (int cb = 0; cb < NCBH; ++cb) vf[(s + 1) & 1][cb] = vfrag(s + 1, cb);
+        }
+#pragma unroll
+        for (int cb = 0; cb < NCBH; ++cb) {
+          acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[s & 1][cb], pf_prev[s], acc_o[cb], 0, 0, 0);
+          if (have_sm) {
+#pragma unroll
+            for (int q = 0; q < EPG; ++q)
+              if ((s * NCBH + cb) * EPG + q < 16) softmax_slice((s * NCBH + cb) * EPG + q);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
-      pf[s2] = pk;
-      *reinterpret_cast<h16x8*>(px_own + s2 * 1024) = pk;
+    } else if (have_sm) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) softmax_slice(e);
     }
-    l_run = fmaf(l_run, alpha, lsum);
-    m_run = m_new;
-    if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+    if (have_sm) {
+      l_run = fmaf(l_run, alpha, lsum);
+      m_run = m_new;
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {   // O (incl. tile jt-1) moves to the new maximum
 #pragma unroll
-      for (int cb = 0; cb < NCBH; ++cb)
+        for (int cb = 0; cb < NCBH; ++cb)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc_o[cb][e] *= alpha;
-    }
-    h16x8 vf[2][NCBH];
-#pragma unroll
-    for (int cb = 0; cb < NCBH; ++cb) vf[0][cb] = vfrag(0, cb);
-    __syncthreads();                                  // B: P fragments visible
-    pf[2] = *reinterpret_cast<const h16x8*>(px_par);
-    pf[3] = *reinterpret_cast<const h16x8*>(px_par + 1024);
-
-    // ---- O^T += V^T . P^T over the 4 k-steps (own two first); fragments double-buffered one k-step ahead
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (s + 1 < 4) {
-#pragma unroll
-        for (int cb = 0; cb < NCBH; ++cb) vf[(s + 1) & 1][cb] = vfrag(s + 1, cb);
+          for (int e = 0; e < 16; ++e) acc_o[cb][e] *= alpha;
       }
-#pragma unroll
-      for (int cb = 0; cb < NCBH; ++cb)
-        acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[s & 1][cb], pf[s], acc_o[cb], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
+      pf_prev[0] = pk[0];
+      pf_prev[1] = pk[1];
     }
-
-    // next tile's half-tile maximum goes out before the barrier that also publishes the staged tiles
+    __syncthreads();                                    // B: P fragments of tile jt visible; V^T buffer (jt+1)&1 free
+    if (have_sm) {
+      pf_prev[2] = *reinterpret_cast<const h16x8*>(px_par);
+      pf_prev[3] = *reinterpret_cast<const h16x8*>(px_par + 1024);
+    }
     if (jt + 1 < njt) {
+      dma_v(jt + 1, (jt + 1) & 1);                      // consumed in iteration jt+2
+      scores(jt + 1, s_nxt);
       mloc_cur = mask_max(jt + 1, s_nxt);
       *mx_own = mloc_cur;
       s_cur = s_nxt;
     }
     dma_wait();
-    __syncthreads();                                  // A/C: maxima + staged tiles visible, exchange slots free
+    __syncthreads();                                    // A: maxima + staged tiles visible, exchange slots free
   }
 
   // ---- epilogue: total l = both hi halves of both waves of the pair
