@@ -188,6 +188,79 @@ class QuantLatentCache:
         return self.dequantized(layer_idx)
 
 
+CACHE_FORMAT = "palu-latent-cache"
+CACHE_FORMAT_VERSION = "1"
+
+
+def save_cache(cache, path: str) -> None:
+    """Write a LatentCache / QuantLatentCache to one safetensors file -- the stable on-disk form of the latent cache
+    (SURVEY 8(f) N2).  Only the valid rows are stored, in the device layout of DESIGN.md section 3:
+      fp16 cache : `layer{i}.k` [G, n, Rk], `layer{i}.v` [G, n, Rv]                         fp16
+      packed     : `layer{i}.k_codes` [G, n, Rk*bits/8] uint8 (little-endian bit stream per row, code j at bits
+                   [j*bits, (j+1)*bits)), `layer{i}.k_meta` [G, n, 2] fp16 = (scale, zero); same for v
+    metadata: format, version, kind (fp16|packed), bits, layers, rank_k / rank_v per layer."""
+    from safetensors.torch import save_file
+    tensors, meta = {}, {"format": CACHE_FORMAT, "version": CACHE_FORMAT_VERSION, "layers": str(len(cache))}
+    if isinstance(cache, QuantLatentCache):
+        meta.update(kind="packed", bits=str(cache.n_bits))
+        for i in range(len(cache)):
+            st, n = cache.buffers(i), cache.get_seq_length(i)
+            if st is None:
+                continue
+            meta[f"layer{i}.rank_k"], meta[f"layer{i}.rank_v"] = str(st["Rk"]), str(st["Rv"])
+            for name, key in (("k_codes", "kc"), ("k_meta", "km"), ("v_codes", "vc"), ("v_meta", "vm")):
+                tensors[f"layer{i}.{name}"] = st[key][0, :, :n].contiguous().cpu()
+    elif isinstance(cache, LatentCache):
+        meta.update(kind="fp16", bits="16")
+        for i in range(len(cache)):
+            k, v = cache.buffers(i)
+            n = cache.get_seq_length(i)
+            if k is None:
+                continue
+            tensors[f"layer{i}.k"] = k[0, :, :n].contiguous().cpu()
+            tensors[f"layer{i}.v"] = v[0, :, :n].contiguous().cpu()
+    else:
+        raise TypeError("save_cache expects a LatentCache or QuantLatentCache")
+    save_file(tensors, path, metadata=meta)
+
+
+def load_cache(path: str, device="cpu", capacity: int = 0, headroom: int = 256):
+    """Inverse of save_cache: rebuilds the cache object (pre-allocated to max(capacity, rows + headroom)) on `device`."""
+    from safetensors import safe_open
+    with safe_open(path, framework="pt", device="cpu") as f:
+        meta = f.metadata() or {}
+        if meta.get("format") != CACHE_FORMAT:
+            raise ValueError(f"{path}: not a {CACHE_FORMAT} file")
+        if meta.get("version") != CACHE_FORMAT_VERSION:
+            raise ValueError(f"{path}: unsupported {CACHE_FORMAT} version {meta.get('version')}")
+        layers = int(meta["layers"])
+        names = set(f.keys())
+        if meta["kind"] == "packed":
+            cache = QuantLatentCache(int(meta["bits"]), capacity, headroom)
+            for i in range(layers):
+                if f"layer{i}.k_codes" not in names:
+                    cache._ensure_layer(i)
+                    continue
+                kc = f.get_tensor(f"layer{i}.k_codes")
+                G, n = kc.shape[0], kc.shape[1]
+                cache.reserve(i, n + headroom, G, int(meta[f"layer{i}.rank_k"]), int(meta[f"layer{i}.rank_v"]), device)
+                st = cache.buffers(i)
+                for name, key in (("k_codes", "kc"), ("k_meta", "km"), ("v_codes", "vc"), ("v_meta", "vm")):
+                    st[key][0, :, :n].copy_(f.get_tensor(f"layer{i}.{name}"))
+                cache.advance(i, n)
+        elif meta["kind"] == "fp16":
+            cache = LatentCache(capacity, headroom)
+            for i in range(layers):
+                if f"layer{i}.k" not in names:
+                    cache._ensure_layer(i)
+                    continue
+                k, v = f.get_tensor(f"layer{i}.k"), f.get_tensor(f"layer{i}.v")
+                cache.update(k.unsqueeze(0).to(device), v.unsqueeze(0).to(device), i)
+        else:
+            raise ValueError(f"{path}: unknown cache kind {meta['kind']}")
+    return cache
+
+
 DynamicCache = LatentCache  # name used by run_latency_attention.py:62-65 and the reference tests
 
 

@@ -157,3 +157,46 @@ def test_latent_cache_protocol():
     assert c.get_seq_length(2) == 5 and c.get_seq_length(1) == 0 and len(c) == 3
     with pytest.raises(ValueError):
         c.update(k0[0], v0[0], 0)
+
+
+def test_cache_save_load_roundtrip(tmp_path):
+    """On-disk form of the latent caches (safetensors container): valid rows, layout and
+    metadata survive a round trip for the fp16 and the packed cache, several layers, empty layers included."""
+    from palu_amd.kernel.palu_attention import LatentCache, QuantLatentCache, load_cache, save_cache
+    from palu_amd.kernel.quant import packed_row_bytes
+    g = torch.Generator().manual_seed(5)
+    c = LatentCache(capacity=100)
+    for layer, n in ((0, 37), (2, 5)):
+        c.update(torch.randn(1, 2, n, 32, generator=g).half(), torch.randn(1, 2, n, 64, generator=g).half(), layer)
+    c.update(torch.randn(1, 2, 3, 32, generator=g).half(), torch.randn(1, 2, 3, 64, generator=g).half(), 0)
+    path = str(tmp_path / "fp16.safetensors")
+    save_cache(c, path)
+    d = load_cache(path)
+    assert isinstance(d, LatentCache) and len(d) == 3
+    assert [d.get_seq_length(i) for i in range(3)] == [40, 0, 5]
+    for i in (0, 2):
+        n = c.get_seq_length(i)
+        for a, b in zip(c.buffers(i), d.buffers(i)):
+            assert torch.equal(a[:, :, :n], b[:, :, :n])
+    # packed cache: fill the buffers directly (quantisation itself is a GPU kernel, tested in the gpu suite)
+    q = QuantLatentCache(3)
+    q.reserve(0, 50, 2, 64, 128, "cpu")
+    st = q.buffers(0)
+    assert st["kc"].shape[-1] == packed_row_bytes(64, 3) == 24
+    for key in ("kc", "vc"):
+        st[key][:, :, :41] = torch.randint(0, 256, st[key][:, :, :41].shape, generator=g, dtype=torch.uint8)
+    for key in ("km", "vm"):
+        st[key][:, :, :41] = torch.randn(st[key][:, :, :41].shape, generator=g).half()
+    q.advance(0, 41)
+    path = str(tmp_path / "packed.safetensors")
+    save_cache(q, path)
+    r = load_cache(path)
+    assert isinstance(r, QuantLatentCache) and r.n_bits == 3 and r.get_seq_length(0) == 41
+    rt = r.buffers(0)
+    assert (rt["Rk"], rt["Rv"]) == (64, 128)
+    for key in ("kc", "km", "vc", "vm"):
+        assert torch.equal(st[key][:, :, :41], rt[key][:, :, :41])
+    with pytest.raises(ValueError):
+        from safetensors.torch import save_file
+        save_file({"x": torch.zeros(1)}, str(tmp_path / "other.safetensors"))
+        load_cache(str(tmp_path / "other.safetensors"))
