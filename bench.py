@@ -201,7 +201,7 @@ def main():
                       "as built by run_latency_attention.py)" % (rank_k, Lp // 1024),
             "value": round(us_step, 2), "unit": "us", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(us_step * 1e-3, 5), "higher_is_better": False,
-            "scaling": "strong" if world > 1 else "weak",
+            "scaling": "strong",   # one decode step of the same problem: total work is fixed as N grows
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": "Palu low-rank KV attention decode step (kernel/palu_attention.py decode branch): "
                                    "H=32 D=128 hidden=4096 gs=4 G=8 rank_k=%d rank_v=%d prompt_len=%d fp16 latents batch=1"

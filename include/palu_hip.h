@@ -85,6 +85,10 @@ int palu_abx_rope_f16(const void* a, int64_t sa_h, int64_t sa_d,
  */
 int palu_pv_nsplit(int G, int L);
 size_t palu_pv_workspace_bytes(int H, int G, int L, int Rv);
+/* Byte offset, inside the workspace, of the per-head softmax statistics the call leaves behind:
+ * float stats[H][2] = (max_l x[h,l], sum_l exp(x[h,l] - max)).  With ctx they are what a split-L
+ * (multi-GPU or chunked) caller needs to LSE-merge partial results. */
+size_t palu_pv_stats_offset(int H, int G, int L, int Rv);
 int palu_softmax_pv_f16(const void* scores, int64_t ss_h, const void* mask,
                         const void* v, int64_t sv_g, int64_t sv_l,
                         void* ctx, void* probs, int64_t sp_h, void* workspace,

@@ -489,6 +489,11 @@ extern "C" size_t palu_pv_workspace_bytes(int H, int G, int L, int Rv) {
   return ((size_t)H * ns * (Rv + 2) + (size_t)H * 2) * sizeof(float);
 }
 
+extern "C" size_t palu_pv_stats_offset(int H, int G, int L, int Rv) {
+  int ns = palu_pv_nsplit(G, L);
+  return (size_t)H * ns * (Rv + 2) * sizeof(float);
+}
+
 extern "C" int palu_softmax_pv_f16(const void* scores, int64_t ss_h, const void* mask, const void* v, int64_t sv_g,
                                    int64_t sv_l, void* ctx, void* probs, int64_t sp_h, void* workspace, int H, int G,
                                    int L, int Rv, float sqrt_d, palu_stream_t stream) {

@@ -149,3 +149,106 @@ class HeadParallelDecoder:
         lib.check(lib.lib.palu_gemv_f16(wo.data_ptr(), wo.stride(0), full.data_ptr(), self.out.data_ptr(),
                                         self.hidden, p.num_heads * p.rank_v, lib.current_stream()), "o_proj")
         return self.out
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Split-L: fewer head groups than GPUs ("when groups < GPUs"; 8(f) N3).  Every rank holds all
+# weights and a contiguous range of cache rows of EVERY group; a step exchanges, per head, the locally normalised
+# context and the softmax statistics (max, sum) and LSE-merges them -- the same merge the single-GPU kernel does
+# across its own splits (pv_combine), lifted to the process group.
+def split_ranges(L: int, world: int, align: int = 128):
+    """Contiguous [l0, l1) row ranges, `align`-row granularity (the abx tile), last rank takes the tail (and the
+    rows appended while decoding)."""
+    per = -(-L // world)
+    per = -(-per // align) * align
+    return [(min(r * per, L), min((r + 1) * per, L)) for r in range(world)]
+
+
+def merge_partials(ctx: torch.Tensor, m: torch.Tensor, s: torch.Tensor) -> torch.Tensor:
+    """ctx [N, H, Rv] locally normalised contexts, m / s [N, H] local max / sum of exp(x - max) -> [H, Rv] fp32:
+    softmax over the union = sum_r w_r ctx_r / sum_r w_r with w_r = s_r * exp(m_r - max_r m_r); ranks without rows
+    carry m = -inf, s = 0."""
+    M = m.max(dim=0, keepdim=True).values
+    w = s.float() * torch.exp(m.float() - M.float())
+    w = torch.where(torch.isfinite(m), w, torch.zeros_like(w))
+    return (w.unsqueeze(-1) * ctx.float()).sum(0) / w.sum(0).unsqueeze(-1)
+
+
+def gather_and_merge(ctx_local: torch.Tensor, stats_local: torch.Tensor, world: int, group=None) -> torch.Tensor:
+    """ONE all-gather of [H*Rv + 2H] fp32 per rank (context + (max, sum) per head), then the LSE merge."""
+    import torch.distributed as dist
+    H = stats_local.shape[0]
+    pack = torch.cat((ctx_local.reshape(-1).float(), stats_local.reshape(-1).float()))
+    if world == 1:
+        allp = pack.unsqueeze(0)
+    else:
+        flat = torch.empty(world * pack.numel(), dtype=torch.float32, device=pack.device)
+        dist.all_gather_into_tensor(flat, pack, group=group)
+        allp = flat.view(world, pack.numel())
+    n_ctx = ctx_local.numel()
+    ctx = allp[:, :n_ctx].reshape(world, H, -1)
+    st = allp[:, n_ctx:].reshape(world, H, 2)
+    return merge_partials(ctx, st[..., 0], st[..., 1])
+
+
+class SplitLDecoder:
+    """Per-rank HIP step of the split-L decode: replicated weights {wq, vt_k, vt_v, b, wo}, this rank's rows
+    [l0, l1) of every group in `k_cache` / `v_cache` ([G, cap, R], `rows` valid).  The rank that `owns_tail`
+    appends the new token's latent row; the others compute it too (the projection is fused with q) but park it in
+    the spare row behind their range."""
+
+    def __init__(self, world: int, rank: int, num_heads: int, num_groups: int, head_dim: int, weights, k_cache,
+                 v_cache, rows: int, row0: int, owns_tail: bool, hidden_size: int, theta: float = 10000.0, group=None):
+        from .. import _lib
+        from .abx_rope import prepare_b, rope_inv_freq
+        self._lib = _lib
+        self.world, self.rank, self.H, self.G, self.D = world, rank, num_heads, num_groups, head_dim
+        self.w, self.k, self.v, self.rows, self.row0, self.owns_tail = weights, k_cache, v_cache, rows, row0, owns_tail
+        self.hidden, self.group = hidden_size, group
+        dev = k_cache.device
+        self.Rk, self.Rv = k_cache.shape[2], v_cache.shape[2]
+        cap = k_cache.shape[1]
+        self.frag = prepare_b(weights["b"], num_groups)
+        self.inv = rope_inv_freq(dev, head_dim, theta)
+        self.q = torch.empty(num_heads * head_dim, dtype=torch.float16, device=dev)
+        self.scores = torch.empty((num_heads, (cap + 8) // 8 * 8), dtype=torch.float16, device=dev)
+        self.ctx = torch.zeros((num_heads, self.Rv), dtype=torch.float16, device=dev)
+        self.ws_bytes = _lib.lib.palu_pv_workspace_bytes(num_heads, num_groups, cap, self.Rv)
+        self.pvws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        self.out = torch.empty(hidden_size, dtype=torch.float16, device=dev)
+        self.empty_stats = torch.tensor([[float("-inf"), 0.0]] * num_heads, dtype=torch.float32, device=dev)
+
+    def local_step(self, hidden: torch.Tensor, pos: int):
+        """-> (ctx [H, Rv] fp16 normalised over the local rows, stats [H, 2] fp32 = (max, sum))."""
+        import math
+        lib, w = self._lib, self.w
+        s = lib.current_stream()
+        H, G, D = self.H, self.G, self.D
+        lib.check(lib.lib.palu_decode_qkv_f16(
+            w["wq"].data_ptr(), w["wq"].stride(0), w["vt_k"].data_ptr(), w["vt_k"].stride(0),
+            w["vt_v"].data_ptr(), w["vt_v"].stride(0), hidden.data_ptr(), self.q.data_ptr(),
+            self.k.data_ptr(), self.k.stride(0), self.k.stride(1), self.v.data_ptr(), self.v.stride(0), self.v.stride(1),
+            self.inv.data_ptr(), H, D, self.hidden, G, self.Rk, self.Rv, pos, self.rows, s), "decode_qkv")
+        L = self.rows + (1 if self.owns_tail else 0)
+        if L == 0:
+            return self.ctx, self.empty_stats
+        lib.check(lib.lib.palu_abx_rope_f16(self.q.data_ptr(), D, 1, self.frag.data_ptr(), self.k.data_ptr(),
+                                            self.k.stride(0), self.k.stride(1), self.scores.data_ptr(),
+                                            self.scores.stride(0), H, G, L, self.Rk, D, self.inv.data_ptr(), self.row0, s), "abx")
+        lib.check(lib.lib.palu_softmax_pv_f16(self.scores.data_ptr(), self.scores.stride(0), 0, self.v.data_ptr(),
+                                              self.v.stride(0), self.v.stride(1), self.ctx.data_ptr(), 0, 0,
+                                              self.pvws.data_ptr(), H, G, L, self.Rv, math.sqrt(D), s), "softmax_pv")
+        off = lib.lib.palu_pv_stats_offset(H, G, L, self.Rv)
+        stats = self.pvws[off:off + H * 8].view(torch.float32).view(H, 2)
+        if self.owns_tail:
+            self.rows += 1
+        return self.ctx, stats
+
+    def step(self, hidden: torch.Tensor, pos: int) -> torch.Tensor:
+        lib = self._lib
+        ctx, stats = self.local_step(hidden, pos)
+        full = gather_and_merge(ctx, stats, self.world, self.group).to(torch.float16).reshape(-1).contiguous()
+        wo = self.w["wo"]
+        lib.check(lib.lib.palu_gemv_f16(wo.data_ptr(), wo.stride(0), full.data_ptr(), self.out.data_ptr(),
+                                        self.hidden, self.H * self.Rv, lib.current_stream()), "o_proj")
+        return self.out

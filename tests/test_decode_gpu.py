@@ -300,3 +300,35 @@ def test_lowrank_project_gemm(M, N, K, R):
     assert cache[:, :row0].abs().max() == 0 and cache[:, row0 + M:].abs().max() == 0      # nothing else touched
     t16 = torch.nn.functional.linear(x, w).reshape(M, G, R).transpose(0, 1)
     torch.testing.assert_close(cache[:, row0:row0 + M], t16, rtol=2e-3, atol=2e-3)
+
+
+def test_split_l_decoders_merge_to_full_step():
+    """Split-L (fewer groups than GPUs): two SplitLDecoder instances stand in for two ranks on one GPU; their
+    (context, max, sum) partials LSE-merge to the oracle's full decode step.  Exercises abx at pos0 != 0 and the
+    statistics the P.V kernel leaves in its workspace."""
+    from palu_amd.kernel import head_parallel as hp
+    tag, seed, hidden, H, D, gs, rank_k, rank_v, L, _ = gi.STEP_CASES[0]
+    G = H // gs
+    L = 700
+    w, k_lat, v_lat, tok, _ = gi.step_inputs(seed, hidden, H, D, gs, rank_k, rank_v, L, False)
+    full = {"wq": w["wq"].half(), "vt_k": w["vt_k"].half(), "vt_v": w["vt_v"].half(),
+            "b": oracle.build_b_from_u(w["u_k"], gs, D).half(), "wo": w["wo"].half()}
+    ref, _, _, _ = oracle.decode_step(tok, L, full, k_lat, v_lat)
+    wd = {k: v.to(DEV).contiguous() for k, v in full.items()}
+    ranges = hp.split_ranges(L, 2)
+    parts = []
+    for r, (l0, l1) in enumerate(ranges):
+        cap = (l1 - l0) + 64
+        kc = torch.zeros(G, cap, rank_k // G, dtype=torch.float16, device=DEV)
+        vc = torch.zeros(G, cap, rank_v // G, dtype=torch.float16, device=DEV)
+        kc[:, :l1 - l0] = k_lat[:, l0:l1].to(DEV)
+        vc[:, :l1 - l0] = v_lat[:, l0:l1].to(DEV)
+        dec = hp.SplitLDecoder(2, r, H, G, D, wd, kc, vc, l1 - l0, l0, r == 1, hidden)
+        ctx, stats = dec.local_step(tok.to(DEV), L)
+        parts.append((ctx.clone(), stats.clone()))
+    torch.cuda.synchronize()
+    ctx = torch.stack([p[0] for p in parts])
+    st = torch.stack([p[1] for p in parts])
+    merged = hp.merge_partials(ctx, st[..., 0], st[..., 1]).half()
+    out = torch.nn.functional.linear(merged.reshape(1, -1).cpu(), full["wo"]).reshape(-1)
+    torch.testing.assert_close(out, ref, rtol=2e-3, atol=1e-3)

@@ -95,3 +95,77 @@ def test_plan_validation_and_layout():
     full = torch.arange(H * Rv).reshape(H, Rv)
     parts = [full[hp.make_plan(4, r, H, 4, 128, 32, Rv).head0:][:2].reshape(-1) for r in range(4)]
     assert torch.equal(torch.cat(parts), full.reshape(-1))
+
+
+# ---------------------------------------------------------------------------------------- split-L (G < N)
+def _oracle_split_partial(full, k_all, v_all, q_rot, l0, l1, G, gs):
+    """oracle math for one rank's row range: locally normalised context + (max, sum) per head"""
+    import math
+    H = G * gs
+    D = q_rot.shape[-1]
+    s = (oracle.abx_scores(q_rot, full["b"], k_all) / math.sqrt(D)).reshape(H, -1)[:, l0:l1].float()
+    if l1 == l0:
+        return torch.zeros(H, v_all.shape[-1]), torch.full((H,), float("-inf")), torch.zeros(H)
+    m = s.max(dim=1).values
+    e = torch.exp(s - m.unsqueeze(1))
+    ssum = e.sum(1)
+    p = (e / ssum.unsqueeze(1)).half()
+    ctx = torch.matmul(p.reshape(G, gs, -1), v_all[:, l0:l1]).reshape(H, -1)
+    return ctx, m, ssum
+
+
+def _worker_split(rank, world, port, case, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    tag, seed, hidden, H, D, gs, rank_k, rank_v, L, _ = case
+    G = H // gs
+    w, k_lat, v_lat, tok, _ = gi.step_inputs(seed, hidden, H, D, gs, rank_k, rank_v, L, False)
+    full = {"wq": w["wq"].half(), "vt_k": w["vt_k"].half(), "vt_v": w["vt_v"].half(),
+            "b": oracle.build_b_from_u(w["u_k"], gs, D).half(), "wo": w["wo"].half()}
+    ref, _, k_all, v_all = oracle.decode_step(tok, L, full, k_lat, v_lat)
+    ranges = hp.split_ranges(L, world, align=32)
+    l0, l1 = ranges[rank]
+    if rank == world - 1:
+        l1 = L + 1                                                  # the owner of the tail sees the new row
+    h2 = tok.reshape(1, -1)
+    q = torch.nn.functional.linear(h2, full["wq"]).reshape(H, 1, D)
+    cos, sin = oracle.rope_cos_sin(L + 1, D, start=L)
+    q = q * cos.half() + torch.cat((-q[..., D // 2:], q[..., :D // 2]), dim=-1) * sin.half()
+    ctx, m, ssum = _oracle_split_partial(full, k_all, v_all, q, l0, l1, G, gs)
+    merged = hp.gather_and_merge(ctx.half(), torch.stack((m, ssum), dim=1), world)      # the one collective
+    out = torch.nn.functional.linear(merged.half().reshape(1, -1), full["wo"]).reshape(-1)
+    torch.testing.assert_close(out, ref, rtol=2e-3, atol=1e-3)
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+
+
+@pytest.mark.parametrize("case", [gi.STEP_CASES[0]], ids=["small_gs2"])
+def test_split_l_world2(tmp_path, case):
+    world = 2
+    port = _free_port()
+    mp.spawn(_worker_split, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
+
+
+def test_split_ranges_and_merge():
+    assert hp.split_ranges(65536, 8) == [(i * 8192, (i + 1) * 8192) for i in range(8)]
+    assert hp.split_ranges(300, 2) == [(0, 256), (256, 300)]
+    assert hp.split_ranges(100, 4) == [(0, 100), (100, 100), (100, 100), (100, 100)]
+    # merge of per-range softmax pieces == softmax over the union (incl. an empty range)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 50, generator=g) * 5
+    v = torch.randn(50, 7, generator=g)
+    ref = torch.softmax(x, dim=-1) @ v
+    ctx, m, s = [], [], []
+    for a, b in ((0, 20), (20, 20), (20, 50)):
+        if a == b:
+            ctx.append(torch.zeros(3, 7)); m.append(torch.full((3,), float("-inf"))); s.append(torch.zeros(3))
+            continue
+        mm = x[:, a:b].max(1).values
+        e = torch.exp(x[:, a:b] - mm.unsqueeze(1))
+        ctx.append((e / e.sum(1, keepdim=True)) @ v[a:b]); m.append(mm); s.append(e.sum(1))
+    out = hp.merge_partials(torch.stack(ctx), torch.stack(m), torch.stack(s))
+    torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
