@@ -77,11 +77,7 @@ __global__ __launch_bounds__(PV_THREADS) void pv_partial_kernel(PvParams p) {
   auto load_batch = [&](u32x4 (&raw)[U], int i) {
 #pragma unroll
     for (int u = 0; u < U; ++u)
-#ifdef PALU_PV_PLAIN_LOADS
-      raw[u] = *reinterpret_cast<const u32x4*>(vb + (int64_t)min(i + u * rpp, nlast) * p.sv_l);
-#else
       raw[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (int64_t)min(i + u * rpp, nlast) * p.sv_l));
-#endif
   };
   u32x4 rawA[U], rawB[U];
   if (streamer) load_batch(rawA, rg);   // in flight while the softmax statistics are computed
