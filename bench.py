@@ -165,24 +165,28 @@ def main():
             lib, s = _lib.lib, _lib.current_stream
             Hl = H
             inv = dec.inv
+            # scratch of the per-kernel loops (the step itself runs through palu_decode_attend_f16's own workspace)
+            q_buf = torch.empty(H * D, dtype=torch.float16, device=dev)
+            sc_buf = torch.empty((H, (cap + 8) // 8 * 8), dtype=torch.float16, device=dev)
+            pv_buf = torch.empty(lib.palu_pv_workspace_bytes(H, G, cap, Rv), dtype=torch.uint8, device=dev)
 
             def k_qkv():
                 _lib.check(lib.palu_decode_qkv_f16(w["wq"].data_ptr(), w["wq"].stride(0), w["vt_k"].data_ptr(),
                                                    w["vt_k"].stride(0), w["vt_v"].data_ptr(), w["vt_v"].stride(0),
-                                                   hidden.data_ptr(), dec.q.data_ptr(), k_cache.data_ptr(),
+                                                   hidden.data_ptr(), q_buf.data_ptr(), k_cache.data_ptr(),
                                                    k_cache.stride(0), k_cache.stride(1), v_cache.data_ptr(),
                                                    v_cache.stride(0), v_cache.stride(1), inv.data_ptr(), Hl, D, HIDDEN,
                                                    G, Rk, Rv, Lp, Lp, s()), "qkv")
 
             def k_abx():
-                _lib.check(lib.palu_abx_rope_f16(dec.q.data_ptr(), D, 1, dec.frag.data_ptr(), k_cache.data_ptr(),
-                                                 k_cache.stride(0), k_cache.stride(1), dec.scores.data_ptr(),
-                                                 dec.scores.stride(0), Hl, G, L, Rk, D, inv.data_ptr(), 0, s()), "abx")
+                _lib.check(lib.palu_abx_rope_f16(q_buf.data_ptr(), D, 1, dec.frag.data_ptr(), k_cache.data_ptr(),
+                                                 k_cache.stride(0), k_cache.stride(1), sc_buf.data_ptr(),
+                                                 sc_buf.stride(0), Hl, G, L, Rk, D, inv.data_ptr(), 0, s()), "abx")
 
             def k_pv():
-                _lib.check(lib.palu_softmax_pv_f16(dec.scores.data_ptr(), dec.scores.stride(0), 0, v_cache.data_ptr(),
+                _lib.check(lib.palu_softmax_pv_f16(sc_buf.data_ptr(), sc_buf.stride(0), 0, v_cache.data_ptr(),
                                                    v_cache.stride(0), v_cache.stride(1), dec.ctx.data_ptr(), 0, 0,
-                                                   dec.pvws.data_ptr(), Hl, G, L, Rv, math.sqrt(D), s()), "pv")
+                                                   pv_buf.data_ptr(), Hl, G, L, Rv, math.sqrt(D), s()), "pv")
 
             def k_o():
                 _lib.check(lib.palu_gemv_f16(w["wo"].data_ptr(), w["wo"].stride(0), dec.ctx.data_ptr(),

@@ -126,6 +126,17 @@ int palu_decode_step_f16(const void* hidden,
                          const void* mask, const float* inv_freq, void* out, void* probs, int64_t sp_h,
                          void* workspace, int Lcap, int H, int G, int D, int hidden_size, int Rk, int Rv,
                          int cache_len, int pos, palu_stream_t stream);
+/* The same step WITHOUT the final o_proj: what one rank of the head-group sharding runs on the heads it owns
+ * (H, G = local counts); ctx [H, Rv] fp16 is the slice it contributes to the all-gather.
+ * Workspace as palu_decode_step_f16. */
+int palu_decode_attend_f16(const void* hidden,
+                           const void* wq, int64_t ldq, const void* vtk, int64_t ldk, const void* vtv, int64_t ldv,
+                           const void* bfrag,
+                           void* k_cache, int64_t sk_g, int64_t sk_l, void* v_cache, int64_t sv_g, int64_t sv_l,
+                           const void* mask, const float* inv_freq, void* ctx,
+                           void* workspace, int Lcap, int H, int G, int D, int hidden_size, int Rk, int Rv,
+                           int cache_len, int pos, palu_stream_t stream);
+
 
 /* ------------------------------------------------------------------------------------------
  * 3/4-bit latent quantisation (palu/model/modules/quant.py:5-41, reference defaults: asymmetric,

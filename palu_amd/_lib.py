@@ -64,6 +64,8 @@ SIGNATURES = {
     "palu_unpack_codes": (i32, [vp, vp, i64, i32, vp]),
     "palu_hadamard_transform": (i32, [vp, vp, i64, i32, f32, i32, vp]),
     "palu_decode_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
+    "palu_decode_attend_f16": (i32, [vp, vp, i64, vp, i64, vp, i64, vp, vp, i64, i64, vp, i64, i64, vp, vp, vp, vp,
+                                     i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "palu_decode_step_f16": (i32, [vp, vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64, i64, vp, i64, i64,
                                    vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
 }

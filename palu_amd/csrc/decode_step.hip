@@ -54,6 +54,31 @@ extern "C" int palu_decode_step_f16(const void* hidden, const void* wq, int64_t 
   return palu_gemv_f16(wo, ldo, ctx, out, hidden_size, H * Rv, stream);
 }
 
+// The step without its last GEMV: everything that is local to a head-group shard; the caller
+// all-gathers `ctx` ([H, Rv] fp16 for the H heads it owns) and runs o_proj on the gathered vector.
+extern "C" int palu_decode_attend_f16(const void* hidden, const void* wq, int64_t ldq, const void* vtk, int64_t ldk,
+                                      const void* vtv, int64_t ldv, const void* bfrag, void* k_cache, int64_t sk_g,
+                                      int64_t sk_l, void* v_cache, int64_t sv_g, int64_t sv_l, const void* mask,
+                                      const float* inv_freq, void* ctx, void* workspace, int Lcap, int H, int G, int D,
+                                      int hidden_size, int Rk, int Rv, int cache_len, int pos, palu_stream_t stream) {
+  PALU_REQUIRE(workspace && ctx && Lcap > cache_len && cache_len >= 0, PALU_ERR_ARG,
+               "decode_attend: cache_len %d must be < workspace capacity %d", cache_len, Lcap);
+  const StepWs w = step_layout(H, G, D, Lcap, Rv);
+  char* ws = (char*)workspace;
+  void* q = ws + w.q;
+  void* scores = ws + w.scores;
+  void* pvws = ws + w.pv;
+  const int L = cache_len + 1;
+  const int64_t ss_h = ((int64_t)Lcap + 8) & ~(int64_t)7;
+  int rc = palu_decode_qkv_f16(wq, ldq, vtk, ldk, vtv, ldv, hidden, q, k_cache, sk_g, sk_l, v_cache, sv_g, sv_l,
+                               inv_freq, H, D, hidden_size, G, Rk, Rv, pos, cache_len, stream);
+  if (rc) return rc;
+  rc = palu_abx_rope_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, scores, ss_h, H, G, L, Rk, D, inv_freq, 0, stream);
+  if (rc) return rc;
+  return palu_softmax_pv_f16(scores, ss_h, mask, v_cache, sv_g, sv_l, ctx, nullptr, 0, pvws, H, G, L, Rv,
+                             sqrtf((float)D), stream);
+}
+
 // Same step on a QUANTISED latent cache (3/4-bit codes + per-row (scale, zero); quant.hip layout):
 // qkv GEMV -> quantise+pack the two new latent rows into row `cache_len` -> abx with in-register
 // dequantisation -> softmax.PV on the codes -> o_proj.  6 launches.

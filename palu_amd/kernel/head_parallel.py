@@ -109,31 +109,23 @@ class HeadParallelDecoder:
         self.frag = prepare_b(weights["b"], plan.groups_local)
         self.inv = rope_inv_freq(dev, plan.head_dim, theta)
         Hl, Gl, cap = plan.heads_local, plan.groups_local, k_cache.shape[1]
-        self.q = torch.empty(Hl * plan.head_dim, dtype=torch.float16, device=dev)
-        self.scores = torch.empty((Hl, (cap + 8) // 8 * 8), dtype=torch.float16, device=dev)
+        self.cap = cap
         self.ctx = torch.empty(Hl * plan.rank_v, dtype=torch.float16, device=dev)
         self.ctx_full = torch.empty(plan.num_heads * plan.rank_v, dtype=torch.float16, device=dev)
-        self.pvws = torch.empty(_lib.lib.palu_pv_workspace_bytes(Hl, Gl, cap, plan.rank_v), dtype=torch.uint8, device=dev)
+        self.ws = torch.empty(_lib.lib.palu_decode_workspace_bytes(Hl, Gl, plan.head_dim, cap, plan.rank_v),
+                              dtype=torch.uint8, device=dev)
         self.out = torch.empty(hidden_size, dtype=torch.float16, device=dev)
 
     def local_step(self, hidden: torch.Tensor, cache_len: int, pos: int):
-        """qkv + RoPE + append -> abx -> softmax.PV for this rank's groups; returns the context slice."""
-        import math
+        """qkv + RoPE + append -> abx -> softmax.PV for this rank's groups in ONE native call (three launches, no
+        host work in between); returns the context slice."""
         lib, p, w = self._lib, self.plan, self.w
-        s = lib.current_stream()
-        Hl, Gl, D = p.heads_local, p.groups_local, p.head_dim
-        L = cache_len + 1
-        lib.check(lib.lib.palu_decode_qkv_f16(
-            w["wq"].data_ptr(), w["wq"].stride(0), w["vt_k"].data_ptr(), w["vt_k"].stride(0),
-            w["vt_v"].data_ptr(), w["vt_v"].stride(0), hidden.data_ptr(), self.q.data_ptr(),
+        lib.check(lib.lib.palu_decode_attend_f16(
+            hidden.data_ptr(), w["wq"].data_ptr(), w["wq"].stride(0), w["vt_k"].data_ptr(), w["vt_k"].stride(0),
+            w["vt_v"].data_ptr(), w["vt_v"].stride(0), self.frag.data_ptr(),
             self.k.data_ptr(), self.k.stride(0), self.k.stride(1), self.v.data_ptr(), self.v.stride(0), self.v.stride(1),
-            self.inv.data_ptr(), Hl, D, self.hidden, Gl, p.rank_k, p.rank_v, pos, cache_len, s), "decode_qkv")
-        lib.check(lib.lib.palu_abx_rope_f16(self.q.data_ptr(), D, 1, self.frag.data_ptr(), self.k.data_ptr(),
-                                            self.k.stride(0), self.k.stride(1), self.scores.data_ptr(),
-                                            self.scores.stride(0), Hl, Gl, L, p.rank_k, D, self.inv.data_ptr(), 0, s), "abx")
-        lib.check(lib.lib.palu_softmax_pv_f16(self.scores.data_ptr(), self.scores.stride(0), 0, self.v.data_ptr(),
-                                              self.v.stride(0), self.v.stride(1), self.ctx.data_ptr(), 0, 0,
-                                              self.pvws.data_ptr(), Hl, Gl, L, p.rank_v, math.sqrt(D), s), "softmax_pv")
+            0, self.inv.data_ptr(), self.ctx.data_ptr(), self.ws.data_ptr(), self.cap, p.heads_local, p.groups_local,
+            p.head_dim, self.hidden, p.rank_k, p.rank_v, cache_len, pos, lib.current_stream()), "decode_attend")
         return self.ctx
 
     def step(self, hidden: torch.Tensor, cache_len: int, pos: int) -> torch.Tensor:
