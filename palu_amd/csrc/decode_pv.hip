@@ -51,6 +51,22 @@ static __device__ __forceinline__ float block_sum(float v, float* sh, int tid) {
   return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// the same for GS values at once: one pair of barriers for all heads of the group
+template <int GS, bool MAX>
+static __device__ __forceinline__ void block_reduce(float (&v)[GS], float (*sh)[4], int tid) {
+#pragma unroll
+  for (int h = 0; h < GS; ++h) v[h] = MAX ? wave_max(v[h]) : wave_sum(v[h]);
+  __syncthreads();
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int h = 0; h < GS; ++h) sh[h][tid >> 6] = v[h];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int h = 0; h < GS; ++h)
+    v[h] = MAX ? fmaxf(fmaxf(sh[h][0], sh[h][1]), fmaxf(sh[h][2], sh[h][3])) : (sh[h][0] + sh[h][1]) + (sh[h][2] + sh[h][3]);
+}
+
 template <int GS>
 __global__ __launch_bounds__(PV_THREADS) void pv_partial_kernel(PvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -83,28 +99,32 @@ __global__ __launch_bounds__(PV_THREADS) void pv_partial_kernel(PvParams p) {
   if (streamer) load_batch(rawA, rg);   // in flight while the softmax statistics are computed
 
   // ---- phase A: logits, local max, probabilities, local sum (per head of the group)
+  // all heads of the group in one sweep: one block reduction (two barriers) for the maxima, one for the sums
+  __shared__ float shg[GS][4];
   float mloc[GS], sloc[GS];
 #pragma unroll
-  for (int h = 0; h < GS; ++h) {
-    const h16* sc = p.scores + (int64_t)(g * GS + h) * p.ss_h + l0;
-    float mx = -INFINITY;
-    for (int i = tid; i < n; i += PV_THREADS) {
-      float x = scaled_logit(sc[i], p.inv_scale, p.mask, l0 + i);
+  for (int h = 0; h < GS; ++h) mloc[h] = -INFINITY;
+  for (int i = tid; i < n; i += PV_THREADS) {
+#pragma unroll
+    for (int h = 0; h < GS; ++h) {
+      const float x = scaled_logit(p.scores[(int64_t)(g * GS + h) * p.ss_h + l0 + i], p.inv_scale, p.mask, l0 + i);
       pl[h * p.rps + i] = x;
-      mx = fmaxf(mx, x);
+      mloc[h] = fmaxf(mloc[h], x);
     }
-    mx = block_max(mx, sh, tid);
-    float sm = 0.f;
-    for (int i = tid; i < n; i += PV_THREADS) {
-      float e = (mx == -INFINITY) ? 0.f : __expf(pl[h * p.rps + i] - mx);
-      pl[h * p.rps + i] = e;
-      sm += e;
-    }
-    for (int i = n + tid; i < p.rps; i += PV_THREADS) pl[h * p.rps + i] = 0.f;   // weights of clamped rows
-    sm = block_sum(sm, sh, tid);
-    mloc[h] = mx;
-    sloc[h] = sm;
   }
+  block_reduce<GS, true>(mloc, shg, tid);
+#pragma unroll
+  for (int h = 0; h < GS; ++h) sloc[h] = 0.f;
+  for (int i = tid; i < p.rps; i += PV_THREADS) {
+#pragma unroll
+    for (int h = 0; h < GS; ++h) {
+      float e = 0.f;                                   // rows past the range (clamped re-reads) weigh nothing
+      if (i < n) e = (mloc[h] == -INFINITY) ? 0.f : __expf(pl[h * p.rps + i] - mloc[h]);
+      pl[h * p.rps + i] = e;
+      sloc[h] += e;
+    }
+  }
+  block_reduce<GS, false>(sloc, shg, tid);
   if (tid == 0) {
 #pragma unroll
     for (int h = 0; h < GS; ++h) {
@@ -240,36 +260,43 @@ __global__ __launch_bounds__(PV_THREADS) void pv_partial_q_kernel(PvQParams p) {
   QRow<BITS> rawA[2 * NP], rawB[2 * NP];
   if (streamer) load_batch(rawA, rg);
 
-  // ---- phase A: per head  x -> max -> e^(x-m) -> sum;  w = fp16(e * scale_row) -> LDS;  corr = sum w (1024 + zero_row)
+  // ---- phase A (all heads per sweep):  x -> max -> e^(x-m) -> sum;  w = fp16(e * scale_row) -> LDS;
+  //      corr = sum w (1024 + zero_row)
+  __shared__ float shg[GS][4];
   float mloc[GS], sloc[GS], corr[GS];
 #pragma unroll
-  for (int h = 0; h < GS; ++h) {
-    const h16* sc = p.scores + (int64_t)(g * GS + h) * p.ss_h + l0;
-    float mx = -INFINITY;
-    for (int i = tid; i < n; i += PV_THREADS) {
-      float x = scaled_logit(sc[i], p.inv_scale, p.mask, l0 + i);
+  for (int h = 0; h < GS; ++h) mloc[h] = -INFINITY;
+  for (int i = tid; i < n; i += PV_THREADS) {
+#pragma unroll
+    for (int h = 0; h < GS; ++h) {
+      const float x = scaled_logit(p.scores[(int64_t)(g * GS + h) * p.ss_h + l0 + i], p.inv_scale, p.mask, l0 + i);
       pl[h * p.rps + i] = x;
-      mx = fmaxf(mx, x);
+      mloc[h] = fmaxf(mloc[h], x);
     }
-    mx = block_max(mx, sh, tid);
-    float sm = 0.f, cr = 0.f;
-    for (int i = tid; i < p.rps; i += PV_THREADS) {
+  }
+  block_reduce<GS, true>(mloc, shg, tid);
+#pragma unroll
+  for (int h = 0; h < GS; ++h) {
+    sloc[h] = 0.f;
+    corr[h] = 0.f;
+  }
+  for (int i = tid; i < p.rps; i += PV_THREADS) {
+    h16x2 m2 = {(h16)0.f, (h16)0.f};
+    if (i < n) m2 = __builtin_bit_cast(h16x2, *reinterpret_cast<const unsigned*>(mb + (int64_t)i * p.sm_l));
+#pragma unroll
+    for (int h = 0; h < GS; ++h) {
       h16 wq = (h16)0.f;
       if (i < n) {
-        const float e = (mx == -INFINITY) ? 0.f : __expf(pl[h * p.rps + i] - mx);
-        sm += e;
-        const h16x2 m2 = __builtin_bit_cast(h16x2, *reinterpret_cast<const unsigned*>(mb + (int64_t)i * p.sm_l));
+        const float e = (mloc[h] == -INFINITY) ? 0.f : __expf(pl[h * p.rps + i] - mloc[h]);
+        sloc[h] += e;
         wq = (h16)(e * (float)m2[0]);
-        cr = fmaf((float)wq, 1024.f + (float)m2[1], cr);
+        corr[h] = fmaf((float)wq, 1024.f + (float)m2[1], corr[h]);
       }
       wl[h * p.rps + i] = wq;
     }
-    sm = block_sum(sm, sh, tid);
-    cr = block_sum(cr, sh, tid);
-    mloc[h] = mx;
-    sloc[h] = sm;
-    corr[h] = cr;
   }
+  block_reduce<GS, false>(sloc, shg, tid);
+  block_reduce<GS, false>(corr, shg, tid);
   if (tid == 0) {
 #pragma unroll
     for (int h = 0; h < GS; ++h) {
