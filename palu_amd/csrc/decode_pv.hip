@@ -51,6 +51,41 @@ static __device__ __forceinline__ float block_sum(float v, float* sh, int tid) {
   return (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// Sweep 1 of the softmax statistics for all GS heads of a group: the raw scores (and mask values) of up to PA_UN rows
+// per thread are requested together, so a range costs ceil(rows / (PA_UN * threads)) memory latencies instead of one
+// per row.  Writes the scaled logits to pl[h][i] and returns the running maxima.
+constexpr int PA_UN = 4;
+template <int GS>
+static __device__ __forceinline__ void logits_sweep(const h16* scores, int64_t ss_h, const h16* mask, int g, int l0, int n,
+                                                    int rps, float inv_scale, float* pl, float (&mloc)[GS], int tid) {
+  const int nlast = max(n - 1, 0);
+  for (int k0 = 0; k0 * PV_THREADS < n; k0 += PA_UN) {
+    h16 sc[PA_UN][GS], mk[PA_UN];
+#pragma unroll
+    for (int u = 0; u < PA_UN; ++u) {
+      const int ic = min(tid + (k0 + u) * PV_THREADS, nlast);
+#pragma unroll
+      for (int h = 0; h < GS; ++h) sc[u][h] = scores[(int64_t)(g * GS + h) * ss_h + l0 + ic];
+      mk[u] = mask ? mask[l0 + ic] : (h16)0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < PA_UN; ++u) {
+      const int i = tid + (k0 + u) * PV_THREADS;
+      if (i < n) {
+#pragma unroll
+        for (int h = 0; h < GS; ++h) {
+          // fp16 tensor / python float -> fp32 divide, rounded to fp16 (torch semantics); then + mask in fp16
+          h16 x16 = (h16)((float)sc[u][h] / inv_scale);
+          if (mask) x16 = (h16)((float)x16 + (float)mk[u]);
+          const float x = (float)x16;
+          pl[h * rps + i] = x;
+          mloc[h] = fmaxf(mloc[h], x);
+        }
+      }
+    }
+  }
+}
+
 // the same for GS values at once: one pair of barriers for all heads of the group
 template <int GS, bool MAX>
 static __device__ __forceinline__ void block_reduce(float (&v)[GS], float (*sh)[4], int tid) {
@@ -104,14 +139,7 @@ __global__ __launch_bounds__(PV_THREADS) void pv_partial_kernel(PvParams p) {
   float mloc[GS], sloc[GS];
 #pragma unroll
   for (int h = 0; h < GS; ++h) mloc[h] = -INFINITY;
-  for (int i = tid; i < n; i += PV_THREADS) {
-#pragma unroll
-    for (int h = 0; h < GS; ++h) {
-      const float x = scaled_logit(p.scores[(int64_t)(g * GS + h) * p.ss_h + l0 + i], p.inv_scale, p.mask, l0 + i);
-      pl[h * p.rps + i] = x;
-      mloc[h] = fmaxf(mloc[h], x);
-    }
-  }
+  logits_sweep<GS>(p.scores, p.ss_h, p.mask, g, l0, n, p.rps, p.inv_scale, pl, mloc, tid);
   block_reduce<GS, true>(mloc, shg, tid);
 #pragma unroll
   for (int h = 0; h < GS; ++h) sloc[h] = 0.f;
@@ -266,23 +294,24 @@ __global__ __launch_bounds__(PV_THREADS) void pv_partial_q_kernel(PvQParams p) {
   float mloc[GS], sloc[GS], corr[GS];
 #pragma unroll
   for (int h = 0; h < GS; ++h) mloc[h] = -INFINITY;
-  for (int i = tid; i < n; i += PV_THREADS) {
+  // the (scale, zero) pairs of this thread's rows are requested before the score sweep (rps <= 2048: 8 rows at most)
+  constexpr int MAXR = 2048 / PV_THREADS;
+  unsigned metar[MAXR];
 #pragma unroll
-    for (int h = 0; h < GS; ++h) {
-      const float x = scaled_logit(p.scores[(int64_t)(g * GS + h) * p.ss_h + l0 + i], p.inv_scale, p.mask, l0 + i);
-      pl[h * p.rps + i] = x;
-      mloc[h] = fmaxf(mloc[h], x);
-    }
-  }
+  for (int k = 0; k < MAXR; ++k)
+    metar[k] = (k * PV_THREADS < n) ? *reinterpret_cast<const unsigned*>(mb + (int64_t)min(tid + k * PV_THREADS, nlast) * p.sm_l) : 0u;
+  logits_sweep<GS>(p.scores, p.ss_h, p.mask, g, l0, n, p.rps, p.inv_scale, pl, mloc, tid);
   block_reduce<GS, true>(mloc, shg, tid);
 #pragma unroll
   for (int h = 0; h < GS; ++h) {
     sloc[h] = 0.f;
     corr[h] = 0.f;
   }
-  for (int i = tid; i < p.rps; i += PV_THREADS) {
-    h16x2 m2 = {(h16)0.f, (h16)0.f};
-    if (i < n) m2 = __builtin_bit_cast(h16x2, *reinterpret_cast<const unsigned*>(mb + (int64_t)i * p.sm_l));
+#pragma unroll
+  for (int k = 0; k < MAXR; ++k) {
+    const int i = tid + k * PV_THREADS;
+    if (i >= p.rps) break;
+    const h16x2 m2 = __builtin_bit_cast(h16x2, metar[k]);
 #pragma unroll
     for (int h = 0; h < GS; ++h) {
       h16 wq = (h16)0.f;
