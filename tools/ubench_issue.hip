@@ -33,7 +33,10 @@ __global__ __launch_bounds__(512) void k(float* out, unsigned long long* cyc, in
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
         const int r = (g * NV + q) % NR;
-        asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[r]) : "v"(m1), "v"(m2));
+        if (KIND == 4) asm volatile("v_dot2c_f32_f16 %0, %1, %2" : "+v"(v[r]) : "v"(m1), "v"(m2));
+        else if (KIND == 5) asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(v[r]) : "v"(m1), "v"(m2));
+        else if (KIND == 6) asm volatile("v_perm_b32 %0, %1, %2, %0" : "+v"(v[r]) : "v"(m1), "v"(m2));
+        else asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[r]) : "v"(m1), "v"(m2));
       }
       if (KIND == 1) asm volatile("s_nop 0");
       if (KIND == 2 && (g & 3) == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(ld) : "v"(ldsaddr));
@@ -139,6 +142,7 @@ void run(const char* name, int threads) {
   const double ns_gap = ms * 1e6 / 10 / iters / 16.0;   // wall time per gap (kernel ~= loop)
   printf("%-40s w/SIMD %d NV %2d NR %d : %5.1f ticks/gap (%.2f/instr)  %5.2f ns/gap  -> %.2f ticks/ns\n", name, threads / 256, NV, NR, per_gap,
          per_gap / (NV + (MFMA ? 1 : 0) + (KIND == 1 || KIND == 3 ? 1 : 0)), ns_gap, per_gap / ns_gap);
+  fflush(stdout);
   hipFree(out); hipFree(cyc);
 }
 
@@ -150,6 +154,10 @@ int main() {
   RUN(4, 8, 0, false, "valu only, independent");
   RUN(4, 1, 0, false, "valu only, fully dependent");
   RUN(4, 2, 0, false, "valu only, distance 2");
+  RUN(8, 8, 4, false, "v_dot2c_f32_f16 only, independent");
+  RUN(8, 8, 5, false, "v_dot2_f32_f16 only, independent");
+  RUN(8, 8, 6, false, "v_perm_b32 only, independent");
+  RUN(8, 8, 0, false, "v_fma_f32 only, 8 independent");
   RUN(2, 8, 0, true, "mfma + 2 indep valu");
   RUN(4, 8, 0, true, "mfma + 4 indep valu");
   RUN(5, 8, 0, true, "mfma + 5 indep valu");
