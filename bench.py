@@ -36,6 +36,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16 MFMA (no sparsity)
+MFMA_WALL_TFLOPS = 1600.0     # measured: tools/ubench_issue.hip, 1580-1640 TFLOP/s at 1.26-1.31 GHz (power-limited)
 
 H, D, GS, HIDDEN = 32, 128, 4, 4096
 G = H // GS
@@ -232,7 +233,11 @@ def main():
                                    "frac": round(kern["abx"]["tflops"] / MFMA_PEAK_TFLOPS, 4),
                                    "hbm_achieved_GBps": kern["abx"]["hbm_GBps"], "hbm_frac": kern["abx"]["hbm_frac"],
                                    "traffic": None if traffic is None else json.load(open(tf)).get("abx"),
-                                   "note": "arithmetic intensity gs*D=512 flop/B > ridge: MFMA-bound (SURVEY F4)"}
+                                   "measured_power_wall_TFLOPs": MFMA_WALL_TFLOPS,
+                                   "frac_of_power_wall": round(kern["abx"]["tflops"] / MFMA_WALL_TFLOPS, 4),
+                                   "note": "arithmetic intensity gs*D=512 flop/B > ridge: MFMA-bound (SURVEY F4); the "
+                                           "power wall is what an MFMA-only random-operand fp16 stream sustains on "
+                                           "this part (profiles/r01_ubench_issue_mi355x.txt)"}
         if world == 1 and not args.no_cpu_baseline:
             cl = args.cpu_sample_len or L
             t0 = time.perf_counter()
