@@ -7,6 +7,8 @@ dispatcher (torch.compile / export see opaque ops with fake kernels).  Importing
     palu::quantize_pack(x, bits) -> (codes, meta)                     palu/model/modules/quant.py:5-41
     palu::unpack_dequant(codes, meta, bits, rank) -> Tensor
     palu::hadamard_transform(x, scale) -> Tensor                      fast_hadamard_transform.hadamard_transform
+    palu::rope_(x, pos0, theta=1e4) -> ()   (in place)                 rotary_emb + apply_rotary_pos_emb (:204-205)
+    palu::prefill_attn(q, k, v_lat, past, causal, scale) -> Tensor    prompt branch :205-255, flash-style
 
 All run on the current stream and allocate only through torch's caching allocator (graph-capturable).
 """
@@ -103,3 +105,46 @@ def hadamard_transform(x: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
 @hadamard_transform.register_fake
 def _(x, scale=1.0):
     return torch.empty_like(x)
+
+
+@torch.library.custom_op("palu::rope_", mutates_args=("x",))
+def rope_(x: torch.Tensor, pos0: int, theta: float = 10000.0) -> None:
+    """In-place rotary embedding of x [H, T, 128] fp16 (D contiguous, any H/T strides), row t at position pos0 + t."""
+    assert x.dim() == 3 and x.dtype == torch.float16 and x.is_cuda and x.stride(2) == 1
+    inv = _abx.rope_inv_freq(x.device, x.shape[2], theta)
+    _lib.check(_lib.lib.palu_rope_f16(x.data_ptr(), x.stride(0), x.stride(1), x.shape[0], x.shape[1], x.shape[2], pos0,
+                                      inv.data_ptr(), _lib.current_stream()), "palu_rope_f16")
+
+
+@rope_.register_fake
+def _(x, pos0, theta=10000.0):
+    return None
+
+
+@torch.library.custom_op("palu::prefill_attn", mutates_args=())
+def prefill_attn(q: torch.Tensor, k: torch.Tensor, v_lat: torch.Tensor, past: int = 0, causal: bool = True,
+                 scale: float = 1.0 / math.sqrt(128.0)) -> torch.Tensor:
+    """q [H,Tq,D], k [H,Tk,D] (both RoPE'd), v_lat [G,Tk,Rv] fp16 -> [Tq, H*Rv]: softmax(q.k^T*scale [causal]) . V_lat
+    per head, the head's group supplying V (kernel/palu_attention.py:205-255 without the [Tq,Tk] matrix)."""
+    H, Tq, D = q.shape
+    Tk = k.shape[1]
+    G, _, Rv = v_lat.shape
+    assert q.dtype == k.dtype == v_lat.dtype == torch.float16 and q.is_cuda and k.shape[0] == H and v_lat.shape[1] == Tk
+    if q.stride(2) != 1 or q.stride(0) % 8 or q.stride(1) % 8:
+        q = q.contiguous()
+    if k.stride(2) != 1 or k.stride(0) % 8 or k.stride(1) % 8:
+        k = k.contiguous()
+    pad = (Tk + 63) // 64 * 64
+    vt = torch.zeros((G, Rv, pad), dtype=torch.float16, device=q.device)
+    vt[:, :, :Tk].copy_(v_lat.transpose(1, 2))
+    out = torch.empty((Tq, H * Rv), dtype=torch.float16, device=q.device)
+    _lib.check(_lib.lib.palu_prefill_attn_f16(q.data_ptr(), q.stride(0), q.stride(1), k.data_ptr(), k.stride(0), k.stride(1),
+                                              vt.data_ptr(), vt.stride(0), vt.stride(1), out.data_ptr(), out.stride(0),
+                                              H, G, D, Tq, Tk, Rv, int(past), 1 if causal else 0, float(scale),
+                                              _lib.current_stream()), "palu_prefill_attn_f16")
+    return out
+
+
+@prefill_attn.register_fake
+def _(q, k, v_lat, past=0, causal=True, scale=1.0 / math.sqrt(128.0)):
+    return q.new_empty((q.shape[1], q.shape[0] * v_lat.shape[2]))
