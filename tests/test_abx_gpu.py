@@ -149,3 +149,32 @@ def test_abx_errors():
         abx(a.cpu(), b.cpu(), x.cpu())
     out = abx(a, b, x[:, :0])
     assert out.shape == (32, 1, 0)
+
+
+def test_abx_full_size_c5_tail_window():
+    """BASELINE config 5 per-GPU slice (one group of 4 heads, R=128, L=262144): the last 8192 positions -- where the
+    fp32 rounding of l*inv_freq is largest (2^-7 rad on the highest frequency) -- against the oracle's rounding
+    points and against exact fp64 at the oracle's fp32 angles; plus tile independence at that offset."""
+    torch.manual_seed(3)
+    H, G, R, L = 4, 1, 128, 262144
+    dev = "cuda"
+    a = torch.randn(H, 1, 128, dtype=torch.float16, device=dev)
+    b = (torch.randn(H, R, 128, device=dev) / R ** 0.5).half()
+    x = torch.randn(G, L, R, dtype=torch.float16, device=dev)
+    abx = _abx()
+    full = abx(a, b, x)
+    l0 = L - 8192
+    win = abx(a, b, x[:, l0:].contiguous(), pos_offset=l0)
+    assert (win.float() - full[:, :, l0:].float()).abs().max().item() <= 2e-3 * full.float().abs().max().item()
+    ac, bc, xw = a.cpu(), b.cpu(), x[:, l0:].cpu()
+    cos, sin = oracle.rope_cos_sin(L, 128, start=l0)
+    keys = torch.matmul(xw[:, None], bc.reshape(G, H // G, R, 128)).reshape(H, L - l0, 128)
+    ref = torch.matmul(ac, oracle.rope_rotate(keys, cos, sin).to(torch.float16).transpose(-1, -2))
+    keys64 = torch.matmul(xw.double()[:, None], bc.double().reshape(G, H // G, R, 128)).reshape(H, L - l0, 128)
+    ang = torch.outer(torch.arange(l0, L, dtype=torch.int64).to(torch.float32), oracle.rope_inv_freq(128)).double()
+    ang = torch.cat((ang, ang), dim=-1)
+    exact = torch.matmul(ac.double(), oracle.rope_rotate(keys64, ang.cos(), ang.sin()).transpose(-1, -2))
+    got = full[:, :, l0:].cpu()
+    scale = exact.abs().max().item()
+    assert (got.double() - ref.double()).abs().max().item() / scale <= 1e-3
+    assert (got.double() - exact).abs().max().item() <= 1.5 * (ref.double() - exact).abs().max().item() + 1e-3 * scale / 4
