@@ -123,3 +123,38 @@ def test_hadamard_fusion_is_output_invariant():
     k0, k1 = c0.buffers(0)[0][0, :, :L].float(), c1.buffers(0)[0][0, :, :L].float()
     assert (k0 - k1).abs().max() > 0.05                                                       # latents really rotated
     torch.testing.assert_close(k0.norm(dim=-1), k1.norm(dim=-1), rtol=2e-2, atol=2e-2)        # by an orthogonal map
+
+
+@pytest.mark.parametrize("bits,R,Rv,L", [(3, 128, 384, 65537), (4, 64, 192, 131073)], ids=["config3", "config4"])
+def test_quantised_kernels_full_size(bits, R, Rv, L):
+    """BASELINE configs 3 and 4 at full length: the quantised score kernel is BIT-IDENTICAL to the fp16 kernel on the
+    de-quantised latents, the quantised P.V agrees with the fp16 P.V on the de-quantised values (size-independent
+    properties; the oracle cannot hold these sizes in seconds)."""
+    from palu_amd import _lib
+    from palu_amd.kernel import quant as q
+    from palu_amd.kernel.abx_rope import abx, prepare_b, rope_inv_freq
+    H, G = 32, 8
+    g = torch.Generator(device=DEV).manual_seed(bits)
+    a = torch.randn(H, 1, 128, dtype=torch.float16, device=DEV, generator=g)
+    b = (torch.randn(H, R, 128, device=DEV, generator=g) / math.sqrt(R)).half()
+    x = torch.randn(G, L, R, dtype=torch.float16, device=DEV, generator=g)
+    codes, meta, deq = q.quantize_pack(x, bits, want_dequant=True)
+    ref = abx(a, b, deq)
+    out = torch.empty(H, 1, L, dtype=torch.float16, device=DEV)
+    frag, inv = prepare_b(b, G), rope_inv_freq(x.device)
+    _lib.check(_lib.lib.palu_abx_rope_q(a.data_ptr(), a.stride(0), a.stride(2), frag.data_ptr(), codes.data_ptr(),
+                                        codes.stride(0), codes.stride(1), meta.data_ptr(), meta.stride(0), meta.stride(1),
+                                        out.data_ptr(), out.stride(0), H, G, L, R, 128, bits, inv.data_ptr(), 0,
+                                        _lib.current_stream()), "abx_q")
+    assert torch.equal(out, ref)
+    del x, deq, codes, meta
+    v = torch.randn(G, L, Rv, dtype=torch.float16, device=DEV, generator=g)
+    vc, vm, vdeq = q.quantize_pack(v, bits, want_dequant=True)
+    scores = out[:, 0].contiguous()
+    ws = torch.empty(_lib.lib.palu_pv_workspace_bytes(H, G, L, Rv), dtype=torch.uint8, device=DEV)
+    ctx = torch.empty(H, Rv, dtype=torch.float16, device=DEV)
+    _lib.check(_lib.lib.palu_softmax_pv_q(scores.data_ptr(), scores.stride(0), 0, vc.data_ptr(), vc.stride(0), vc.stride(1),
+                                          vm.data_ptr(), vm.stride(0), vm.stride(1), ctx.data_ptr(), 0, 0, ws.data_ptr(),
+                                          H, G, L, Rv, bits, math.sqrt(128.0), _lib.current_stream()), "pv_q")
+    ref_ctx, _ = softmax_pv(scores, vdeq)
+    torch.testing.assert_close(ctx, ref_ctx, rtol=1e-3, atol=1e-3)
