@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Exercise HeadParallelDecoder.step with world_size 2 on ONE GPU (both ranks on cuda:0, gloo carrying the
+all-gather through the host) and compare with the unsharded step -- a functional check of the N > 1 code path
+that bench.py --gpus N uses, for boxes with a single GPU (RCCL refuses two ranks on one device)."""
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+H, G, D, HIDDEN, RK, RV, LP = 32, 8, 128, 4096, 1024, 3072, 4096
+
+
+def build(world, rank, dev):
+    from palu_amd.kernel import head_parallel as hp
+    torch.manual_seed(1234)
+    Rk, Rv = RK // G, RV // G
+    full = {"wq": (torch.randn(H * D, HIDDEN, device=dev) / 64).half(),
+            "vt_k": (torch.randn(RK, HIDDEN, device=dev) / 64).half(),
+            "vt_v": (torch.randn(RV, HIDDEN, device=dev) / 64).half(),
+            "b": (torch.randn(H, Rk, D, device=dev) * Rk ** -0.5).half(),
+            "wo": (torch.randn(HIDDEN, H * Rv, device=dev) * 0.01).half()}
+    cap = LP + 64
+    k_all = torch.randn(G, cap, Rk, device=dev, dtype=torch.float16)
+    v_all = torch.randn(G, cap, Rv, device=dev, dtype=torch.float16)
+    hidden = torch.randn(HIDDEN, device=dev, dtype=torch.float16)
+    plan = hp.make_plan(world, rank, H, G, D, Rk, Rv)
+    w = {k: v.contiguous() for k, v in hp.shard_weights(plan, full).items()}
+    kc, vc = hp.shard_cache(plan, k_all, v_all)
+    return hp.HeadParallelDecoder(plan, w, kc.contiguous(), vc.contiguous(), HIDDEN), hidden
+
+
+def worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dec, hidden = build(world, rank, dev)
+    # gloo moves host tensors: wrap the one collective
+    orig = dist.all_gather_into_tensor
+
+    def via_host(out, inp, group=None):
+        o, i = out.cpu(), inp.cpu()
+        orig(o, i, group=group)
+        out.copy_(o)
+    dist.all_gather_into_tensor = via_host
+    out = dec.step(hidden, LP, LP).float().cpu()
+    torch.cuda.synchronize()
+    if rank == 0:
+        q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    sharded = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
+    dec, hidden = build(1, 0, torch.device("cuda", 0))
+    ref = dec.step(hidden, LP, LP).float().cpu()
+    err = (sharded - ref).abs().max().item()
+    print(f"world 2 on one GPU vs unsharded: max|diff| = {err:.3e} (scale {ref.abs().max().item():.3e})")
+    sys.exit(0 if err <= 1e-3 * max(1.0, ref.abs().max().item()) else 1)
+
+
+if __name__ == "__main__":
+    main()
