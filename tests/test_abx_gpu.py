@@ -178,3 +178,37 @@ def test_abx_full_size_c5_tail_window():
     scale = exact.abs().max().item()
     assert (got.double() - ref.double()).abs().max().item() / scale <= 1e-3
     assert (got.double() - exact).abs().max().item() <= 1.5 * (ref.double() - exact).abs().max().item() + 1e-3 * scale / 4
+
+
+def test_abx_random_shapes_and_strides():
+    """Seeded sweep over group sizes, ranks (fast and chunked paths), ragged lengths, position offsets and padded /
+    interleaved latent layouts (row stride > R, groups interleaved in memory) against the oracle (P2)."""
+    rng = np.random.default_rng(20260927)
+    abx = _abx()
+    for it in range(28):
+        gs = int(rng.choice([1, 2, 3, 4, 8]))
+        G = int(rng.choice([1, 2, 4]))
+        H = G * gs
+        R = int(rng.choice([32, 64, 128, 128, 96, 160, 256]))
+        L = int(rng.integers(1, 2600))
+        a = torch.from_numpy(rng.standard_normal((H, 1, 128)).astype(np.float16))
+        b = torch.from_numpy((rng.standard_normal((H, R, 128)) / np.sqrt(R)).astype(np.float16))
+        x = torch.from_numpy(rng.standard_normal((G, L, R)).astype(np.float16))
+        layout = it % 3
+        xd = x.cuda()
+        if layout == 1:                                   # padded rows: stride(1) = R + 8
+            buf = torch.zeros(G, L, R + 8, dtype=torch.float16, device="cuda")
+            buf[:, :, :R] = xd
+            xd = buf[:, :, :R]
+        elif layout == 2:                                 # [L, G, R] storage viewed as [G, L, R]
+            xd = xd.transpose(0, 1).contiguous().transpose(0, 1)
+        off = int(rng.choice([0, 0, 1, 4097])) if R in (32, 64, 128) else 0
+        got = abx(a.cuda(), b.cuda(), xd, pos_offset=off)
+        if off == 0:
+            _check(got, a, b, x)
+        else:                                             # same rows placed at absolute positions off..off+L-1
+            xz = torch.cat((torch.zeros(G, off, R, dtype=torch.float16), x), dim=1)
+            ref = oracle.abx_scores(a, b, xz)[:, :, off:]
+            exact = oracle.abx_scores_f64(a, b, xz)[:, :, off:]
+            scale = exact.abs().max().item()
+            assert (got.cpu().double() - ref.double()).abs().max().item() / scale <= 1e-3, (it, gs, G, R, L, off)
