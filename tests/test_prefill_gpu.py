@@ -230,3 +230,41 @@ def test_rope_inplace_matches_reference_rounding(H, T, pos0, strided):
     got = xg.cpu()
     torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-3)
     assert (got != ref).float().mean().item() < 0.02          # the odd fp16 ulp from cos/sin of large angles
+
+
+@pytest.mark.parametrize("quant_bits", [16, 4])
+def test_three_layers_share_one_cache(quant_bits):
+    """A small stack of attention modules (layer_idx 0..2) threading one cache object, as a decoder would: prompt pass
+    then two decode steps; every layer's rows land in its own buffers and the outputs equal those of the same modules
+    run with private caches."""
+    from palu_amd.kernel.palu_attention import LatentCache, QuantLatentCache
+    tag, seed, hidden, H, D, gs, rank_k, rank_v, T, _ = gi.PREFILL_CASES[0]
+    mods = []
+    for li in range(3):
+        w, prompt, _ = gi.prefill_inputs(seed + li, hidden, H, D, gs, rank_k, rank_v, T, True)
+        m = _module_from_palu_weights(hidden, H, D, gs, rank_k, rank_v, w)
+        m.layer_idx = li
+        mods.append(m)
+    mk = (lambda: LatentCache()) if quant_bits == 16 else (lambda: QuantLatentCache(quant_bits))
+    shared, private = mk(), [mk() for _ in mods]
+    x = prompt.reshape(1, T, hidden).to(DEV)
+    rng = np.random.default_rng(5)
+    toks = [torch.from_numpy(rng.standard_normal((1, 1, hidden)).astype(np.float16)).to(DEV) for _ in range(2)]
+    with torch.no_grad():
+        hs, hp_ = x, x
+        for li, m in enumerate(mods):                        # prompt pass, layer by layer
+            hs, _, _ = m(hs, past_key_value=shared, is_causal=True)
+            m.layer_idx = 0
+            hp_, _, _ = m(hp_, past_key_value=private[li], is_causal=True)
+            m.layer_idx = li
+        torch.testing.assert_close(hs, hp_, rtol=0, atol=0)
+        for step, tok in enumerate(toks):
+            hs, hp_ = tok, tok
+            pos = torch.tensor([[T + step]])
+            for li, m in enumerate(mods):
+                hs, _, _ = m(hs, past_key_value=shared, position_ids=pos)
+                m.layer_idx = 0
+                hp_, _, _ = m(hp_, past_key_value=private[li], position_ids=pos)
+                m.layer_idx = li
+            torch.testing.assert_close(hs, hp_, rtol=0, atol=0)
+    assert [shared.get_seq_length(li) for li in range(3)] == [T + 2] * 3
