@@ -155,17 +155,20 @@ def profile_tpot(model, cache_size_k, cache_size_v, cache_type=torch.float16, ba
     return dur / reps
 
 
-def profile_ttft(model, prompt_len, repeats=5):
+def profile_ttft(model, prompt_len, repeats=5, bits=16):
     """Prompt pass (q_len = prompt_len, empty cache) through the flash-style prefill kernel: time to first token
     of ONE attention module.  Additive to the reference harness, which only profiles TPOT."""
     device = next(iter(model.parameters())).device
     x = torch.randn((1, prompt_len, model.config.hidden_size), dtype=torch.float16, device=device)
     with torch.no_grad():
+        def new_cache():
+            cap = prompt_len + 64
+            return DynamicCache(capacity=cap) if bits >= 16 else QuantLatentCache(bits, capacity=cap)
         for _ in range(2):
-            model(x, past_key_value=DynamicCache(capacity=prompt_len + 64), is_causal=True)
+            model(x, past_key_value=new_cache(), is_causal=True)
         torch.cuda.synchronize()
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        caches = [DynamicCache(capacity=prompt_len + 64) for _ in range(repeats)]
+        caches = [new_cache() for _ in range(repeats)]
         start.record()
         for c in caches:
             model(x, past_key_value=c, is_causal=True)
@@ -190,7 +193,7 @@ def main(args):
     if args.hadamard:
         attention.fuse_hadamard()
     if args.ttft:
-        ms = profile_ttft(attention, args.prompt_len, max(1, min(args.repeats, 5)))
+        ms = profile_ttft(attention, args.prompt_len, max(1, min(args.repeats, 5)), bits=args.bits)
         if args.json:
             H, D, Rv = config.num_attention_heads, config.hidden_size // config.num_attention_heads, group_dim_v
             flops = H * (args.prompt_len ** 2 / 2) * (D + Rv) * 2
