@@ -35,6 +35,7 @@ struct PfParams {
   int H, G, gs, Tq, Tk, Rv, past, causal;
   float scale_log2;   // scale * log2(e)
   int nqt;
+  int head_major;     // 1: blockIdx.x = head (heavy query tiles of ALL heads first); 0: blockIdx.x = query tile
 };
 
 template <int NCB>
@@ -50,8 +51,11 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(PfParams p)
   const int lane = tid & 63;
   const int w = tid >> 6;
   const int n = lane & 31, hi = lane >> 5;
-  const int qt = p.nqt - 1 - (int)blockIdx.x;      // heavy (late) query tiles first
-  const int h = blockIdx.y;
+  // dispatch order (x fastest), heavy (late) query tiles first.  head-major: the heavy tiles of ALL heads go first
+  // (best balance when there are few workgroups per CU); tile-major: all tiles of a head run together and share its
+  // K~ / V^T stream through L2 / MALL (best for long prompts).  Chosen by the host (PfParams::head_major).
+  const int qt = p.nqt - 1 - (int)(p.head_major ? blockIdx.y : blockIdx.x);
+  const int h = p.head_major ? blockIdx.x : blockIdx.y;
   const int g = h / p.gs;
   const int c0 = blockIdx.z * 32 * NCB;
 
@@ -273,8 +277,8 @@ __global__ __launch_bounds__(PFP_THREADS, 1) void prefill_attn_pair_kernel(PfPar
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qblk = w & 3, half = w >> 2;
   const int n = lane & 31, hi = lane >> 5;
-  const int qt = p.nqt - 1 - (int)blockIdx.x;
-  const int h = blockIdx.y;
+  const int qt = p.nqt - 1 - (int)(p.head_major ? blockIdx.y : blockIdx.x);   // see prefill_attn_kernel
+  const int h = p.head_major ? blockIdx.x : blockIdx.y;
   const int g = h / p.gs;
   const int c0 = half * 32 * NCBH;
 
@@ -533,7 +537,7 @@ int launch_prefill_pair(const PfParams& p, hipStream_t stream) {
     }
     attr_done = true;
   }
-  dim3 grid(p.nqt, p.H, 1);
+  dim3 grid(p.head_major ? p.H : p.nqt, p.head_major ? p.nqt : p.H, 1);
   hipLaunchKernelGGL(kern, grid, dim3(PFP_THREADS), smem, stream, p);
   PALU_LAUNCH_CHECK();
   return PALU_OK;
@@ -552,7 +556,7 @@ int launch_prefill(const PfParams& p, hipStream_t stream) {
     }
     attr_done = true;
   }
-  dim3 grid(p.nqt, p.H, p.Rv / (32 * NCB));
+  dim3 grid(p.head_major ? p.H : p.nqt, p.head_major ? p.nqt : p.H, p.Rv / (32 * NCB));
   hipLaunchKernelGGL(kern, grid, dim3(PF_THREADS), smem, stream, p);
   PALU_LAUNCH_CHECK();
   return PALU_OK;
@@ -588,6 +592,14 @@ extern "C" int palu_prefill_attn_f16(const void* q, int64_t sq_h, int64_t sq_t, 
   p.H = H; p.G = G; p.gs = H / G; p.Tq = Tq; p.Tk = Tk; p.Rv = Rv; p.past = past; p.causal = causal ? 1 : 0;
   p.scale_log2 = scale * 1.4426950408889634f;
   p.nqt = (Tq + PF_BM - 1) / PF_BM;
+  {
+    static int force = -2;                       // PALU_PREFILL_HEAD_MAJOR = 0 / 1 overrides the size rule
+    if (force == -2) {
+      const char* e = getenv("PALU_PREFILL_HEAD_MAJOR");
+      force = e ? atoi(e) : -1;
+    }
+    p.head_major = force >= 0 ? force : ((int64_t)p.nqt * H <= 8192 ? 1 : 0);
+  }
   hipStream_t s = (hipStream_t)stream;
   static int use_pair = -1;
   if (use_pair < 0) {
