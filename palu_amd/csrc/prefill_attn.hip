@@ -35,7 +35,8 @@ struct PfParams {
   int H, G, gs, Tq, Tk, Rv, past, causal;
   float scale_log2;   // scale * log2(e)
   int nqt;
-  int head_major;     // 1: blockIdx.x = head (heavy query tiles of ALL heads first); 0: blockIdx.x = query tile
+  int head_major;     // dispatch order: 0 tile-major (all tiles of a head together), 1 head-major (heavy tiles of ALL heads
+                      // first), 2 eight heads at a time, one per XCD, heavy tiles first (default beyond 2048 workgroups)
 };
 
 template <int NCB>
@@ -51,11 +52,20 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(PfParams p)
   const int lane = tid & 63;
   const int w = tid >> 6;
   const int n = lane & 31, hi = lane >> 5;
-  // dispatch order (x fastest), heavy (late) query tiles first.  head-major: the heavy tiles of ALL heads go first
-  // (best balance when there are few workgroups per CU); tile-major: all tiles of a head run together and share its
-  // K~ / V^T stream through L2 / MALL (best for long prompts).  Chosen by the host (PfParams::head_major).
-  const int qt = p.nqt - 1 - (int)(p.head_major ? blockIdx.y : blockIdx.x);
-  const int h = p.head_major ? blockIdx.x : blockIdx.y;
+  // dispatch order (x fastest), heavy (late) query tiles first, chosen by the host (PfParams::head_major):
+  // 1 = the heavy tiles of ALL heads first (best balance with few workgroups per CU); 2 = eight heads at a time, head
+  // 8j + x on XCD x, so each XCD's L2 serves ONE head's K~ / V^T stream to its 32 CUs (best for long prompts);
+  // 0 = all tiles of a head together.
+  int qt_rev, h;
+  if (p.head_major == 2) {                          // 8 heads at a time, one per XCD; within them heavy tiles first
+    const int id = blockIdx.x;
+    qt_rev = (id >> 3) % p.nqt;
+    h = ((id >> 3) / p.nqt) * 8 + (id & 7);
+  } else {
+    qt_rev = p.head_major ? blockIdx.y : blockIdx.x;
+    h = p.head_major ? blockIdx.x : blockIdx.y;
+  }
+  const int qt = p.nqt - 1 - qt_rev;
   const int g = h / p.gs;
   const int c0 = blockIdx.z * 32 * NCB;
 
@@ -277,8 +287,16 @@ __global__ __launch_bounds__(PFP_THREADS, 1) void prefill_attn_pair_kernel(PfPar
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int qblk = w & 3, half = w >> 2;
   const int n = lane & 31, hi = lane >> 5;
-  const int qt = p.nqt - 1 - (int)(p.head_major ? blockIdx.y : blockIdx.x);   // see prefill_attn_kernel
-  const int h = p.head_major ? blockIdx.x : blockIdx.y;
+  int qt_rev, h;
+  if (p.head_major == 2) {   // see prefill_attn_kernel
+    const int id = blockIdx.x;
+    qt_rev = (id >> 3) % p.nqt;
+    h = ((id >> 3) / p.nqt) * 8 + (id & 7);
+  } else {
+    qt_rev = p.head_major ? blockIdx.y : blockIdx.x;
+    h = p.head_major ? blockIdx.x : blockIdx.y;
+  }
+  const int qt = p.nqt - 1 - qt_rev;
   const int g = h / p.gs;
   const int c0 = half * 32 * NCBH;
 
@@ -537,7 +555,7 @@ int launch_prefill_pair(const PfParams& p, hipStream_t stream) {
     }
     attr_done = true;
   }
-  dim3 grid(p.head_major ? p.H : p.nqt, p.head_major ? p.nqt : p.H, 1);
+  dim3 grid(p.head_major == 2 ? p.H * p.nqt : (p.head_major ? p.H : p.nqt), p.head_major == 2 ? 1 : (p.head_major ? p.nqt : p.H), 1);
   hipLaunchKernelGGL(kern, grid, dim3(PFP_THREADS), smem, stream, p);
   PALU_LAUNCH_CHECK();
   return PALU_OK;
@@ -556,7 +574,7 @@ int launch_prefill(const PfParams& p, hipStream_t stream) {
     }
     attr_done = true;
   }
-  dim3 grid(p.head_major ? p.H : p.nqt, p.head_major ? p.nqt : p.H, p.Rv / (32 * NCB));
+  dim3 grid(p.head_major == 2 ? p.H * p.nqt : (p.head_major ? p.H : p.nqt), p.head_major == 2 ? 1 : (p.head_major ? p.nqt : p.H), p.Rv / (32 * NCB));
   hipLaunchKernelGGL(kern, grid, dim3(PF_THREADS), smem, stream, p);
   PALU_LAUNCH_CHECK();
   return PALU_OK;
@@ -598,7 +616,8 @@ extern "C" int palu_prefill_attn_f16(const void* q, int64_t sq_h, int64_t sq_t, 
       const char* e = getenv("PALU_PREFILL_HEAD_MAJOR");
       force = e ? atoi(e) : -1;
     }
-    p.head_major = force >= 0 ? force : ((int64_t)p.nqt * H <= 8192 ? 1 : 0);
+    p.head_major = force >= 0 ? force : ((int64_t)p.nqt * H <= 2048 ? 1 : 2);
+    if (p.head_major == 2 && H % 8 != 0) p.head_major = 0;
   }
   hipStream_t s = (hipStream_t)stream;
   static int use_pair = -1;
