@@ -82,6 +82,8 @@ int palu_abx_rope_f16(const void* a, int64_t sa_h, int64_t sa_d,
  * 16-byte aligned rows, ctx: [H, Rv] fp16 (= the [1,1,H*Rv] o_proj input), probs: [H, L] fp16 or
  * NULL (the attn_weights of output_attentions=True).  workspace: palu_pv_workspace_bytes() bytes.
  * gs = H/G in {1,2,4,8}; Rv % 8 == 0.
+ * palu_pv_workspace_bytes(H, G, Lcap, Rv) is an upper bound over every L <= Lcap (the split count is not
+ * monotone in L), so a workspace sized for a cache capacity serves every fill level.
  */
 int palu_pv_nsplit(int G, int L);
 size_t palu_pv_workspace_bytes(int H, int G, int L, int Rv);
@@ -93,6 +95,28 @@ int palu_softmax_pv_f16(const void* scores, int64_t ss_h, const void* mask,
                         const void* v, int64_t sv_g, int64_t sv_l,
                         void* ctx, void* probs, int64_t sp_h, void* workspace,
                         int H, int G, int L, int Rv, float sqrt_d, palu_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused attention core of one decode step: abx scores -> /sqrt(D) -> softmax -> latent P.V in ONE kernel
+ * (replaces kernel/palu_attention.py:219 recompute_k_gemv(...)/sqrt(D), :238 softmax, :246-251 latent P.V;
+ * the [H, L] score tensor never exists in memory).  Same operands as palu_abx_rope_f16 + palu_softmax_pv_f16:
+ *   q [H, D] rotated query, bfrag from palu_abx_prepare_b, k [G, L, Rk] / v [G, L, Rv] fp16 latents (16-byte
+ *   aligned rows), ctx [H, Rv] fp16, key row l at position pos0 + l, no mask, no attention weights.
+ * palu_decode_attn_supported() != 0 for the shapes the kernel covers (D = 128, gs in {3,4}, Rk in {64,128},
+ * Rv in {128,192,256,384}); palu_decode_attn_preferred() != 0 where palu_decode_step_f16 / palu_decode_attend_f16
+ * pick it over the two-kernel path (measured: one latent group per GPU, i.e. the head-group shard of an 8-GPU node;
+ * PALU_FUSED_ATTN=1 / 0 in the environment forces it on for every covered shape / off).  workspace:
+ * palu_pv_workspace_bytes(H, G, L, Rv) bytes; the per-head (max, sum) statistics are left at
+ * palu_decode_attn_stats_offset() like palu_softmax_pv_f16 leaves them at palu_pv_stats_offset().
+ */
+int palu_decode_attn_supported(int H, int G, int Rk, int Rv, int D);
+int palu_decode_attn_preferred(int H, int G, int Rk, int Rv, int D);
+int palu_decode_attn_nsplit(int G, int L);
+size_t palu_decode_attn_stats_offset(int H, int G, int L, int Rv);
+int palu_decode_attn_f16(const void* q, int64_t sq_h, int64_t sq_d, const void* bfrag,
+                         const void* k, int64_t sk_g, int64_t sk_l, const void* v, int64_t sv_g, int64_t sv_l,
+                         void* ctx, void* workspace, int H, int G, int L, int Rk, int Rv, int D,
+                         const float* inv_freq, int pos0, float sqrt_d, palu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Batch-1 projections.

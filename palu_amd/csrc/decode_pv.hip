@@ -508,18 +508,26 @@ __global__ void probs_kernel(const h16* scores, int64_t ss_h, const h16* mask, c
   }
 }
 
-int pv_rows_per_split(int G, int L) {
-  // ~PALU_PV_WGS_PER_CU (default 4) workgroups per CU in flight; 64-row granularity; at most 1024 rows (LDS), at least 128
+int pv_wgs_per_cu() {
   static int per_cu = 0;
   if (per_cu == 0) {
     const char* e = getenv("PALU_PV_WGS_PER_CU");
     per_cu = e ? atoi(e) : 4;
     if (per_cu < 1) per_cu = 1;
   }
-  // whole multiples of the CU count: every CU gets the same number of workgroups (no straggler round)
-  const int cus = palu_num_cus();
-  long long nsplit = ((long long)per_cu * cus + G - 1) / G;
-  if (nsplit < 1) nsplit = 1;
+  return per_cu;
+}
+
+// split target: ~PALU_PV_WGS_PER_CU (default 4) workgroups per CU in flight, whole multiples of the CU count
+// (every CU gets the same number of workgroups: no straggler round)
+long long pv_split_target(int G) {
+  long long t = ((long long)pv_wgs_per_cu() * palu_num_cus() + G - 1) / G;
+  return t < 1 ? 1 : t;
+}
+
+int pv_rows_per_split(int G, int L) {
+  // 8-row granularity; at most 2048 rows (LDS), at least 128
+  const long long nsplit = pv_split_target(G);
   long long rps = (L + nsplit - 1) / nsplit;
   rps = (rps + 7) / 8 * 8;
   if (rps < 128) rps = 128;
@@ -527,7 +535,32 @@ int pv_rows_per_split(int G, int L) {
   return (int)rps;
 }
 
+// Upper bound of the split count over EVERY L <= Lcap.  ceil(L / rps(L)) is not monotone in L (rps is rounded up to
+// 8 and clamped), so a workspace sized from nsplit(Lcap) can be too small for a shorter fill level: with
+// rps = clamp(round8(ceil(L/T)), 128, 2048) the count is <= min(T, ceil(L/128)) while rps < 2048 and ceil(L/2048) after.
+// The fused decode kernel (decode_fused.hip) splits into min(CUs / G, ceil(L/64)) ranges: covered by min(T, ceil(L/64)).
+int pv_nsplit_bound(int G, int Lcap) {
+  const long long T = pv_split_target(G);
+  long long a = ((long long)Lcap + 63) / 64;
+  if (a > T) a = T;
+  const long long b = ((long long)Lcap + 2047) / 2048;
+  return (int)(a > b ? a : b);
+}
+
 }  // namespace
+
+// split merge shared with the fused decode kernel (decode_fused.hip): ws = part [H][ns][Rv] | ml [H][ns][2] | stats [H][2]
+int palu_pv_combine_launch(float* ws, void* ctx, int H, int G, int Rv, int ns, hipStream_t s) {
+  CombineParams c;
+  c.part = ws;
+  c.ml = ws + (size_t)H * ns * Rv;
+  c.ctx = (h16*)ctx;
+  c.stats = ws + (size_t)H * ns * (Rv + 2);
+  c.G = G; c.gs = H / G; c.Rv = Rv; c.nsplit = ns;
+  hipLaunchKernelGGL(pv_combine_kernel, dim3(H, (Rv + 63) / 64), dim3(64 * CB_WAVES), 0, s, c);
+  PALU_LAUNCH_CHECK();
+  return PALU_OK;
+}
 
 extern "C" int palu_pv_nsplit(int G, int L) {
   if (L <= 0 || G <= 0) return 0;
@@ -536,8 +569,10 @@ extern "C" int palu_pv_nsplit(int G, int L) {
 }
 
 extern "C" size_t palu_pv_workspace_bytes(int H, int G, int L, int Rv) {
-  int ns = palu_pv_nsplit(G, L);
-  // part [H][ns][Rv] + ml [H][ns][2] + stats [H][2], fp32
+  if (L <= 0 || G <= 0) return 0;
+  // part [H][ns][Rv] + ml [H][ns][2] + stats [H][2], fp32, for the largest split count any L' <= L can produce
+  // (this kernel's and the fused decode kernel's, which never exceeds CUs / G <= the split target)
+  const int ns = pv_nsplit_bound(G, L);
   return ((size_t)H * ns * (Rv + 2) + (size_t)H * 2) * sizeof(float);
 }
 

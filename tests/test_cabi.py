@@ -61,3 +61,41 @@ def test_host_only_entry_points_work_without_gpu():
     assert _lib.lib.palu_pv_workspace_bytes(32, 8, 2048, 96) > 0
     assert _lib.lib.palu_decode_workspace_bytes(32, 8, 128, 4096, 96) > 0
     assert _lib.lib.palu_version() >= 100
+
+
+def test_pv_workspace_covers_every_fill_level():
+    """the split count is not monotone in L, so a workspace sized for a cache capacity must hold the
+    partials of EVERY L <= capacity -- for the split-L P.V kernel and for the fused decode kernel (host arithmetic only;
+    without a GPU the library assumes 256 CUs)."""
+    from palu_amd import _lib
+    lib = _lib.lib
+    Rv = 384
+    for G, H in ((8, 32), (1, 4), (2, 8), (4, 16), (3, 12)):
+        for cap in list(range(64, 4200, 64)) + [8192, 16392, 16512, 65536 + 64, 131072 + 64, 300032]:
+            nbytes = lib.palu_pv_workspace_bytes(H, G, cap, Rv)
+            worst = 0
+            step = 1 if cap <= 4200 else 61
+            for L in list(range(1, cap + 1, step)) + [cap]:
+                ns = max(lib.palu_pv_nsplit(G, L), lib.palu_decode_attn_nsplit(G, L))
+                worst = max(worst, ns)
+                need = (H * ns * (Rv + 2) + H * 2) * 4
+                assert need <= nbytes, (G, cap, L, ns, need, nbytes)
+                assert lib.palu_pv_stats_offset(H, G, L, Rv) + H * 2 * 4 <= nbytes
+                assert lib.palu_decode_attn_stats_offset(H, G, L, Rv) + H * 2 * 4 <= nbytes
+            assert worst >= 1
+    # the round-1 failure: capacity 16512 was sized for 122 splits while L <= 16384 uses up to 128
+    assert lib.palu_pv_nsplit(8, 16384) == 128
+    assert lib.palu_pv_workspace_bytes(32, 8, 16512, 384) >= (32 * 128 * (384 + 2) + 64) * 4
+
+
+def test_fused_attention_shape_policy():
+    from palu_amd import _lib
+    lib = _lib.lib
+    assert lib.palu_decode_attn_supported(32, 8, 128, 384, 128) == 1
+    assert lib.palu_decode_attn_supported(32, 8, 64, 192, 128) == 1
+    assert lib.palu_decode_attn_supported(32, 8, 32, 96, 128) == 0       # C1 ranks: two-kernel path
+    assert lib.palu_decode_attn_supported(32, 8, 128, 384, 64) == 0
+    assert lib.palu_decode_attn_supported(32, 16, 128, 384, 128) == 0    # gs = 2
+    if "PALU_FUSED_ATTN" not in os.environ:
+        assert lib.palu_decode_attn_preferred(4, 1, 128, 384, 128) == 1  # one group per GPU: measured win
+        assert lib.palu_decode_attn_preferred(32, 8, 128, 384, 128) == 0

@@ -1,0 +1,194 @@
+"""GPU parity of the single-kernel attention core of the decode step (palu_decode_attn_f16: abx scores -> /sqrt(D) ->
+softmax -> latent P.V, csrc/decode_fused_kernel.h) against the CPU oracle (torch_abx + the decode branch of
+kernel/palu_attention.py:219-251) and against the two-kernel HIP path, criterion P1: rtol = atol = 1e-3."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle
+
+DEV = "cuda"
+D = 128
+
+
+def _lib():
+    from palu_amd import _lib
+    return _lib
+
+
+def fused_attn(q, b, k, v, L, pos0=0):
+    """q [H,D], b [H,Rk,D], k [G,cap,ldk] (first Rk columns), v [G,cap,ldv]: all cuda fp16 -> ctx [H,Rv], (max,sum) [H,2]"""
+    from palu_amd.kernel.abx_rope import prepare_b, rope_inv_freq
+    lib = _lib()
+    H, Rk, _ = b.shape
+    G = k.shape[0]
+    Rv = v.shape[2]
+    frag = prepare_b(b, G)
+    inv = rope_inv_freq(torch.device(DEV))
+    nbytes = lib.lib.palu_pv_workspace_bytes(H, G, k.shape[1], Rv)
+    ws = torch.zeros(nbytes + 4096, dtype=torch.uint8, device=DEV)
+    ws[nbytes:] = 0x5A                                            # canary behind the workspace
+    ctx = torch.full((H, Rv), float("nan"), dtype=torch.float16, device=DEV)
+    lib.check(lib.lib.palu_decode_attn_f16(q.data_ptr(), q.stride(0), q.stride(1), frag.data_ptr(), k.data_ptr(),
+                                           k.stride(0), k.stride(1), v.data_ptr(), v.stride(0), v.stride(1),
+                                           ctx.data_ptr(), ws.data_ptr(), H, G, L, Rk, Rv, D, inv.data_ptr(), pos0,
+                                           math.sqrt(D), torch.cuda.current_stream().cuda_stream), "decode_attn")
+    torch.cuda.synchronize()
+    assert bool((ws[nbytes:] == 0x5A).all()), "fused kernel wrote past its workspace"
+    off = lib.lib.palu_decode_attn_stats_offset(H, G, L, Rv)
+    stats = ws[off:off + H * 8].view(torch.float32).reshape(H, 2).clone()
+    return ctx, stats
+
+
+def oracle_attn(q, b, k, v):
+    """CPU oracle: scores (torch_abx) / sqrt(D) -> softmax fp32 -> fp16 -> latent P.V (fp16 tensors on the CPU)"""
+    H = q.shape[0]
+    G, L, _ = k.shape
+    scores = oracle.abx_scores(q.reshape(H, 1, D), b, k) / math.sqrt(D)
+    probs = torch.softmax(scores, dim=-1, dtype=torch.float32).to(torch.float16)
+    ctx = torch.matmul(probs.reshape(G, H // G, L), v)
+    return ctx.reshape(H, -1), scores.reshape(H, L)
+
+
+@pytest.mark.parametrize("H,G,Rk,Rv,L", [
+    (32, 8, 128, 384, 1), (32, 8, 128, 384, 63), (32, 8, 128, 384, 64), (32, 8, 128, 384, 65), (32, 8, 128, 384, 129),
+    (32, 8, 128, 384, 2049), (4, 1, 128, 384, 1500), (8, 2, 128, 384, 4097), (32, 8, 64, 192, 2500),
+    (32, 8, 128, 256, 777), (32, 8, 64, 128, 1000), (24, 8, 128, 384, 900), (32, 8, 128, 192, 333),
+])
+def test_fused_attn_vs_oracle(H, G, Rk, Rv, L):
+    rng = np.random.default_rng(H * 7 + L + Rv)
+    q = torch.from_numpy(rng.standard_normal((H, D)).astype(np.float16))
+    b = torch.from_numpy((rng.standard_normal((H, Rk, D)) * Rk ** -0.5).astype(np.float16))
+    k = torch.from_numpy(rng.standard_normal((G, L, Rk)).astype(np.float16))
+    v = torch.from_numpy(rng.standard_normal((G, L, Rv)).astype(np.float16))
+    # device caches with capacity > L whose unused rows hold NaN: they must never reach the result
+    cap = L + 70
+    kd = torch.full((G, cap, Rk), float("nan"), dtype=torch.float16, device=DEV)
+    vd = torch.full((G, cap, Rv), float("nan"), dtype=torch.float16, device=DEV)
+    kd[:, :L] = k.to(DEV)
+    vd[:, :L] = v.to(DEV)
+    ctx, stats = fused_attn(q.to(DEV), b.to(DEV), kd, vd, L)
+    rctx, rscores = oracle_attn(q, b, k, v)
+    torch.testing.assert_close(ctx.cpu(), rctx, rtol=1e-3, atol=1e-3)
+    # the softmax statistics the split-L callers merge with: max and sum of exp over the fp16 logits
+    x = rscores.float()
+    torch.testing.assert_close(stats[:, 0].cpu(), x.max(dim=-1).values, rtol=2e-3, atol=2e-3)
+    ref_sum = torch.exp(x.double() - stats[:, 0].cpu().double()[:, None]).sum(dim=-1)
+    torch.testing.assert_close(stats[:, 1].cpu().double(), ref_sum, rtol=5e-3, atol=1e-3)
+
+
+def two_kernel_attn(q, b, k, v, L, pos0=0):
+    """the two-kernel HIP path (abx -> softmax.PV) on the same device tensors -> (ctx [H,Rv], raw fp16 scores [H,L])"""
+    from palu_amd.kernel.abx_rope import prepare_b, rope_inv_freq
+    lib = _lib()
+    H, Rk, _ = b.shape
+    G, Rv = k.shape[0], v.shape[2]
+    frag = prepare_b(b, G)
+    inv = rope_inv_freq(torch.device(DEV))
+    scores = torch.empty(H, L + 8, dtype=torch.float16, device=DEV)
+    ws = torch.empty(lib.lib.palu_pv_workspace_bytes(H, G, L, Rv), dtype=torch.uint8, device=DEV)
+    ctx2 = torch.empty(H, Rv, dtype=torch.float16, device=DEV)
+    s = torch.cuda.current_stream().cuda_stream
+    lib.check(lib.lib.palu_abx_rope_f16(q.data_ptr(), q.stride(0), 1, frag.data_ptr(), k.data_ptr(), k.stride(0),
+                                        k.stride(1), scores.data_ptr(), scores.stride(0), H, G, L, Rk, D,
+                                        inv.data_ptr(), pos0, s), "abx")
+    lib.check(lib.lib.palu_softmax_pv_f16(scores.data_ptr(), scores.stride(0), 0, v.data_ptr(), v.stride(0),
+                                          v.stride(1), ctx2.data_ptr(), 0, 0, ws.data_ptr(), H, G, L, Rv,
+                                          math.sqrt(D), s), "pv")
+    return ctx2, scores[:, :L]
+
+
+def fp64_pv_of_scores(scores16, v, L):
+    """softmax(fp16(fp16 scores / sqrt(D))) . V evaluated in fp64 (the reference's rounding points on the logits)"""
+    H = scores16.shape[0]
+    G, _, Rv = v.shape
+    xs = (scores16.float() / math.sqrt(D)).half().double()
+    return torch.einsum("ghl,glr->ghr", torch.softmax(xs, -1).view(G, H // G, L), v[:, :L].double()).reshape(H, Rv)
+
+
+def test_fused_attn_matches_two_kernel_path_long():
+    """C2-sized ranks at L = 20000, strided cache rows, key positions offset by pos0 (the split-L use)."""
+    torch.manual_seed(3)
+    H, G, Rk, Rv, L, pos0 = 32, 8, 128, 384, 20000, 4096
+    q = torch.randn(H, D, device=DEV).half()
+    b = (torch.randn(H, Rk, D, device=DEV) * Rk ** -0.5).half()
+    kbuf = torch.randn(G, L + 64, Rk + 8, device=DEV).half()
+    vbuf = torch.randn(G, L + 64, Rv + 8, device=DEV).half()
+    k, v = kbuf[:, :, :Rk], vbuf[:, :, :Rv]
+    ctx, _ = fused_attn(q, b, k, v, L, pos0=pos0)
+    ctx2, scores = two_kernel_attn(q, b, k, v, L, pos0=pos0)
+    torch.testing.assert_close(ctx, ctx2, rtol=1e-3, atol=2e-4)
+    ref = fp64_pv_of_scores(scores, v, L)
+    assert (ctx.double() - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_fused_attn_peaked_softmax_rescales():
+    """Scores with a large spread whose maximum comes late in every range: the running-maximum rescale of the
+    accumulators and of the partial sums is exercised in every workgroup.  With |score| ~ 100 the oracle's own fp16
+    score error is visible in a peaked softmax (criterion P2 regime), so the reference here is the
+    fp64 evaluation on the oracle-validated abx kernel's fp16 scores, which the fused kernel reproduces exactly."""
+    rng = np.random.default_rng(11)
+    H, G, Rk, Rv, L = 32, 8, 128, 384, 3000
+    q = torch.from_numpy((rng.standard_normal((H, D)) * 4).astype(np.float16)).to(DEV)
+    b = torch.from_numpy((rng.standard_normal((H, Rk, D)) * Rk ** -0.5).astype(np.float16)).to(DEV)
+    k = rng.standard_normal((G, L, Rk)) * np.linspace(0.2, 2.0, L)[None, :, None]     # growing key norm
+    k = torch.from_numpy(k.astype(np.float16)).to(DEV)
+    v = torch.from_numpy(rng.standard_normal((G, L, Rv)).astype(np.float16)).to(DEV)
+    ctx, stats = fused_attn(q, b, k, v, L)
+    ctx2, scores = two_kernel_attn(q, b, k, v, L)
+    ref = fp64_pv_of_scores(scores, v, L)
+    assert (scores.float().abs().max() > 40).item()
+    torch.testing.assert_close(ctx.double(), ref, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(ctx, ctx2, rtol=2e-3, atol=2e-3)
+    xs = (scores.float() / math.sqrt(D)).half().float()
+    torch.testing.assert_close(stats[:, 0], xs.max(dim=-1).values, rtol=0, atol=0)
+
+
+def test_fused_attn_rejects_uncovered_shapes():
+    lib = _lib()
+    q = torch.zeros(32, D, dtype=torch.float16, device=DEV)
+    rc = lib.lib.palu_decode_attn_f16(q.data_ptr(), D, 1, q.data_ptr(), q.data_ptr(), 64, 32, q.data_ptr(), 64, 96,
+                                      q.data_ptr(), q.data_ptr(), 32, 8, 2, 32, 96, D, q.data_ptr(), 0, 11.3, 0)
+    assert rc == -2 and b"not covered" in lib.lib.palu_last_error()
+
+
+@pytest.mark.parametrize("fused", [0, 1])
+def test_decode_step_same_result_with_and_without_fused_core(fused, monkeypatch):
+    """The whole step through palu_decode_step_f16 with the attention core forced to either implementation: both
+    must agree with the oracle step (P1)."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import math, sys, torch, numpy as np
+sys.path.insert(0, %r)
+import oracle
+from palu_amd import _lib
+from palu_amd.kernel import head_parallel as hp
+torch.manual_seed(5)
+H, G, D, HID, Rk, Rv, L = 32, 8, 128, 512, 128, 384, 1500
+w = {"wq": (torch.randn(H * D, HID) / 16).half(), "vt_k": (torch.randn(G * Rk, HID) / 16).half(),
+     "vt_v": (torch.randn(G * Rv, HID) / 16).half(), "b": (torch.randn(H, Rk, D) * Rk ** -0.5).half(),
+     "wo": (torch.randn(HID, H * Rv) * 0.02).half()}
+k = torch.randn(G, L, Rk).half(); v = torch.randn(G, L, Rv).half(); tok = torch.randn(HID).half()
+ref, _, _, _ = oracle.decode_step(tok, L, w, k, v)
+plan = hp.make_plan(1, 0, H, G, D, Rk, Rv)
+wd = {n: t.cuda() for n, t in hp.shard_weights(plan, w).items()}
+kc = torch.zeros(G, L + 64, Rk, dtype=torch.float16, device="cuda"); kc[:, :L] = k.cuda()
+vc = torch.zeros(G, L + 64, Rv, dtype=torch.float16, device="cuda"); vc[:, :L] = v.cuda()
+dec = hp.HeadParallelDecoder(plan, wd, kc, vc, HID)
+out = dec.step(tok.cuda(), L, L)
+torch.cuda.synchronize()
+err = (out.cpu().float() - ref.float()).abs().max().item()
+print("preferred", _lib.lib.palu_decode_attn_preferred(H, G, Rk, Rv, D), "err", err)
+torch.testing.assert_close(out.cpu(), ref, rtol=1e-3, atol=1e-3)
+''' % root
+    env = dict(os.environ, PALU_FUSED_ATTN=str(fused))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert f"preferred {fused}" in r.stdout
