@@ -36,7 +36,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md)
 MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16 MFMA (no sparsity)
-MFMA_WALL_TFLOPS = 1600.0     # measured: tools/ubench_issue.hip, 1580-1640 TFLOP/s at 1.26-1.31 GHz (power-limited)
+MFMA_WALL_TFLOPS = 1630.0     # measured: MFMA-only random-operand fp16 stream, 1.69 GHz at 92 % MFMA busy (profiles/r02_ubench_issue_pmc_clock.txt)
 
 H, D, GS, HIDDEN = 32, 128, 4, 4096
 G = H // GS
@@ -83,8 +83,9 @@ def time_loop(fn, steps, warmup, sync):
     return wall, ev0.elapsed_time(ev1)      # (host wall between the two syncs, device event time), ms over `steps`
 
 
-def cpu_baseline(rank_k, rank_v, L, reps=1):
-    """The CPU oracle's decode step (port of the reference's PyTorch path) at the SAME shapes on this host."""
+def cpu_baseline(rank_k, rank_v, L, reps=3):
+    """The CPU oracle's decode step (port of the reference's PyTorch path) at the SAME shapes on this host: 1 warm-up +
+    `reps` timed runs.  Returns (min us, median us, inputs, output) -- the inputs/output feed the GPU parity check."""
     import oracle
     torch.manual_seed(0)
     Rk, Rv = rank_k // G, rank_v // G
@@ -95,12 +96,156 @@ def cpu_baseline(rank_k, rank_v, L, reps=1):
     v = torch.randn(G, L - 1, Rv).half()
     tok = torch.randn(HIDDEN).half()
     times = []
+    out = None
     with torch.no_grad():
         for i in range(reps + 1):
             t0 = time.perf_counter()
-            oracle.decode_step(tok, L - 1, w, k, v)
+            out = oracle.decode_step(tok, L - 1, w, k, v)[0]
             times.append(time.perf_counter() - t0)
-    return min(times[1:]) * 1e6
+    ts = sorted(times[1:])
+    return ts[0] * 1e6, ts[len(ts) // 2] * 1e6, (w, k, v, tok), out
+
+
+def gpu_step_parity(inputs, ref_out, L):
+    """The HIP decode step on the SAME inputs the CPU oracle just ran: max |gpu - oracle| of the attention output."""
+    from palu_amd.kernel import head_parallel as hp
+    w, k, v, tok = inputs
+    dev = torch.device("cuda", torch.cuda.current_device())
+    Rk, Rv = k.shape[2], v.shape[2]
+    plan = hp.make_plan(1, 0, H, G, D, Rk, Rv)
+    wd = {n: t.to(dev) for n, t in w.items()}
+    cap = (L + 64 + 63) // 64 * 64
+    kc = torch.zeros(G, cap, Rk, dtype=torch.float16, device=dev)
+    vc = torch.zeros(G, cap, Rv, dtype=torch.float16, device=dev)
+    kc[:, :L - 1] = k.to(dev)
+    vc[:, :L - 1] = v.to(dev)
+    dec = hp.HeadParallelDecoder(plan, wd, kc, vc, HIDDEN)
+    out = dec.step(tok.to(dev), L - 1, L - 1)
+    torch.cuda.synchronize()
+    d = (out.float().cpu() - ref_out.float()).abs()
+    return float(d.max()), float(ref_out.float().abs().max())
+
+
+def graph_of(fn, warm=3):
+    """Capture one call of `fn` (kernel launches on the current stream, no allocation) into a hipGraph; returns replay."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(warm):
+            fn()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    return g.replay
+
+
+def alg_bytes_q(rank_k, rank_v, L, bits):
+    """SURVEY.md 8(d) with packed latents: codes b/8 bytes per value + 4 bytes (scale, zero) per (row, group)."""
+    Rk, Rv = rank_k // G, rank_v // G
+    kb = G * L * Rk * bits // 8 + 4 * G * L
+    vb = G * L * Rv * bits // 8 + 4 * G * L
+    abx_b = kb + 2 * H * Rk * D + 2 * H * D + 2 * H * L
+    pv_b = vb + 2 * H * L + 2 * H * Rv
+    qkv_b = 2 * HIDDEN * (H * D + rank_k + rank_v) + 2 * HIDDEN
+    o_b = 2 * HIDDEN * H * Rv + 2 * H * Rv
+    return {"abx": abx_b, "softmax_pv": pv_b, "step": abx_b + pv_b + qkv_b + o_b}
+
+
+def bench_quant_config(name, rank_k, rank_v, Lp, bits, steps, dev):
+    """BASELINE configs 3 / 4: the decode step on a packed 3/4-bit latent cache (palu_decode_step_q): step us (graph
+    replay) + the two attention kernels on their own.  Hadamard (config 3) is folded into the weights offline
+    (LlamaPaluAttention.fuse_hadamard): with random-init weights it changes no shape and adds no kernel."""
+    from palu_amd import _lib
+    from palu_amd.kernel.abx_rope import prepare_b, rope_inv_freq
+    from palu_amd.kernel import quant as q
+    lib = _lib.lib
+    Rk, Rv = rank_k // G, rank_v // G
+    L = Lp + 1
+    cap = (Lp + 64 + 63) // 64 * 64
+    torch.manual_seed(4321)
+    wq = (torch.randn(H * D, HIDDEN, device=dev) / 64).half()
+    vtk = (torch.randn(rank_k, HIDDEN, device=dev) / 64).half()
+    vtv = (torch.randn(rank_v, HIDDEN, device=dev) / 64).half()
+    b = (torch.randn(H, Rk, D, device=dev) * Rk ** -0.5).half()
+    wo = (torch.randn(HIDDEN, H * Rv, device=dev) * 0.01).half()
+    kc, km = q.quantize_pack(torch.randn(G, cap, Rk, device=dev, dtype=torch.float16), bits)
+    vc, vm = q.quantize_pack(torch.randn(G, cap, Rv, device=dev, dtype=torch.float16), bits)
+    hidden = torch.randn(HIDDEN, device=dev, dtype=torch.float16)
+    frag = prepare_b(b, G)
+    inv = rope_inv_freq(dev)
+    ws = torch.empty(lib.palu_decode_workspace_bytes(H, G, D, cap + 8, Rv), dtype=torch.uint8, device=dev)
+    out = torch.empty(HIDDEN, dtype=torch.float16, device=dev)
+    scores = torch.empty(H, (L + 7) // 8 * 8, dtype=torch.float16, device=dev)
+    ctx = torch.empty(H, Rv, dtype=torch.float16, device=dev)
+    pvws = torch.empty(lib.palu_pv_workspace_bytes(H, G, cap, Rv), dtype=torch.uint8, device=dev)
+    q_buf = torch.randn(H * D, device=dev).half()
+    s = _lib.current_stream
+
+    def step():
+        _lib.check(lib.palu_decode_step_q(
+            hidden.data_ptr(), wq.data_ptr(), wq.stride(0), vtk.data_ptr(), vtk.stride(0), vtv.data_ptr(), vtv.stride(0),
+            frag.data_ptr(), wo.data_ptr(), wo.stride(0),
+            kc.data_ptr(), kc.stride(0), kc.stride(1), km.data_ptr(), km.stride(0), km.stride(1),
+            vc.data_ptr(), vc.stride(0), vc.stride(1), vm.data_ptr(), vm.stride(0), vm.stride(1),
+            0, inv.data_ptr(), out.data_ptr(), 0, 0, ws.data_ptr(), cap + 8, H, G, D, HIDDEN, Rk, Rv, bits, Lp, Lp,
+            s()), "decode_step_q")
+
+    def k_abx():
+        _lib.check(lib.palu_abx_rope_q(q_buf.data_ptr(), D, 1, frag.data_ptr(), kc.data_ptr(), kc.stride(0), kc.stride(1),
+                                       km.data_ptr(), km.stride(0), km.stride(1), scores.data_ptr(), scores.stride(0),
+                                       H, G, L, Rk, D, bits, inv.data_ptr(), 0, s()), "abx_q")
+
+    def k_pv():
+        _lib.check(lib.palu_softmax_pv_q(scores.data_ptr(), scores.stride(0), 0, vc.data_ptr(), vc.stride(0), vc.stride(1),
+                                         vm.data_ptr(), vm.stride(0), vm.stride(1), ctx.data_ptr(), 0, 0, pvws.data_ptr(),
+                                         H, G, L, Rv, bits, math.sqrt(D), s()), "pv_q")
+    replay = graph_of(step)
+    _, ms = time_loop(replay, steps, 10, torch.cuda.synchronize)
+    us = ms * 1e3 / steps
+    alg = alg_bytes_q(rank_k, rank_v, L, bits)
+    rec = {"workload": "%s: rank_k=%d rank_v=%d prompt_len=%d %d-bit packed latents (asym, per (token, group) row)"
+                       % (name, rank_k, rank_v, Lp, bits),
+           "step_us": round(us, 2), "step_algorithmic_bytes": alg["step"],
+           "step_hbm_frac": round(alg["step"] / us * 1e-3 / HBM_PEAK_GBPS, 4), "kernels": {}}
+    for kn, fn in (("abx", k_abx), ("softmax_pv", k_pv)):
+        _, kms = time_loop(fn, 50, 5, torch.cuda.synchronize)
+        kus = kms * 1e3 / 50
+        rec["kernels"][kn] = {"us": round(kus, 2), "algorithmic_bytes": alg[kn],
+                              "hbm_frac": round(alg[kn] / kus * 1e-3 / HBM_PEAK_GBPS, 4)}
+    return rec
+
+
+def bench_c5_slice(steps, dev):
+    """BASELINE config 5, what ONE of the 8 GPUs runs per step: its latent group (G=1, H=4) of the rank 1024/3072 model at
+    prompt_len 256k -- qkv for its heads, attention core (the fused single-kernel path is selected for G=1), no o_proj
+    (that follows the all-gather).  The RCCL leg needs 8 GPUs and is measured by `bench.py --gpus 8`."""
+    from palu_amd import _lib
+    from palu_amd.kernel import head_parallel as hp
+    Lp, Rk, Rv = 262144, 128, 384
+    plan = hp.make_plan(8, 0, H, G, D, Rk, Rv)
+    torch.manual_seed(99)
+    full = {"wq": (torch.randn(H * D, HIDDEN, device=dev) / 64).half(),
+            "vt_k": (torch.randn(G * Rk, HIDDEN, device=dev) / 64).half(),
+            "vt_v": (torch.randn(G * Rv, HIDDEN, device=dev) / 64).half(),
+            "b": (torch.randn(H, Rk, D, device=dev) * Rk ** -0.5).half(),
+            "wo": torch.zeros(1, 1, device=dev).half()}
+    w = {k_: v_.contiguous() for k_, v_ in hp.shard_weights(plan, full).items()}
+    cap = Lp + 64
+    kc = torch.randn(1, cap, Rk, device=dev, dtype=torch.float16)
+    vc = torch.randn(1, cap, Rv, device=dev, dtype=torch.float16)
+    hidden = torch.randn(HIDDEN, device=dev, dtype=torch.float16)
+    dec = hp.HeadParallelDecoder(plan, w, kc, vc, HIDDEN)
+    replay = graph_of(lambda: dec.local_step(hidden, Lp, Lp))
+    _, ms = time_loop(replay, steps, 10, torch.cuda.synchronize)
+    us = ms * 1e3 / steps
+    L = Lp + 1
+    byt = 2 * L * (Rk + Rv) + 2 * 4 * Rk * D + 2 * HIDDEN * (4 * D + Rk + Rv)
+    return {"workload": "config-5 per-GPU slice: G=1 H=4 rank_k=1024/8 rank_v=3072/8 prompt_len=262144 fp16 (qkv + attention "
+                        "core of one rank, before the all-gather)",
+            "attend_us": round(us, 2), "algorithmic_bytes": byt, "hbm_frac": round(byt / us * 1e-3 / HBM_PEAK_GBPS, 4),
+            "fused_attention_core": bool(_lib.lib.palu_decode_attn_preferred(4, 1, Rk, Rv, D))}
 
 
 def main():
@@ -112,6 +257,8 @@ def main():
     ap.add_argument("--rank_v", type=int, default=3072)
     ap.add_argument("--prompt_len", type=int, default=65536)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--no_graph", action="store_true", help="launch the step directly instead of replaying a captured hipGraph")
+    ap.add_argument("--no_extra_configs", action="store_true", help="skip the config 3/4/5 sub-records")
     ap.add_argument("--cpu_sample_len", type=int, default=0, help="positions used for the CPU baseline (0 = full)")
     args = ap.parse_args()
 
@@ -162,7 +309,11 @@ def main():
         dec.step(hidden, Lp, Lp)
 
     sync()
-    ms, ev_ms = time_loop(step, args.steps, args.warmup, sync)
+    use_graph = world == 1 and not args.no_graph
+    # the reference harness replays a captured graph of the step (run_latency_attention.py:81-90, --cache_graph); the
+    # launches are the same 5 kernels either way
+    run = graph_of(step) if use_graph else step
+    ms, ev_ms = time_loop(run, args.steps, args.warmup, sync)
     t = torch.tensor([ms], device=dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -225,7 +376,8 @@ def main():
                                    "H=32 D=128 hidden=4096 gs=4 G=8 rank_k=%d rank_v=%d prompt_len=%d fp16 latents batch=1"
                                    % (rank_k, rank_v, Lp),
                        "parallelism": "head-group x%d + RCCL all-gather" % world if world > 1 else "single GPU",
-                       "kernels_per_step": 5 if world == 1 else 6},
+                       "kernels_per_step": 5 if world == 1 else 6,
+                       "launch": "hipGraph replay of the captured step" if use_graph else "direct launches"},
             "step_algorithmic_bytes": step_b,
             "step_hbm_GBps": round(step_b / us_step * 1e-3, 1),
             "step_hbm_frac": round(step_b / us_step * 1e-3 / HBM_PEAK_GBPS, 4),
@@ -254,13 +406,31 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cl = args.cpu_sample_len or L
             t0 = time.perf_counter()
-            cpu_us = cpu_baseline(rank_k, rank_v, cl)
-            rec["cpu_baseline"] = {"value": round(cpu_us, 1), "unit": "us", "cores": torch.get_num_threads(),
-                                   "kind": "port",
+            cpu_min, cpu_med, cpu_in, cpu_out = cpu_baseline(rank_k, rank_v, cl)
+            rec["cpu_baseline"] = {"value": round(cpu_min, 1), "median": round(cpu_med, 1), "unit": "us",
+                                   "cores": torch.get_num_threads(), "kind": "port",
                                    "sample": "oracle.decode_step (CPU port of the reference's PyTorch decode branch) at "
-                                             "the same shapes, %d cached positions, 1 timed run after 1 warm-up; host %s"
-                                             % (cl, _cpu_model()),
+                                             "the same shapes, %d cached positions, min / median of 3 timed runs after 1 "
+                                             "warm-up; host %s" % (cl, _cpu_model()),
                                    "seconds_spent": round(time.perf_counter() - t0, 1)}
+            # parity of the HIP step against the oracle output just computed, same inputs, full size
+            pmax, pscale = gpu_step_parity(cpu_in, cpu_out, cl)
+            rec["parity_max_abs"] = round(pmax, 6)
+            rec["parity"] = {"max_abs_diff_vs_oracle": round(pmax, 6), "oracle_out_max_abs": round(pscale, 5),
+                             "positions": cl, "tolerance": "rtol=atol=1e-3 (test_palu_attention.py:183-195)",
+                             "ok": bool(pmax <= 1e-3 + 1e-3 * pscale)}
+        if world == 1 and not args.no_extra_configs:
+            sub = {}
+            for nm, rk_, rv_, lp_, bits_ in (("C3", 1024, 3072, 65536, 3), ("C4", 512, 1536, 131072, 4)):
+                try:
+                    sub[nm] = bench_quant_config(nm, rk_, rv_, lp_, bits_, max(50, args.steps // 2), dev)
+                except Exception as e:                      # noqa: BLE001 -- a sub-record must not kill the headline line
+                    sub[nm] = {"error": repr(e)[:200]}
+            try:
+                sub["C5_per_gpu_slice"] = bench_c5_slice(max(50, args.steps // 2), dev)
+            except Exception as e:                          # noqa: BLE001
+                sub["C5_per_gpu_slice"] = {"error": repr(e)[:200]}
+            rec["configs"] = sub
         print(json.dumps(rec), flush=True)
     if dist is not None:
         dist.barrier()

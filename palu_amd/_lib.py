@@ -90,6 +90,16 @@ def check(code: int, what: str = ""):
         raise PaluError(f"{what}: {msg} (code {code})")
 
 
-def current_stream() -> int:
+def current_stream(device=None) -> int:
+    """Stream handle the launches go to.  The library launches on the PROCESS's current device (hipGetDevice), so callers
+    working on tensors of another GPU wrap their calls in `on_device(t)`; passing the device here only selects whose
+    current stream is returned."""
     import torch
-    return torch.cuda.current_stream().cuda_stream
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def on_device(t):
+    """Context manager: make `t`'s GPU the current device for the enclosed library calls (the C ABI takes raw
+    pointers and uses the current device for launches, CU counts and workspace sizing)."""
+    import torch
+    return torch.cuda.device(t.device)

@@ -6,6 +6,11 @@ namespace {
 
 template <int NKS, int NMB, bool FOLD>
 int launch_abx_fast(const AbxParams& p, int nwg, hipStream_t stream) {
+  // positions beyond 2^18: the second-order angle correction (abx_rope_kernel.h, ORDER2)
+  if ((int64_t)p.pos0 + p.L > 262144) {
+    static bool attr_done2 = false;
+    return launch_kernel(abx_rope_kernel<NKS, NMB, FOLD, false, 0, true>, abx_smem_fast(NKS), &attr_done2, p, nwg, stream);
+  }
   static bool attr_done = false;
   return launch_kernel(abx_rope_kernel<NKS, NMB, FOLD>, abx_smem_fast(NKS), &attr_done, p, nwg, stream);
 }

@@ -366,7 +366,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_generic_kernel(AbxParams
 // Software pipeline: the MFMAs of block b+1 and the RoPE/reduction epilogue of block b are
 // independent instruction streams in one basic block (two accumulator sets), so the matrix pipe
 // and the VALU overlap inside a wave as well as across the two waves of a SIMD.
-template <int NKS, int NMB, bool FOLD, bool TIMING = false, int QBITS = 0>
+// ORDER2: keep the lo^2/2 term of the angle correction (needed once positions exceed 2^18, see chunk t == 0).
+template <int NKS, int NMB, bool FOLD, bool TIMING = false, int QBITS = 0, bool ORDER2 = false>
 __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
   using Geo = LdsGeom<NKS>;
   constexpr int HPW = 2 * NMB;
@@ -656,12 +657,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
     auto chunk = [&](int c) {
       const int j = c / CPP, t = c % CPP;
       if (t == 0) {
-        // cos/sin at the oracle's fp32-rounded angle fl(l*f): exact angle = ang + lo (first order in lo;
-        // the dropped term lo^2/2 is < 3.1e-5 for positions < 2^18)
+        // cos/sin at the oracle's fp32-rounded angle fl(l*f): exact angle = ang + lo.  First order in lo drops
+        // lo^2/2 < 3.1e-5 for positions < 2^18 (|lo| <= half an ulp of the angle); the host selects ORDER2 beyond that
+        // (palu_abx_rope_f16: pos0 + L > 262144), e.g. the harness's max_position_embeddings = 300000
         const float ang = lf * fr[j];
         const float lo = fmaf(lf, fr[j], -ang);
-        cc = fmaf(lo, sn[j], cs[j]);
-        ss = fmaf(-lo, cs[j], sn[j]);
+        if (ORDER2) {
+          const float hh = 0.5f * lo * lo;
+          cc = fmaf(-hh, cs[j], fmaf(lo, sn[j], cs[j]));
+          ss = fmaf(-hh, sn[j], fmaf(-lo, cs[j], sn[j]));
+        } else {
+          cc = fmaf(lo, sn[j], cs[j]);
+          ss = fmaf(-lo, cs[j], sn[j]);
+        }
         asm volatile("" : "+v"(cc), "+v"(ss));
       } else if (t <= NMB) {
         const int mb = t - 1;

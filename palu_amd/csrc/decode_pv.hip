@@ -12,6 +12,7 @@
 #include <stdlib.h>
 
 #include "palu_common.h"
+#include "pv_mfma.h"
 
 namespace {
 
@@ -236,6 +237,7 @@ struct PvQParams {
   float* ml;
   int G, gs, L, Rv, nsplit, rps;
   float inv_scale;
+  int exp_flags;   // PALU_PVQ_EXP (timing experiments of the matrix-core kernel; results are wrong when set)
 };
 
 // one thread owns a 16-code column chunk (8 bytes at 4 bit, 6 bytes at 3 bit) and walks the rows in PAIRS:
@@ -433,6 +435,243 @@ __global__ __launch_bounds__(PV_THREADS) void pv_partial_q_kernel(PvQParams p) {
       for (int q = 0; q < rpp; ++q) s += redb[(size_t)(q * cpr + c) * 16 + j];
       part[h * p.Rv + r] = s;
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Quantised V latents on the matrix cores (pv_mfma.h).  The VALU kernel above spends 3-4.5 instructions per code
+// (extraction + one v_dot2 per head); here a code costs one extraction step and nothing per head:
+//   packed codes --coalesced global loads, thread = one 32-code chunk of a [32*NRH rows][Rv] tile, PF tiles in flight-->
+//     registers --(1024 + code) fp16 pairs: v_and_or / v_bfe + v_lshl_or--> ds_write_b128 into [32 rows][64 codes] fp16
+//     unit images (the XOR-swizzled layout of pv_mfma.h, double buffered, one barrier per tile)
+//     --ds_read_b64_tr_b16--> v_mfma_f32_16x16x32_f16
+// with B = w = fp16(e^(x-m) * scale_row):   sum_l w_l (1024 + c_l)  -  sum_l w_l (1024 + z_l)  =  sum_l p_l s_l (c_l - z_l).
+// Wave (slice cs, phase uh) owns 64 latent columns of every NRH-th 32-row unit; threads = Rv * NRH, so a tile is exactly
+// one chunk per thread.  The logits are evaluated twice (maximum, then weights) instead of being parked in LDS.
+template <int BITS>
+static __device__ __forceinline__ void unpack32(const unsigned (&w)[BITS], unsigned (&o)[16]) {
+  if (BITS == 4) {
+    // dword d = codes c0..c7: (d >> 4i) & 0x000F000F = (c_i, c_{i+4}) -> image column order [c0 c4 c1 c5 c2 c6 c3 c7]
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[4 * d + i] = ((w[d] >> (4 * i)) & 0x000F000Fu) | 0x64006400u;
+  } else {
+    // 6-bit field f = (c_2i, c_2i+1) at bit 6i of the 96-bit row chunk; f | f << 13 puts c_2i+1 at bits 16..18
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int bit = 6 * i, dw = bit >> 5, sh = bit & 31;
+      unsigned f;
+      if (sh + 6 <= 32) {
+        f = __builtin_amdgcn_ubfe(w[dw], sh, 6);
+      } else {
+        f = __builtin_amdgcn_alignbit(w[(dw + 1) % BITS], w[dw], sh) & 0x3Fu;
+      }
+      o[i] = ((f | (f << 13)) & 0x00070007u) | 0x64006400u;
+    }
+  }
+}
+
+template <int GS, int BITS, int NCS, int NRH>
+__global__ __launch_bounds__(64 * NCS * NRH) void pv_partial_qm_kernel(PvQParams p) {
+  constexpr int NWV = NCS * NRH, NTH = 64 * NWV, BT = 3, TR = 32 * NRH, CR = 2 * NCS;   // CR: 32-code chunks per row
+  // unit images are 4096 + 128 bytes apart and slice cs XORs its 32-byte segments with (cs >> 1) & 3 on top of the row
+  // key: the 8 lanes of a ds_write_b128 group (4 slices x 2 halves of one row) then hit 8 different 16-byte bank groups
+  // (4 KB apart with the plain layout they were 4-way conflicts, and the LDS write port was the kernel's bottleneck)
+  constexpr int IMG = 4096 + 128;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const unsigned smem_lds = (unsigned)reinterpret_cast<uintptr_t>(smem_raw);
+  h16* wl = reinterpret_cast<h16*>(smem_raw);                        // [4][rps] fp16 weights (heads >= GS: zeros)
+  const unsigned img_off = (unsigned)(4 * p.rps * sizeof(h16));      // [2 buffers][NWV][4 KB] unit images
+  // block-reduction scratch behind the images (no static __shared__: the image addresses must stay 128-byte aligned)
+  float (*shg)[GS][NWV] = reinterpret_cast<float (*)[GS][NWV]>(smem_raw + img_off + 2 * NWV * IMG);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = blockIdx.x % p.G;
+  const int split = blockIdx.x / p.G;
+  const int l0 = split * p.rps;
+  const int n = max(0, min(p.L - l0, p.rps));
+  const int nlast = max(n - 1, 0);
+  float* ml = p.ml + ((size_t)(g * p.nsplit + split) * GS) * 2;
+  float* part = p.part + (size_t)(g * p.nsplit + split) * GS * p.Rv;
+
+  // ---- V stream: thread = chunk (row trow of the tile, 32 codes cchunk of the row): consecutive threads read
+  //      consecutive bytes of the packed rows
+  const int trow = tid / CR, cchunk = tid - trow * CR;
+  const unsigned char* cb = p.codes + (int64_t)g * p.sc_g + (int64_t)l0 * p.sc_l + cchunk * (32 * BITS / 8);
+  const int ntile = p.rps / TR;             // every workgroup walks its whole range (rps is a multiple of BT tiles): rows
+                                            // past n are re-reads of row n-1 with weight 0, so the loop is branch-free
+  unsigned rawA[BT][BITS], rawB[BT][BITS];
+  auto load_tile = [&](unsigned (&r)[BITS], int t) {
+    const int row = min(TR * t + trow, nlast);
+    const unsigned* src = reinterpret_cast<const unsigned*>(cb + (int64_t)row * p.sc_l);
+    if (BITS == 4) {
+      const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
+      r[0] = v[0]; r[1] = v[1]; r[2 % BITS] = v[2]; r[3 % BITS] = v[3];
+    } else {
+#pragma unroll
+      for (int e = 0; e < BITS; ++e) r[e] = __builtin_nontemporal_load(src + e);
+    }
+  };
+  auto load_batch = [&](unsigned (&r)[BT][BITS], int t) {
+#pragma unroll
+    for (int j = 0; j < BT; ++j) load_tile(r[j], t + j);
+  };
+  load_batch(rawA, 0);   // in flight while the softmax statistics are computed
+
+  // ---- phase A: the raw scores (and mask, (scale, zero)) of this thread's <= MAXR rows are requested together (one
+  //      memory round trip), the scaled logits stay in registers between the maximum and the weight pass
+  constexpr int MAXR = (2048 + NTH - 1) / NTH;
+  h16 sc[MAXR][GS], mk[MAXR];
+  unsigned mt[MAXR];
+  const h16* mb = p.meta + (int64_t)g * p.sm_g + (int64_t)l0 * p.sm_l;
+  const h16* mkp = p.mask ? p.mask : p.scores + (int64_t)g * GS * p.ss_h;   // branch-free: a dummy row when there is no mask
+#pragma unroll
+  for (int k = 0; k < MAXR; ++k) {
+    const int ic = min(tid + k * NTH, nlast);
+#pragma unroll
+    for (int h = 0; h < GS; ++h) sc[k][h] = p.scores[(int64_t)(g * GS + h) * p.ss_h + l0 + ic];
+    mk[k] = mkp[l0 + ic];
+    mt[k] = *reinterpret_cast<const unsigned*>(mb + (int64_t)ic * p.sm_l);
+  }
+  float xl[MAXR][GS];
+  float mloc[GS], sloc[GS], corr[GS];
+#pragma unroll
+  for (int h = 0; h < GS; ++h) mloc[h] = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < MAXR; ++k) {
+    const bool ok = tid + k * NTH < n;
+#pragma unroll
+    for (int h = 0; h < GS; ++h) {
+      // fp16 tensor / python float -> fp32 divide, rounded to fp16 (torch semantics); then + mask in fp16
+      h16 x16 = (h16)((float)sc[k][h] / p.inv_scale);
+      if (p.mask) x16 = (h16)((float)x16 + (float)mk[k]);
+      xl[k][h] = ok ? (float)x16 : -INFINITY;
+      mloc[h] = fmaxf(mloc[h], xl[k][h]);
+    }
+  }
+  auto block_all = [&](float (&v)[GS], int slot, bool is_max) {
+#pragma unroll
+    for (int h = 0; h < GS; ++h) v[h] = is_max ? wave_max(v[h]) : wave_sum(v[h]);
+    if (lane == 0) {
+#pragma unroll
+      for (int h = 0; h < GS; ++h) shg[slot][h][wv] = v[h];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < GS; ++h) {
+      float r = shg[slot][h][0];
+#pragma unroll
+      for (int k = 1; k < NWV; ++k) r = is_max ? fmaxf(r, shg[slot][h][k]) : r + shg[slot][h][k];
+      v[h] = r;
+    }
+  };
+  block_all(mloc, 0, true);
+#pragma unroll
+  for (int h = 0; h < GS; ++h) {
+    sloc[h] = 0.f;
+    corr[h] = 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < MAXR; ++k) {
+    const int i = tid + k * NTH;
+    if (i < p.rps) {
+      const h16x2 m2 = __builtin_bit_cast(h16x2, mt[k]);
+#pragma unroll
+      for (int h = 0; h < 4; ++h) {
+        h16 wq = (h16)0.f;
+        if (h < GS && i < n) {
+          const float e = (mloc[h % GS] == -INFINITY) ? 0.f : __expf(xl[k][h % GS] - mloc[h % GS]);
+          sloc[h % GS] += e;
+          wq = (h16)(e * (float)m2[0]);
+          corr[h % GS] = fmaf((float)wq, 1024.f + (float)m2[1], corr[h % GS]);
+        }
+        wl[h * p.rps + i] = wq;
+      }
+    }
+  }
+  block_all(sloc, 1, false);
+  block_all(corr, 2, false);
+  if (tid == 0) {
+#pragma unroll
+    for (int h = 0; h < GS; ++h) {
+      ml[2 * h] = mloc[h];
+      ml[2 * h + 1] = sloc[h];
+    }
+  }
+  // (wl is published by the first barrier of the loop below)
+
+  // ---- phase B: unpack -> unit images -> barrier -> transpose read -> MFMA
+  pvm::Lane<4> ln = pvm::make_lane<4>(lane, 0, 0u, p.rps * 2);
+  ln.rd ^= (unsigned)((((wv % NCS) >> 1) & 3) << 5);                   // the slice's segment XOR (see IMG)
+  // where this thread's chunk goes: unit image (phase trow / 32, slice cchunk / 2), row trow % 32, the two 32-byte
+  // segments 2 * half and 2 * half + 1 (16 codes each), XOR-swizzled by the row key
+  const int w_uh = trow >> 5, w_row = trow & 31, w_half = cchunk & 1, w_cs = cchunk >> 1;
+  const unsigned wimg = smem_lds + img_off + (unsigned)((w_uh * NCS + w_cs) * IMG + w_row * 128);
+  const int w_key = pvm::Cfg<4>::key(w_row) ^ ((w_cs >> 1) & 3);
+  const unsigned wr0 = wimg + (unsigned)(((2 * w_half) ^ w_key) * 32);
+  const unsigned wr1 = wimg + (unsigned)(((2 * w_half + 1) ^ w_key) * 32);
+  const int uh = wv / NCS;                                            // this wave consumes image wv = uh * NCS + cs
+  const unsigned rimg = smem_lds + img_off + (unsigned)(wv * IMG);
+  f32x4 acc[4];
+#pragma unroll
+  for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+  auto consume = [&](const unsigned (&r)[BT][BITS], int t0) {
+#pragma unroll
+    for (int j = 0; j < BT; ++j) {
+      const int t = t0 + j;
+      const unsigned boff = (unsigned)((t & 1) * NWV * IMG);
+      unsigned o[16];
+      unpack32<BITS>(r[j], o);
+      *(lds_u32x4*)(uintptr_t)(wr0 + boff) = u32x4{o[0], o[1], o[2], o[3]};
+      *(lds_u32x4*)(uintptr_t)(wr0 + boff + 16) = u32x4{o[4], o[5], o[6], o[7]};
+      *(lds_u32x4*)(uintptr_t)(wr1 + boff) = u32x4{o[8], o[9], o[10], o[11]};
+      *(lds_u32x4*)(uintptr_t)(wr1 + boff + 16) = u32x4{o[12], o[13], o[14], o[15]};
+      __syncthreads();   // tile t is complete; tile t-1's buffer is rewritten only after every wave passed this point
+      pvm::pv_unit<4>(acc, ln, rimg + boff, smem_lds + (unsigned)(32 * (t * NRH + uh) * 2));
+    }
+  };
+  // two register batches of BT tiles, one a full batch ahead (the streaming structure of pv_partial_kernel): the
+  // compiler's waits then keep a batch in flight; in-place refills of a single ring made it drain vmcnt(0) per iteration
+  for (int t = 0;;) {
+    load_batch(rawB, t + BT);
+    consume(rawA, t);
+    t += BT;
+    if (t >= ntile) break;
+    load_batch(rawA, t + BT);
+    consume(rawB, t);
+    t += BT;
+    if (t >= ntile) break;
+  }
+  // ---- sum the row phases, subtract the zero-point term, write the partial context
+  __syncthreads();   // all images are dead: reuse the area as red [NRH][NCS][GS][64]
+  float* red = reinterpret_cast<float*>(smem_raw + img_off);
+  {
+    // D layout (pv_mfma.h): lane l, reg j -> image column 16*ct + 4*(l/16) + j, head l % 16
+    const int cs = wv % NCS;
+    const int hn = lane & 15, qd = lane >> 4;
+    if (hn < GS) {
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int pc = 16 * ct + 4 * qd + j;                                   // image column inside the slice
+          const int col = BITS == 4 ? 8 * (pc >> 3) + ((pc & 7) >> 1) + 4 * (pc & 1) : pc;   // undo the unpack order
+          red[((uh * NCS + cs) * GS + hn) * 64 + col] = acc[ct][j];
+        }
+    }
+  }
+  __syncthreads();
+  for (int o = tid; o < GS * p.Rv; o += NTH) {
+    const int h = o / p.Rv, c = o - h * p.Rv;
+    float cr = corr[0];                       // corr[h] for a runtime h: unrolled select chain (no scratch)
+#pragma unroll
+    for (int hh = 1; hh < GS; ++hh) cr = (h == hh) ? corr[hh] : cr;
+    float sum = -cr;
+#pragma unroll
+    for (int r = 0; r < NRH; ++r) sum += red[((r * NCS + (c >> 6)) * GS + h) * 64 + (c & 63)];
+    part[o] = sum;
   }
 }
 
@@ -645,7 +884,42 @@ extern "C" int palu_softmax_pv_q(const void* scores, int64_t ss_h, const void* m
                    sm_g % 2 == 0 && sm_l % 2 == 0,
                PALU_ERR_ARG, "softmax_pv_q: packed rows / meta must be 4-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  const int rps = pv_rows_per_split(G, L);
+  // matrix-core kernel: gs = 4, Rv a multiple of 64 with a (column slices, row phases) plan, 16-byte aligned 4-bit rows
+  int ncs = 0, nrh = 0;
+  switch (Rv) {
+    case 384: ncs = 6; nrh = 1; break;
+    case 192: ncs = 3; nrh = 2; break;
+    case 256: ncs = 4; nrh = 2; break;
+    case 128: ncs = 2; nrh = 4; break;
+    default: break;
+  }
+  static int qm_enabled = -1;
+  if (qm_enabled < 0) {
+    const char* e = getenv("PALU_PVQ_MFMA");
+    qm_enabled = e ? atoi(e) : 1;
+  }
+  // measured (tools/bench_q_kernels.py, same box): 3-bit C3 49 vs 54 us for the VALU kernel, 4-bit C4 55-62 vs 50 us --
+  // the matrix-core kernel is the default for 3-bit codes only (PALU_PVQ_MFMA=2 forces it for 4-bit as well, 0 turns it off)
+  const bool qm = qm_enabled && gs == 4 && ncs > 0 &&
+                  (bits == 3 || (qm_enabled == 2 && ((uintptr_t)codes & 15) == 0 && sc_g % 16 == 0 && sc_l % 16 == 0));
+  int rps = pv_rows_per_split(G, L);
+  if (qm) {
+    // whole tiles; as many workgroups as are resident at once (PALU_PVQ_WGS per CU, default 2), never more splits than the VALU kernel would use (the workspace bound holds)
+    static int wgs = 0;
+    if (wgs == 0) {
+      const char* e = getenv("PALU_PVQ_WGS");
+      wgs = e ? atoi(e) : 2;
+      if (wgs < 1) wgs = 1;
+    }
+    long long target = ((long long)wgs * palu_num_cus()) / G;
+    if (target < 1) target = 1;
+    long long r2 = (L + target - 1) / target;
+    r2 = (r2 + 383) / 384 * 384;          // whole batches of 3 tiles of 32 * NRH <= 128 rows
+    if (r2 > 1920) r2 = 1920;
+    if (r2 > rps) rps = (int)r2;
+    rps = (rps + 383) / 384 * 384;
+    if (rps > 1920) rps = 1920;
+  }
   const int ns = (L + rps - 1) / rps;
   float* ws = (float*)workspace;
   PvQParams p;
@@ -657,6 +931,38 @@ extern "C" int palu_softmax_pv_q(const void* scores, int64_t ss_h, const void* m
   float* stats = p.ml + (size_t)H * ns * 2;
   p.G = G; p.gs = gs; p.L = L; p.Rv = Rv; p.nsplit = ns; p.rps = rps;
   p.inv_scale = sqrt_d;
+  {
+    static int ex = -1;
+    if (ex < 0) {
+      const char* e = getenv("PALU_PVQ_EXP");
+      ex = e ? atoi(e) : 0;
+    }
+    p.exp_flags = ex;
+  }
+  if (qm) {
+    const int nwv = ncs * nrh;
+    const size_t ldsq = (size_t)8 * rps + (size_t)2 * nwv * (4096 + 128) + (size_t)3 * 4 * nwv * sizeof(float);
+    dim3 gridq(G * ns), blockq(64 * nwv);
+#define PALU_PVQM(NCSV, NRHV)                                                                                  \
+  if (bits == 4) hipLaunchKernelGGL((pv_partial_qm_kernel<4, 4, NCSV, NRHV>), gridq, blockq, ldsq, s, p);      \
+  else hipLaunchKernelGGL((pv_partial_qm_kernel<4, 3, NCSV, NRHV>), gridq, blockq, ldsq, s, p)
+    if (ncs == 6) { PALU_PVQM(6, 1); }
+    else if (ncs == 3) { PALU_PVQM(3, 2); }
+    else if (ncs == 4) { PALU_PVQM(4, 2); }
+    else { PALU_PVQM(2, 4); }
+#undef PALU_PVQM
+    PALU_LAUNCH_CHECK();
+    int rcq = palu_pv_combine_launch(ws, ctx, H, G, Rv, ns, s);
+    if (rcq) return rcq;
+    if (probs) {
+      int bx = (L + 255) / 256;
+      if (bx > 64) bx = 64;
+      hipLaunchKernelGGL(probs_kernel, dim3(bx, H), dim3(256), 0, s, (const h16*)scores, ss_h, (const h16*)mask,
+                         (const float*)stats, (h16*)probs, sp_h, L, sqrt_d);
+      PALU_LAUNCH_CHECK();
+    }
+    return PALU_OK;
+  }
   size_t lds = (size_t)gs * rps * (sizeof(float) + sizeof(h16));
   if (lds < (size_t)PV_THREADS * 16 * sizeof(float)) lds = (size_t)PV_THREADS * 16 * sizeof(float);
   dim3 grid(G * ns), block(PV_THREADS);

@@ -38,9 +38,20 @@ def set_fold(enable: bool) -> bool:
     return bool(_lib.lib.palu_abx_set_fold(1 if enable else 0))
 
 
+def invalidate_b(b: torch.Tensor | None = None) -> None:
+    """Drop the cached fragments of `b` (or of every tensor).  The cache key is (object, _version, data_ptr); writes
+    through `.data` (`b.data.copy_(...)`, the idiom of weight loading and of fuse_hadamard) change none of them, so code
+    that mutates B that way calls this afterwards (LlamaPaluAttention.fuse_hadamard / load_state_dict hooks do)."""
+    if b is None:
+        _bfrag_cache.clear()
+    else:
+        _bfrag_cache.pop(id(b), None)
+
+
 def prepare_b(b: torch.Tensor, num_groups: int) -> torch.Tensor:
     """Lay the weight B [H,R,D] out as MFMA A-operand fragments (palu_abx_prepare_b).  Cached per
-    tensor object + version, because B is a weight (nn.Parameter at kernel/palu_attention.py:114)."""
+    tensor object + version, because B is a weight (nn.Parameter at kernel/palu_attention.py:114); see invalidate_b
+    for in-place updates through `.data`."""
     key = id(b)
     hit = _bfrag_cache.get(key)
     if hit is not None:
@@ -78,15 +89,16 @@ def abx(a: torch.Tensor, b: torch.Tensor, x: torch.Tensor, *, theta: float = 100
         raise ValueError(f"abx: inconsistent shapes a{tuple(a.shape)} b{tuple(b.shape)} x{tuple(x.shape)}")
     if x.stride(2) != 1 or x.stride(1) % 8 or x.stride(0) % 8 or x.data_ptr() % 16:
         x = x.contiguous()
-    frag = prepare_b(b, G)
-    if out is None:
-        out = torch.empty((H, 1, L), dtype=x.dtype, device=x.device)
-    else:
-        assert out.shape == (H, 1, L) and out.dtype == torch.float16 and out.stride(2) == 1
-    inv = rope_inv_freq(x.device, D, theta)
-    _lib.check(_lib.lib.palu_abx_rope_f16(a.data_ptr(), a.stride(0), a.stride(2), frag.data_ptr(),
-                                          x.data_ptr(), x.stride(0), x.stride(1),
-                                          out.data_ptr(), out.stride(0), H, G, L, R, D,
-                                          inv.data_ptr(), int(pos_offset), _lib.current_stream()),
-               "palu_abx_rope_f16")
+    with _lib.on_device(x):                 # launches go to the current device: make it the tensors' GPU
+        frag = prepare_b(b, G)
+        if out is None:
+            out = torch.empty((H, 1, L), dtype=x.dtype, device=x.device)
+        else:
+            assert out.shape == (H, 1, L) and out.dtype == torch.float16 and out.stride(2) == 1
+        inv = rope_inv_freq(x.device, D, theta)
+        _lib.check(_lib.lib.palu_abx_rope_f16(a.data_ptr(), a.stride(0), a.stride(2), frag.data_ptr(),
+                                              x.data_ptr(), x.stride(0), x.stride(1),
+                                              out.data_ptr(), out.stride(0), H, G, L, R, D,
+                                              inv.data_ptr(), int(pos_offset), _lib.current_stream()),
+                   "palu_abx_rope_f16")
     return out

@@ -56,7 +56,7 @@ class ShardPlan:
 def make_plan(world: int, rank: int, num_heads: int, num_groups: int, head_dim: int, rank_k: int, rank_v: int) -> ShardPlan:
     if num_groups % world != 0:
         raise ValueError(f"head-group parallelism needs num_groups ({num_groups}) divisible by world size ({world}); "
-                         "use split-L for fewer groups than GPUs (not implemented)")
+                         "use SplitLDecoder (split-L) for fewer groups than GPUs")
     if not 0 <= rank < world:
         raise ValueError("rank out of range")
     return ShardPlan(world, rank, num_heads, num_groups, head_dim, rank_k, rank_v)

@@ -13,8 +13,9 @@ Same class names, constructor arguments, method names, return tuples and error b
   * the module does not inherit from `transformers.LlamaAttention` (the reference pins 4.37.2; the
     attributes it relied on are gone in 5.x), it only reads the config fields the reference reads.
 
-The prefill branch (q_len > 1, :196-206) is composed from torch ops (rocBLAS) for now -- it is the
-"next" row N1 of SURVEY.md 8(f), not part of the decode hot path.
+The prefill branch (q_len > 1, :196-206; row N1 of SURVEY.md 8(f)) runs on the flash-style HIP kernel
+`palu_prefill_attn_f16` (`_prefill_flash`); a torch-op composition of the same branch remains only for what that
+kernel does not take (output_attentions, arbitrary masks, non-standard position ids, un-fused o_proj).
 """
 from __future__ import annotations
 
@@ -27,7 +28,7 @@ from torch import nn
 
 from .. import _lib
 from .abx_rope import abx as recompute_k_gemv  # same alias as kernel/palu_attention.py:13
-from .abx_rope import prepare_b, rope_inv_freq
+from .abx_rope import invalidate_b, prepare_b, rope_inv_freq
 
 __all__ = ["HeadwiseLowRankModule", "LlamaPaluAttention", "LatentCache", "QuantLatentCache", "DynamicCache",
            "build_b", "fuse_wo"]
@@ -314,6 +315,13 @@ class HeadwiseLowRankModule(nn.Module):
             nn.init.normal_(lin.weight)
             ups.append(lin)
         self.U_list = nn.ModuleList(ups)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        # load_state_dict copies into B.data in place: neither B._version nor data_ptr moves, so the cached MFMA
+        # fragments of the old weight must be dropped explicitly
+        super()._load_from_state_dict(*args, **kwargs)
+        if hasattr(self, "B"):
+            invalidate_b(self.B)
 
     @staticmethod
     def _check3(x):
@@ -603,11 +611,32 @@ class LlamaPaluAttention(nn.Module):
             self.o_proj.weight.data = apply_hadamard(w.reshape(w.shape[0], self.num_heads, Rv).contiguous()).reshape(w.shape)
         return self
 
+    def _hip_step_shapes_ok(self, cache) -> bool:
+        """What palu_decode_step_f16 / _q accept (everything else takes the general path BEFORE anything is written to
+        the cache): fp16 -- gs in {1,2,4,8}, ranks multiples of 8; packed cache -- gs in {1,2,4},
+        (bits, Rk) in {(4,32),(4,64),(4,128),(3,128)} (palu_abx_rope_q) and Rv % 32 == 0 (palu_softmax_pv_q)."""
+        gs, Rk, Rv = self.group_size, self.group_rank_k, self.group_rank_v
+        if isinstance(cache, QuantLatentCache):
+            bits = cache.n_bits
+            return (gs in (1, 2, 4) and Rv % 32 == 0 and Rv // 16 <= 256
+                    and ((bits == 4 and Rk in (32, 64, 128)) or (bits == 3 and Rk == 128)))
+        return gs in (1, 2, 4, 8) and Rk % 8 == 0 and Rv % 8 == 0 and Rv // 8 <= 256
+
     # -- forward -----------------------------------------------------------------------------
     def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                 position_ids: Optional[torch.LongTensor] = None, past_key_value=None,
                 output_attentions: bool = False, golden_kernel: bool = False, **kwargs
                 ) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[object]]:
+        if hidden_states.is_cuda:
+            # the C ABI launches on the process's current device: make it the tensors' GPU for the whole call
+            with _lib.on_device(hidden_states):
+                return self._forward(hidden_states, attention_mask, position_ids, past_key_value, output_attentions,
+                                     golden_kernel, **kwargs)
+        return self._forward(hidden_states, attention_mask, position_ids, past_key_value, output_attentions,
+                             golden_kernel, **kwargs)
+
+    def _forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None,
+                 output_attentions=False, golden_kernel=False, **kwargs):
         if "padding_mask" in kwargs:
             warnings.warn("Passing `padding_mask` is deprecated; use `attention_mask` instead.")
         bsz, q_len, _ = hidden_states.size()
@@ -624,8 +653,7 @@ class LlamaPaluAttention(nn.Module):
                 f"Attention mask should be of size {(bsz, 1, q_len, kv_seq_len)}, but is {attention_mask.size()}")
 
         fused_o = self.o_proj.in_features == self.fused_hidden_dim_o
-        hip_step_ok = (self.q_proj.bias is None and self.head_dim == 128
-                       and self.group_size in ((1, 2, 4) if isinstance(past_key_value, QuantLatentCache) else (1, 2, 4, 8)))
+        hip_step_ok = self.q_proj.bias is None and self.head_dim == 128 and self._hip_step_shapes_ok(past_key_value)
         if (q_len == 1 and bsz == 1 and isinstance(past_key_value, (LatentCache, QuantLatentCache)) and fused_o
                 and hip_step_ok and hidden_states.is_cuda and hidden_states.dtype == torch.float16
                 and hasattr(self.k_proj, "B")):
@@ -651,8 +679,12 @@ class LlamaPaluAttention(nn.Module):
                 if position_ids is None:
                     position_ids = torch.arange(past, kv_seq_len, device=hidden_states.device).unsqueeze(0)
                 pos = position_ids.to(hidden_states.device).reshape(-1, q_len)
-                out = self._prefill_flash(hidden_states, pos, past_key_value, causal)
-                return out, None, past_key_value
+                # the flash path rotates key row j at position j: only valid for the standard ids past..past+q_len-1
+                # (offset / left-padded ids take the general path, which rotates the new keys with position_ids)
+                std = torch.arange(past, kv_seq_len, device=pos.device)
+                if pos.shape[0] == 1 and bool((pos[0] == std).all()):
+                    out = self._prefill_flash(hidden_states, pos, past_key_value, causal)
+                    return out, None, past_key_value
 
         # ---- general path (no_fusion, foreign cache objects, arbitrary masks, output_attentions): torch composition
         query_states = self.q_proj(hidden_states).view(bsz, q_len, H, D).transpose(1, 2)

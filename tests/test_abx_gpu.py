@@ -106,6 +106,41 @@ def test_abx_long_context_positions():
     assert e_mine <= max(1.5 * e_ref, 2.0 ** -10), (e_mine, e_ref)
 
 
+def _scores_f64_at(a, b, x, pos0):
+    """fp64 evaluation of the abx math with the oracle's fp32-rounded angles fl32(l * inv_freq) at rows pos0 + l
+    (pytorch_reference.py:5-6, abx_rope.py:152-171)"""
+    H, R, D = b.shape
+    G, L, _ = x.shape
+    keys = torch.matmul(x.double()[:, None], b.double().reshape(G, H // G, R, D)).reshape(H, L, D)
+    pos = torch.arange(pos0, pos0 + L, dtype=torch.int64).to(torch.float32)
+    ang = torch.outer(pos, oracle.rope_inv_freq(D)).double()
+    ang = torch.cat((ang, ang), dim=-1)
+    keys = oracle.rope_rotate(keys, ang.cos(), ang.sin())
+    return torch.matmul(a.double(), keys.transpose(-1, -2))
+
+
+@pytest.mark.parametrize("R", [128, 64])
+def test_abx_positions_beyond_2_18(R):
+    """run_latency_attention.py builds its model with max_position_embeddings = 300000: past 2^18 positions the fast
+    kernel switches to the second-order angle correction (ORDER2).  Window [290000, 300000) against the fp64 value of
+    the oracle's formula; the first-order kernel on the same window (forced through a small pos0 + huge L is not
+    possible, so the check is the error level itself) must stay at the fp16 output rounding."""
+    rng = np.random.default_rng(R)
+    H, G, L, pos0 = 32, 8, 10000, 290000
+    a = torch.from_numpy(rng.standard_normal((H, 1, 128)).astype(np.float16))
+    b = torch.from_numpy((rng.standard_normal((H, R, 128)) / np.sqrt(R)).astype(np.float16))
+    x = torch.from_numpy(rng.standard_normal((G, L, R)).astype(np.float16))
+    got = _abx()(a.cuda(), b.cuda(), x.cuda(), pos_offset=pos0).cpu()
+    exact = _scores_f64_at(a, b, x, pos0)
+    scale = exact.abs().max().item()
+    err = (got.double() - exact).abs().max().item() / scale
+    assert err <= 2.0 ** -10, err          # half an fp16 ulp of the largest score + the fp16 operand roundings
+    # the same rows at small positions give the same error level (the angle correction is not the limiting term)
+    got0 = _abx()(a.cuda(), b.cuda(), x.cuda(), pos_offset=0).cpu()
+    err0 = (got0.double() - _scores_f64_at(a, b, x, 0)).abs().max().item() / scale
+    assert err <= 1.5 * err0 + 1e-5, (err, err0)
+
+
 def test_abx_full_size_c2_properties():
     """BASELINE config 2 shape (H=32, R=128, L=65536): size-independent properties.
     (1) linearity in a; (2) tile independence: scores of rows [s, e) computed on the slice with

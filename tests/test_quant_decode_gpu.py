@@ -63,7 +63,9 @@ def test_softmax_pv_q(bits, Rv, gs, H, L):
                                           math.sqrt(128.0), _lib.current_stream()), "pv_q")
     ref_ctx, ref_p = softmax_pv(scores, deq, want_probs=True)                      # fp16 HIP kernel on dequantised V
     torch.testing.assert_close(ctx, ref_ctx, rtol=1e-3, atol=1e-3)
-    torch.testing.assert_close(probs, ref_p, rtol=0, atol=0)
+    # same logits, same global maximum; the normaliser is summed over a different split structure (the matrix-core
+    # kernel uses larger ranges), so a weight may land on the other side of an fp16 rounding boundary: one ulp
+    torch.testing.assert_close(probs, ref_p, rtol=1e-3, atol=1e-7)
     x = (scores.cpu() / math.sqrt(128.0))
     p64 = torch.softmax(x.double(), dim=-1)
     c64 = torch.matmul(p64.reshape(G, gs, L), deq.cpu().double()).reshape(H, Rv)
