@@ -12,8 +12,10 @@ all resident in HBM before the timed region.  One step = qkv GEMV + q-RoPE + in-
 fused reconstruct-K/RoPE/q.K^T (abx) -> softmax + latent P.V -> o_proj GEMV, i.e. the decode branch of
 kernel/palu_attention.py:147-263 through the C ABI (palu_decode_step_f16).
 
-N > 1: head-group parallel (strong scaling of the same step): rank r owns G/N groups, one RCCL
-all-gather of the [H/N*Rv] fp16 context slice per step, replicated o_proj.
+N > 1: head-group parallel (strong scaling of the same step): rank r owns G/N groups; one RCCL collective per
+step -- `--oproj sharded` (default): every rank multiplies its context slice by its 1/N column block of W_o' and
+the ranks all-reduce the [hidden] fp32 partials (16 KiB); `--oproj replicated`: all-gather of the [H/N*Rv] fp16
+slices and the full o_proj on every rank.  `collective_us` is the collective alone (CUDA events, max over ranks).
 
 Prints ONE JSON line (rank 0).  `value` = decode-step microseconds (lower is better); `roofline` is the
 dominant kernel of the step by measured time, `roofline_abx` the fused score kernel the north star
@@ -257,6 +259,8 @@ def main():
     ap.add_argument("--rank_v", type=int, default=3072)
     ap.add_argument("--prompt_len", type=int, default=65536)
     ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--oproj", choices=("replicated", "sharded"), default="sharded",
+                    help="N > 1: all-gather + replicated o_proj, or column-sharded o_proj + all-reduce of the [hidden] partials")
     ap.add_argument("--no_graph", action="store_true", help="launch the step directly instead of replaying a captured hipGraph")
     ap.add_argument("--no_extra_configs", action="store_true", help="skip the config 3/4/5 sub-records")
     ap.add_argument("--cpu_sample_len", type=int, default=0, help="positions used for the CPU baseline (0 = full)")
@@ -291,7 +295,7 @@ def main():
             "vt_v": (torch.randn(rank_v, HIDDEN, device=dev) / 64).half(),
             "b": (torch.randn(H, Rk, D, device=dev) * Rk ** -0.5).half(),
             "wo": (torch.randn(HIDDEN, H * Rv, device=dev) * 0.01).half()}
-    w = {k: v.contiguous() for k, v in hp.shard_weights(plan, full).items()}
+    w = {k: (v.contiguous() if k != "wo" else v) for k, v in hp.shard_weights(plan, full, oproj=args.oproj).items()}
     del full
     Gl = plan.groups_local
     k_cache = torch.randn(Gl, cap, Rk, device=dev, dtype=torch.float16)       # run_latency_attention.py:62-63
@@ -319,6 +323,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ms = float(t.item())
     us_step = ms * 1e3 / args.steps
+    coll_us = None
+    if world > 1:
+        # collective-only latency: CUDA events around the step's one collective, median over 50 steps, max over ranks
+        ts = []
+        for _ in range(50):
+            dec.step(hidden, Lp, Lp, time_collective=True)
+            torch.cuda.synchronize()
+            e0, e1 = dec.t_collective
+            ts.append(e0.elapsed_time(e1) * 1e3)
+        tc = torch.tensor([sorted(ts)[len(ts) // 2]], device=dev)
+        dist.all_reduce(tc, op=dist.ReduceOp.MAX)
+        coll_us = float(tc.item())
 
     rec = None
     if rank == 0:
@@ -375,9 +391,12 @@ def main():
                                    "geometry as built by run_latency_attention.py (LlamaConfig() defaults): "
                                    "H=32 D=128 hidden=4096 gs=4 G=8 rank_k=%d rank_v=%d prompt_len=%d fp16 latents batch=1"
                                    % (rank_k, rank_v, Lp),
-                       "parallelism": "head-group x%d + RCCL all-gather" % world if world > 1 else "single GPU",
+                       "parallelism": ("head-group x%d + RCCL %s" % (world, "all-gather, replicated o_proj" if args.oproj == "replicated"
+                                                                       else "column-sharded o_proj + all-reduce of [hidden] fp32"))
+                       if world > 1 else "single GPU",
                        "kernels_per_step": 5 if world == 1 else 6,
                        "launch": "hipGraph replay of the captured step" if use_graph else "direct launches"},
+            "collective_us": None if coll_us is None else round(coll_us, 2),
             "step_algorithmic_bytes": step_b,
             "step_hbm_GBps": round(step_b / us_step * 1e-3, 1),
             "step_hbm_frac": round(step_b / us_step * 1e-3 / HBM_PEAK_GBPS, 4),

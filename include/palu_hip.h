@@ -128,6 +128,10 @@ int palu_decode_attn_f16(const void* q, int64_t sq_h, int64_t sq_d, const void* 
  *   (replaces DynamicCache.update's torch.cat at :193).  q_out: [H*D] fp16.
  */
 int palu_gemv_f16(const void* W, int64_t ldw, const void* x, void* y, int N, int K, palu_stream_t stream);
+/* Same product, fp32 accumulators written out unrounded (y: [N] fp32): the per-rank partial of a column-sharded o_proj
+ * (kernel/palu_attention.py:254-257): W = this rank's [hidden, H/N*Rv] column block (ldw = H*Rv),
+ * x = its context slice; the ranks all-reduce the partials and round to fp16 once. */
+int palu_gemv_f16_acc32(const void* W, int64_t ldw, const void* x, float* y, int N, int K, palu_stream_t stream);
 int palu_decode_qkv_f16(const void* wq, int64_t ldq, const void* vtk, int64_t ldk, const void* vtv, int64_t ldv,
                         const void* x, void* q_out,
                         void* k_cache, int64_t sk_g, int64_t sk_l, void* v_cache, int64_t sv_g, int64_t sv_l,
@@ -177,6 +181,14 @@ int palu_quantize_pack(const void* x, int64_t sx_g, int64_t sx_l,
                        void* codes, int64_t sc_g, int64_t sc_l, void* meta, int64_t sm_g, int64_t sm_l,
                        void* dequant, int64_t sd_g, int64_t sd_l,
                        int G, int nrows, int R, int bits, palu_stream_t stream);
+/* The other modes of quantize_tensor (quant.py:18-36; flags lt_sym / lt_clip_ratio of utils.py:101-109):
+ * sym != 0: scale = clamp(amax|w|, 1e-5)[* clip] / (2^(b-1) - 1), signed codes; stored in offset binary
+ * (code + 2^(b-1), zero = 2^(b-1)) so that (stored - zero) * scale is the reference's value bit for bit and every decode
+ * kernel works unchanged.  clip_ratio in (0, 1]: max / min (asym) or amax (sym) are scaled before the grid is built. */
+int palu_quantize_pack_ex(const void* x, int64_t sx_g, int64_t sx_l,
+                          void* codes, int64_t sc_g, int64_t sc_l, void* meta, int64_t sm_g, int64_t sm_l,
+                          void* dequant, int64_t sd_g, int64_t sd_l,
+                          int G, int nrows, int R, int bits, int sym, float clip_ratio, palu_stream_t stream);
 int palu_unpack_dequant(const void* codes, int64_t sc_g, int64_t sc_l, const void* meta, int64_t sm_g, int64_t sm_l,
                         void* out, int64_t so_g, int64_t so_l, int G, int nrows, int R, int bits,
                         palu_stream_t stream);

@@ -20,7 +20,7 @@ __all__ = [
     "rope_inv_freq", "rope_cos_sin", "rope_rotate", "abx_scores", "abx_scores_f64",
     "build_b_from_u", "fuse_uv_into_wo", "decode_step", "prefill", "quantize_rows",
     "pack_codes", "unpack_codes", "packed_row_bytes", "dequant_codes",
-    "fwht", "had12", "apply_hadamard", "fuse_hadamard_into_weights",
+    "fwht", "had12", "hadK_for", "HAD_K_ORDER", "apply_hadamard", "fuse_hadamard_into_weights",
 ]
 
 
@@ -337,20 +337,43 @@ def had12() -> torch.Tensor:
     return m
 
 
-def apply_hadamard(x: torch.Tensor) -> torch.Tensor:
-    """x -> x . Had_n / sqrt(n) over the last dim, n = 2^m or 12 * 2^m.
+HAD_K_ORDER = (244, 180, 172, 156, 140, 108, 92, 84, 76, 68, 60, 52, 44, 36, 28, 40, 20, 12)
 
-    Follows hadamard_utils.py:85-90 + :138-147 (matmul_hadU_cuda): for n = 12*2^m the row is
-    viewed as [12, n/12], Sylvester-transformed over the inner axis, then mixed by had12 over
-    the outer axis; one 1/sqrt(n) scale.  (Other K tables of get_hadK :5-83 are out of scope.)
+
+def hadK_for(n: int):
+    """(hadK [K,K] fp32 or None, K): the table get_hadK (hadamard_utils.py:5-83) selects for a width n = K * 2^m --
+    first K in its test order with n % K == 0.  K = 12 is the bordered circulant below; the other 17 factors are the
+    reference's literal matrices, read as data from tests/golden/g8_hadk.npz (written by tests/golden/make_hadk.py)."""
+    for K in HAD_K_ORDER:
+        if n % K == 0:
+            assert ((n // K) & (n // K - 1)) == 0, "n must be K * 2^m"
+            if K == 12:
+                return had12(), 12
+            import os
+            import numpy as np
+            z = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                                     "g8_hadk_tables.npz"))
+            bits = np.unpackbits(z[f"had{K}"])[:K * K].reshape(K, K)
+            return torch.from_numpy(bits.astype(np.float32) * 2.0 - 1.0), K
+    assert (n & (n - 1)) == 0, "n must be 2^m or K * 2^m"
+    return None, 1
+
+
+def apply_hadamard(x: torch.Tensor) -> torch.Tensor:
+    """x -> x . Had_n / sqrt(n) over the last dim, n = 2^m or K * 2^m for the K of get_hadK.
+
+    Follows hadamard_utils.py:85-90 + :138-147 (matmul_hadU_cuda): for n = K*2^m the row is
+    viewed as [K, n/K], Sylvester-transformed over the inner axis, then mixed by hadK over
+    the outer axis; one 1/sqrt(n) scale.
     """
     n = x.shape[-1]
     dt = x.dtype
-    if (n & (n - 1)) == 0:
+    hk, K = hadK_for(n)
+    if K == 1:
         return (fwht(x.float()) / math.sqrt(n)).to(dt)
-    assert n % 12 == 0 and ((n // 12) & (n // 12 - 1)) == 0, "only 2^m and 12*2^m supported"
-    y = fwht(x.float().reshape(*x.shape[:-1], 12, n // 12)) / math.sqrt(n)
-    y = torch.matmul(had12(), y)
+    y = x.float().reshape(*x.shape[:-1], K, n // K)
+    y = (fwht(y) if n // K > 1 else y) / math.sqrt(n)
+    y = torch.matmul(hk, y)
     return y.reshape(x.shape).to(dt)
 
 

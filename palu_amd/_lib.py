@@ -52,6 +52,7 @@ SIGNATURES = {
     "palu_decode_attn_f16": (i32, [vp, i64, i64, vp, vp, i64, i64, vp, i64, i64, vp, vp, i32, i32, i32, i32, i32, i32,
                                    vp, i32, f32, vp]),
     "palu_gemv_f16": (i32, [vp, i64, vp, vp, i32, i32, vp]),
+    "palu_gemv_f16_acc32": (i32, [vp, i64, vp, vp, i32, i32, vp]),
     "palu_decode_qkv_f16": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, vp, i64, i64, vp, i64, i64, vp,
                                   i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "palu_abx_rope_q": (i32, [vp, i64, i64, vp, vp, i64, i64, vp, i64, i64, vp, i64, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
@@ -65,6 +66,7 @@ SIGNATURES = {
                                     i32, i32, f32, vp]),
     "palu_packed_row_bytes": (sz, [i32, i32]),
     "palu_quantize_pack": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, vp]),
+    "palu_quantize_pack_ex": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, i32, f32, vp]),
     "palu_unpack_dequant": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, vp]),
     "palu_pack_codes": (i32, [vp, vp, i64, i32, vp]),
     "palu_unpack_codes": (i32, [vp, vp, i64, i32, vp]),

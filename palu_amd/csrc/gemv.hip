@@ -61,8 +61,9 @@ static __device__ __forceinline__ void stage_x(const h16* __restrict__ x, h16* x
   __syncthreads();
 }
 
+template <typename OUT>
 __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const h16* __restrict__ W, int64_t ldw,
-                                                          const h16* __restrict__ x, h16* __restrict__ y, int N,
+                                                          const h16* __restrict__ x, OUT* __restrict__ y, int N,
                                                           int K) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   h16* xs = reinterpret_cast<h16*>(smem_raw);
@@ -75,8 +76,8 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const h16* __restrict_
   float y0, y1;
   row_pair_dot(W + (int64_t)n0 * ldw, W + (int64_t)n1 * ldw, xs, K, lane, &y0, &y1);
   if (lane == 0) {
-    y[n0] = (h16)y0;
-    if (n0 + 1 < N) y[n0 + 1] = (h16)y1;
+    y[n0] = (OUT)y0;
+    if (n0 + 1 < N) y[n0 + 1] = (OUT)y1;
   }
 }
 
@@ -159,8 +160,24 @@ extern "C" int palu_gemv_f16(const void* W, int64_t ldw, const void* x, void* y,
   PALU_REQUIRE((size_t)K * 2 <= 64 * 1024, PALU_ERR_UNSUPPORTED, "gemv: K too large for the LDS-resident vector");
   const int pairs = (N + 1) / 2;
   const int blocks = (pairs + GV_THREADS / 64 - 1) / (GV_THREADS / 64);
-  hipLaunchKernelGGL(gemv_kernel, dim3(blocks), dim3(GV_THREADS), (size_t)K * 2, (hipStream_t)stream, (const h16*)W,
+  hipLaunchKernelGGL(gemv_kernel<h16>, dim3(blocks), dim3(GV_THREADS), (size_t)K * 2, (hipStream_t)stream, (const h16*)W,
                      ldw, (const h16*)x, (h16*)y, N, K);
+  PALU_LAUNCH_CHECK();
+  return PALU_OK;
+}
+
+// the same product with the fp32 accumulator written out unrounded: the partial sums of a column-sharded o_proj
+// (each rank multiplies its own context slice by its column block; the ranks all-reduce [N] fp32 and round once)
+extern "C" int palu_gemv_f16_acc32(const void* W, int64_t ldw, const void* x, float* y, int N, int K,
+                                   palu_stream_t stream) {
+  PALU_REQUIRE(W && x && y && N > 0 && K > 0, PALU_ERR_ARG, "gemv_acc32: bad arguments");
+  PALU_REQUIRE(K % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)x & 15) == 0, PALU_ERR_ARG,
+               "gemv_acc32: K, ldw must be multiples of 8 and W, x 16-byte aligned");
+  PALU_REQUIRE((size_t)K * 2 <= 64 * 1024, PALU_ERR_UNSUPPORTED, "gemv_acc32: K too large for the LDS-resident vector");
+  const int pairs = (N + 1) / 2;
+  const int blocks = (pairs + GV_THREADS / 64 - 1) / (GV_THREADS / 64);
+  hipLaunchKernelGGL(gemv_kernel<float>, dim3(blocks), dim3(GV_THREADS), (size_t)K * 2, (hipStream_t)stream,
+                     (const h16*)W, ldw, (const h16*)x, y, N, K);
   PALU_LAUNCH_CHECK();
   return PALU_OK;
 }

@@ -22,14 +22,21 @@ struct QpTensor {
   h16* meta;     int64_t sm_g, sm_l;
   h16* deq;      int64_t sd_g, sd_l;
   int R;
+  float clip;    // lt_clip_ratio (quant.py:18-36); 1.0 = off
 };
 
-// one wave quantises + packs one (group, row) of R codes
-template <int BITS>
+// one wave quantises + packs one (group, row) of R codes.
+// SYM (quant.py:18-28): scale = clamp(amax|w|, 1e-5)[*clip] / (2^(b-1)-1), signed codes in [-2^(b-1), 2^(b-1)-1], base 0.
+// The packed format stores unsigned codes, so a symmetric row is stored in offset binary: code + 2^(b-1) with
+// zero = 2^(b-1) in the meta pair -- (stored - zero) * scale is the reference's code * scale bit for bit, and the
+// decode kernels need no symmetric variant.
+template <int BITS, bool SYM>
 static __device__ __forceinline__ void quantize_row(const QpTensor& t, int g, int l, int lane) {
   const int R = t.R;
   const h16* row = t.x + g * t.sx_g + l * t.sx_l;
-  constexpr float QMAX = (float)((1 << BITS) - 1);
+  constexpr float QMAX = SYM ? (float)((1 << (BITS - 1)) - 1) : (float)((1 << BITS) - 1);
+  constexpr float QMIN = SYM ? -(float)(1 << (BITS - 1)) : 0.f;
+  constexpr float OFFS = SYM ? (float)(1 << (BITS - 1)) : 0.f;     // stored code = code + OFFS
   float mx = -INFINITY, mn = INFINITY;
   for (int j = lane; j < R; j += 64) {
     float v = (float)row[j];
@@ -38,17 +45,30 @@ static __device__ __forceinline__ void quantize_row(const QpTensor& t, int g, in
   }
   mx = wave_max(mx);
   mn = -wave_max(-mn);
-  // quant.py:36-38: scales = (max-min).clamp(min=1e-5)/q_max ; base = round(-min/scales).clamp(0, q_max)
-  float range = r16(mx - mn);
   const float floor16 = (float)(h16)1e-5f;   // the clamp constant is cast to fp16 (a subnormal)
-  range = fmaxf(range, floor16);
-  const float scale = r16(range / QMAX);
-  float zero = rintf(r16(-mn / scale));
-  zero = fminf(fmaxf(zero, 0.f), QMAX);
+  float scale, zero;
+  if (SYM) {
+    // quant.py:18-24: w_max = amax|w|.clamp(min=1e-5) [* clip]; scales = w_max / q_max; base = 0
+    float top = fmaxf(fmaxf(mx, -mn), floor16);
+    if (t.clip < 1.0f) top = r16(top * t.clip);
+    scale = r16(top / QMAX);
+    zero = 0.f;
+  } else {
+    // quant.py:29-38: [max, min *= clip]; scales = (max-min).clamp(min=1e-5)/q_max ; base = round(-min/scales).clamp(0, q_max)
+    if (t.clip < 1.0f) {
+      mx = r16(mx * t.clip);
+      mn = r16(mn * t.clip);
+    }
+    float range = r16(mx - mn);
+    range = fmaxf(range, floor16);
+    scale = r16(range / QMAX);
+    zero = rintf(r16(-mn / scale));
+    zero = fminf(fmaxf(zero, 0.f), QMAX);
+  }
   if (lane == 0) {
     h16* m = t.meta + g * t.sm_g + l * t.sm_l;
     m[0] = (h16)scale;
-    m[1] = (h16)zero;
+    m[1] = (h16)(zero + OFFS);
   }
   unsigned char* crow = t.codes + g * t.sc_g + l * t.sc_l;
   h16* drow = t.deq ? t.deq + g * t.sd_g + l * t.sd_l : nullptr;
@@ -60,8 +80,8 @@ static __device__ __forceinline__ void quantize_row(const QpTensor& t, int g, in
       const float w = (float)row[8 * u + e];
       // quant.py:39: clamp(round(w/scales) + base, q_min, q_max)
       float q = r16(rintf(r16(w / scale)) + zero);
-      q = fminf(fmaxf(q, 0.f), QMAX);
-      bits |= (unsigned)q << (BITS * e);
+      q = fminf(fmaxf(q, QMIN), QMAX);
+      bits |= (unsigned)(q + OFFS) << (BITS * e);
       if (drow) drow[8 * u + e] = (h16)(r16(q - zero) * scale);   // (q - base) * scales, fp16
     }
     unsigned char* d = crow + u * BITS;
@@ -76,16 +96,16 @@ static __device__ __forceinline__ void quantize_row(const QpTensor& t, int g, in
 }
 
 // waves [0, G*nrows) -> tensor a, the next G*nrows_b -> tensor b (the K and V latent rows of one decode step)
-template <int BITS>
+template <int BITS, bool SYM>
 __global__ __launch_bounds__(256) void quantize_pack_kernel(QpTensor a, QpTensor b, int G, int nrows, int nrows_b) {
   const int lane = threadIdx.x & 63;
   int64_t wid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t na = (int64_t)G * nrows;
   if (wid < na) {
-    quantize_row<BITS>(a, (int)(wid / nrows), (int)(wid % nrows), lane);
+    quantize_row<BITS, SYM>(a, (int)(wid / nrows), (int)(wid % nrows), lane);
   } else {
     wid -= na;
-    if (wid < (int64_t)G * nrows_b) quantize_row<BITS>(b, (int)(wid / nrows_b), (int)(wid % nrows_b), lane);
+    if (wid < (int64_t)G * nrows_b) quantize_row<BITS, SYM>(b, (int)(wid / nrows_b), (int)(wid % nrows_b), lane);
   }
 }
 
@@ -149,13 +169,17 @@ bool quant_shape_ok(int bits, int R) {
 extern "C" size_t palu_packed_row_bytes(int R, int bits) { return quant_shape_ok(bits, R) ? (size_t)R * bits / 8 : 0; }
 
 namespace {
-int launch_quantize(const QpTensor& ta, const QpTensor& tb, int G, int nrows, int nrows_b, int bits, hipStream_t s) {
+int launch_quantize(const QpTensor& ta, const QpTensor& tb, int G, int nrows, int nrows_b, int bits, hipStream_t s,
+                    bool sym = false) {
   const int64_t waves = (int64_t)G * (nrows + nrows_b);
   dim3 grid((unsigned)((waves + 3) / 4)), block(256);
-  if (bits == 4)
-    hipLaunchKernelGGL(quantize_pack_kernel<4>, grid, block, 0, s, ta, tb, G, nrows, nrows_b);
-  else
-    hipLaunchKernelGGL(quantize_pack_kernel<3>, grid, block, 0, s, ta, tb, G, nrows, nrows_b);
+  if (bits == 4) {
+    if (sym) hipLaunchKernelGGL((quantize_pack_kernel<4, true>), grid, block, 0, s, ta, tb, G, nrows, nrows_b);
+    else hipLaunchKernelGGL((quantize_pack_kernel<4, false>), grid, block, 0, s, ta, tb, G, nrows, nrows_b);
+  } else {
+    if (sym) hipLaunchKernelGGL((quantize_pack_kernel<3, true>), grid, block, 0, s, ta, tb, G, nrows, nrows_b);
+    else hipLaunchKernelGGL((quantize_pack_kernel<3, false>), grid, block, 0, s, ta, tb, G, nrows, nrows_b);
+  }
   PALU_LAUNCH_CHECK();
   return PALU_OK;
 }
@@ -164,7 +188,16 @@ int launch_quantize(const QpTensor& ta, const QpTensor& tb, int G, int nrows, in
 extern "C" int palu_quantize_pack(const void* x, int64_t sx_g, int64_t sx_l, void* codes, int64_t sc_g, int64_t sc_l,
                                   void* meta, int64_t sm_g, int64_t sm_l, void* dequant, int64_t sd_g, int64_t sd_l,
                                   int G, int nrows, int R, int bits, palu_stream_t stream) {
+  return palu_quantize_pack_ex(x, sx_g, sx_l, codes, sc_g, sc_l, meta, sm_g, sm_l, dequant, sd_g, sd_l, G, nrows, R, bits,
+                               0, 1.0f, stream);
+}
+
+extern "C" int palu_quantize_pack_ex(const void* x, int64_t sx_g, int64_t sx_l, void* codes, int64_t sc_g, int64_t sc_l,
+                                     void* meta, int64_t sm_g, int64_t sm_l, void* dequant, int64_t sd_g, int64_t sd_l,
+                                     int G, int nrows, int R, int bits, int sym, float clip_ratio,
+                                     palu_stream_t stream) {
   PALU_REQUIRE(x && codes && meta && G > 0 && nrows >= 0, PALU_ERR_ARG, "quantize_pack: bad arguments");
+  PALU_REQUIRE(clip_ratio > 0.f && clip_ratio <= 1.0f, PALU_ERR_ARG, "quantize_pack: clip_ratio must be in (0, 1]");
   PALU_REQUIRE(quant_shape_ok(bits, R), PALU_ERR_UNSUPPORTED,
                "quantize_pack: bits must be 3 (R %% 32 == 0) or 4 (R %% 8 == 0), got bits=%d R=%d", bits, R);
   PALU_REQUIRE(bits != 4 || (sc_g % 4 == 0 && sc_l % 4 == 0 && ((uintptr_t)codes & 3) == 0), PALU_ERR_ARG,
@@ -172,8 +205,8 @@ extern "C" int palu_quantize_pack(const void* x, int64_t sx_g, int64_t sx_l, voi
   PALU_REQUIRE(sm_l >= 2 || nrows <= 1, PALU_ERR_ARG, "quantize_pack: meta rows hold (scale, zero)");
   if (nrows == 0) return PALU_OK;
   QpTensor t = {(const h16*)x, sx_g, sx_l, (unsigned char*)codes, sc_g, sc_l, (h16*)meta, sm_g, sm_l,
-                (h16*)dequant, sd_g, sd_l, R};
-  return launch_quantize(t, t, G, nrows, 0, bits, (hipStream_t)stream);
+                (h16*)dequant, sd_g, sd_l, R, clip_ratio};
+  return launch_quantize(t, t, G, nrows, 0, bits, (hipStream_t)stream, sym != 0);
 }
 
 // internal (decode_step.hip): quantise+pack the new K and V latent rows of one step in ONE launch
@@ -182,8 +215,8 @@ int palu_quantize_pack_kv(const void* k, int64_t sk_g, void* k_codes, int64_t sk
                           int G, int bits, palu_stream_t stream) {
   PALU_REQUIRE(quant_shape_ok(bits, Rk) && quant_shape_ok(bits, Rv), PALU_ERR_UNSUPPORTED,
                "quantize_pack_kv: unsupported bits=%d Rk=%d Rv=%d", bits, Rk, Rv);
-  QpTensor tk = {(const h16*)k, sk_g, 0, (unsigned char*)k_codes, skc_g, 0, (h16*)k_meta, skm_g, 0, nullptr, 0, 0, Rk};
-  QpTensor tv = {(const h16*)v, sv_g, 0, (unsigned char*)v_codes, svc_g, 0, (h16*)v_meta, svm_g, 0, nullptr, 0, 0, Rv};
+  QpTensor tk = {(const h16*)k, sk_g, 0, (unsigned char*)k_codes, skc_g, 0, (h16*)k_meta, skm_g, 0, nullptr, 0, 0, Rk, 1.0f};
+  QpTensor tv = {(const h16*)v, sv_g, 0, (unsigned char*)v_codes, svc_g, 0, (h16*)v_meta, svm_g, 0, nullptr, 0, 0, Rv, 1.0f};
   return launch_quantize(tk, tv, G, 1, 1, bits, (hipStream_t)stream);
 }
 

@@ -2,17 +2,50 @@
 138-147; svd_linear.py:156-168), backed by the HIP FWHT (`palu_hadamard_transform`).
 
 `hadamard_transform(x, scale)` is the drop-in for the external `fast_hadamard_transform` op.  Sizes:
-n = 2^m, and n = 12 * 2^m through the had12 (x) H_{n/12} Kronecker form (the n % 12 branch of get_hadK,
-:75-78, which BASELINE configs 3/4 hit with R_v = 384 / 192).  The other 19 literal tables are out of
-scope.  The 12x12 mixing is a tiny torch matmul: this is offline weight preparation.
+n = 2^m, and n = K * 2^m for every K of get_hadK (:5-83: 12 ... 244) through the hadK (x) H_{n/K} Kronecker form of
+matmul_hadU_cuda (:138-147) -- BASELINE configs 3/4 hit K = 12 with R_v = 384 / 192, the Fisher rank search
+(rank_search.py:11-17) produces widths such as 160, 224, 320 (K = 40, 28, 40).  The K x K factors are numeric data
+(`hadk_tables.npz`, bit-packed, written by tests/golden/make_hadk.py from the reference's get_hadK) -- they must be
+the reference's own matrices for rotated weights to agree.  The K x K mixing is a small torch matmul: this is offline
+weight preparation.
 """
 from __future__ import annotations
 
 import math
+import os
 
+import numpy as np
 import torch
 
 from .. import _lib
+
+# get_hadK's test order (hadamard_utils.py:7-80): the first K with n % K == 0 wins (e.g. 160 takes 40, not 20)
+HAD_K_ORDER = (244, 180, 172, 156, 140, 108, 92, 84, 76, 68, 60, 52, 44, 36, 28, 40, 20, 12)
+_tables = None
+
+
+def _load_tables():
+    global _tables
+    if _tables is None:
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "hadk_tables.npz"))
+        _tables = {}
+        for K in HAD_K_ORDER:
+            bits = np.unpackbits(z[f"had{K}"])[:K * K].reshape(K, K)
+            _tables[K] = torch.from_numpy(bits.astype(np.float32) * 2.0 - 1.0)
+    return _tables
+
+
+def get_hadK(n: int, transpose: bool = False):
+    """(hadK [K, K] fp32 or None, K) for a width n = K * 2^m, the selection rule of hadamard_utils.py:5-83."""
+    for K in HAD_K_ORDER:
+        if n % K == 0:
+            if not is_pow2(n // K):
+                raise ValueError(f"get_hadK: n={n} is {K} * {n // K}, not {K} * 2^m (hadamard_utils.py asserts the same)")
+            h = _load_tables()[K]
+            return (h.t().contiguous() if transpose else h), K
+    if not is_pow2(n):
+        raise ValueError(f"get_hadK: n={n} is neither 2^m nor K * 2^m for a known Hadamard factor K")
+    return None, 1
 
 
 def is_pow2(n: int) -> bool:
@@ -54,15 +87,15 @@ def apply_hadamard(x: torch.Tensor, transpose: bool = False) -> torch.Tensor:
     dtype = x.dtype
     n = x.shape[-1]
     work = x.float() if dtype not in (torch.float16, torch.float32) else x
-    if is_pow2(n):
+    hadK, K = get_hadK(n, transpose)
+    if K == 1:
         return hadamard_transform(work.contiguous(), 1.0 / math.sqrt(n)).to(dtype)
-    if n % 12 != 0 or not is_pow2(n // 12):
-        raise NotImplementedError(f"apply_hadamard: n={n} needs a Hadamard table that is out of scope (2^m, 12*2^m only)")
-    h12 = get_had12(x.device)
-    if transpose:
-        h12 = h12.t().contiguous()
-    y = hadamard_transform(work.reshape(-1, 12, n // 12).contiguous(), 1.0 / math.sqrt(n))
-    y = torch.matmul(h12.to(y.dtype), y)
+    # matmul_hadU_cuda (:142-147): Sylvester transform over the inner n/K axis, hadK over the outer axis, one 1/sqrt(n)
+    if n == K:
+        y = work.reshape(-1, K, 1) * (1.0 / math.sqrt(n))
+    else:
+        y = hadamard_transform(work.reshape(-1, K, n // K).contiguous(), 1.0 / math.sqrt(n))
+    y = torch.matmul(hadK.to(device=y.device, dtype=y.dtype), y)
     return y.reshape(x.shape).to(dtype)
 
 

@@ -62,19 +62,33 @@ def make_plan(world: int, rank: int, num_heads: int, num_groups: int, head_dim: 
     return ShardPlan(world, rank, num_heads, num_groups, head_dim, rank_k, rank_v)
 
 
-def shard_weights(plan: ShardPlan, w: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+def shard_weights(plan: ShardPlan, w: Dict[str, torch.Tensor], oproj: str = "replicated") -> Dict[str, torch.Tensor]:
     """Slice the full weights {wq [H*D,hid], vt_k [G*Rk,hid], vt_v [G*Rv,hid], b [H,Rk,D], wo [hid,H*Rv]} to
-    what rank `plan.rank` owns.  `wo` stays whole (o_proj is replicated after the all-gather)."""
+    what rank `plan.rank` owns.  oproj = "replicated": `wo` stays whole (o_proj runs on the all-gathered context on every
+    rank); "sharded": the rank keeps only its column block wo[:, h0*Rv:h1*Rv] (1/N of the bytes: 12 MiB instead of
+    96 MiB at C2, N=8) and the ranks all-reduce the [hidden] fp32 partial outputs."""
     D, gs = plan.head_dim, plan.group_size
     h0, h1 = plan.head0, plan.head0 + plan.heads_local
     g0, g1 = plan.group0, plan.group0 + plan.groups_local
+    if oproj not in ("replicated", "sharded"):
+        raise ValueError("oproj must be 'replicated' or 'sharded'")
+    wo = w["wo"] if oproj == "replicated" else w["wo"][:, h0 * plan.rank_v:h1 * plan.rank_v]
     return {
         "wq": w["wq"][h0 * D:h1 * D],
         "vt_k": w["vt_k"][g0 * plan.rank_k:g1 * plan.rank_k],
         "vt_v": w["vt_v"][g0 * plan.rank_v:g1 * plan.rank_v],
         "b": w["b"][h0:h1],
-        "wo": w["wo"],
+        "wo": wo,
     }
+
+
+def reduce_partial_outputs(partial: torch.Tensor, plan: ShardPlan, group=None) -> torch.Tensor:
+    """Sum of the per-rank o_proj partials ([hidden] fp32, one all-reduce of 16 KiB), rounded once to fp16: the same
+    value the un-sharded GEMV produces up to the order of the fp32 additions."""
+    import torch.distributed as dist
+    if plan.world > 1:
+        dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=group)
+    return partial.to(torch.float16)
 
 
 def shard_cache(plan: ShardPlan, k_lat: torch.Tensor, v_lat: torch.Tensor):
@@ -105,6 +119,10 @@ class HeadParallelDecoder:
         from .abx_rope import prepare_b, rope_inv_freq
         self._lib = _lib
         self.plan, self.w, self.k, self.v, self.hidden, self.group = plan, weights, k_cache, v_cache, hidden_size, group
+        # o_proj variant from the shape of the weight the rank was given (shard_weights(..., oproj=...))
+        self.oproj_sharded = plan.world > 1 and weights["wo"].shape[1] == plan.heads_local * plan.rank_v
+        self.partial = torch.empty(hidden_size, dtype=torch.float32, device=k_cache.device)
+        self.t_collective = None      # optional (start, end) CUDA events around the collective of the last step
         dev = k_cache.device
         self.frag = prepare_b(weights["b"], plan.groups_local)
         self.inv = rope_inv_freq(dev, plan.head_dim, theta)
@@ -128,18 +146,40 @@ class HeadParallelDecoder:
             p.head_dim, self.hidden, p.rank_k, p.rank_v, cache_len, pos, lib.current_stream()), "decode_attend")
         return self.ctx
 
-    def step(self, hidden: torch.Tensor, cache_len: int, pos: int) -> torch.Tensor:
+    def step(self, hidden: torch.Tensor, cache_len: int, pos: int, time_collective: bool = False) -> torch.Tensor:
+        """One decode step.  Replicated o_proj: all-gather of the [H/N*Rv] fp16 context slices, then the full GEMV on
+        every rank.  Sharded o_proj: every rank multiplies its own slice by its column block (fp32 partial [hidden]),
+        one all-reduce of 16 KiB, one rounding.  time_collective records CUDA events around the collective
+        (self.t_collective) for the collective-only latency bench.py reports."""
         import torch.distributed as dist
         lib, p = self._lib, self.plan
         ctx = self.local_step(hidden, cache_len, pos)
-        if p.world > 1:
-            dist.all_gather_into_tensor(self.ctx_full, ctx, group=self.group)
-            full = self.ctx_full
-        else:
-            full = ctx
         wo = self.w["wo"]
-        lib.check(lib.lib.palu_gemv_f16(wo.data_ptr(), wo.stride(0), full.data_ptr(), self.out.data_ptr(),
-                                        self.hidden, p.num_heads * p.rank_v, lib.current_stream()), "o_proj")
+        ev = None
+        if time_collective and p.world > 1:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        if self.oproj_sharded:
+            lib.check(lib.lib.palu_gemv_f16_acc32(wo.data_ptr(), wo.stride(0), ctx.data_ptr(), self.partial.data_ptr(),
+                                                  self.hidden, p.heads_local * p.rank_v, lib.current_stream()), "o_proj")
+            if ev:
+                ev[0].record()
+            dist.all_reduce(self.partial, op=dist.ReduceOp.SUM, group=self.group)
+            if ev:
+                ev[1].record()
+            self.out.copy_(self.partial)            # fp32 -> fp16, the single rounding of the output
+        else:
+            if p.world > 1:
+                if ev:
+                    ev[0].record()
+                dist.all_gather_into_tensor(self.ctx_full, ctx, group=self.group)
+                if ev:
+                    ev[1].record()
+                full = self.ctx_full
+            else:
+                full = ctx
+            lib.check(lib.lib.palu_gemv_f16(wo.data_ptr(), wo.stride(0), full.data_ptr(), self.out.data_ptr(),
+                                            self.hidden, p.num_heads * p.rank_v, lib.current_stream()), "o_proj")
+        self.t_collective = ev
         return self.out
 
 

@@ -31,8 +31,10 @@ def _as_gl(x: torch.Tensor):
     return x2
 
 
-def quantize_pack(x: torch.Tensor, n_bits: int, want_dequant: bool = False):
-    """x [..., R] fp16 (cuda) -> (codes uint8 [..., R*b/8], meta fp16 [..., 2] = (scale, zero)[, dequant])."""
+def quantize_pack(x: torch.Tensor, n_bits: int, want_dequant: bool = False, sym: bool = False, clip_ratio: float = 1.0):
+    """x [..., R] fp16 (cuda) -> (codes uint8 [..., R*b/8], meta fp16 [..., 2] = (scale, zero)[, dequant]).
+    sym / clip_ratio: the other modes of quantize_tensor (quant.py:18-36); symmetric rows are stored in offset binary
+    (zero = 2^(b-1)), so unpack_dequant and the decode kernels need no flag."""
     if not x.is_cuda or x.dtype != torch.float16:
         raise TypeError("quantize_pack: fp16 ROCm tensor required (no CPU fallback)")
     R = x.shape[-1]
@@ -42,9 +44,10 @@ def quantize_pack(x: torch.Tensor, n_bits: int, want_dequant: bool = False):
     codes = torch.empty((n, nb), dtype=torch.uint8, device=x.device)
     meta = torch.empty((n, 2), dtype=torch.float16, device=x.device)
     deq = torch.empty((n, R), dtype=torch.float16, device=x.device) if want_dequant else None
-    _lib.check(_lib.lib.palu_quantize_pack(x2.data_ptr(), 0, x2.stride(0), codes.data_ptr(), 0, nb, meta.data_ptr(), 0, 2,
-                                           0 if deq is None else deq.data_ptr(), 0, R, 1, n, R, n_bits,
-                                           _lib.current_stream()), "palu_quantize_pack")
+    _lib.check(_lib.lib.palu_quantize_pack_ex(x2.data_ptr(), 0, x2.stride(0), codes.data_ptr(), 0, nb, meta.data_ptr(), 0, 2,
+                                              0 if deq is None else deq.data_ptr(), 0, R, 1, n, R, n_bits,
+                                              1 if sym else 0, float(clip_ratio), _lib.current_stream()),
+               "palu_quantize_pack")
     lead = x.shape[:-1]
     out = (codes.reshape(*lead, nb), meta.reshape(*lead, 2))
     return out + ((deq.reshape(x.shape),) if want_dequant else ())
@@ -85,13 +88,16 @@ def quantize_tensor(w: torch.Tensor, n_bits, group_size, sym, clip_ratio=1.0) ->
     """Fake-quant with the reference's signature (quant.py:5): returns (code - zero) * scale, same shape."""
     assert w.dim() == 2
     assert n_bits < 16
-    if sym or clip_ratio != 1.0 or n_bits not in (3, 4):
-        raise NotImplementedError("HIP latent quantiser: asymmetric 3/4-bit, clip_ratio 1.0 only (reference defaults)")
+    if n_bits not in (3, 4):
+        raise NotImplementedError("HIP latent quantiser: 3- and 4-bit codes (the packed cache formats)")
+    if not 0.0 < clip_ratio <= 1.0:
+        raise ValueError("clip_ratio must be in (0, 1]")
     shape = w.shape
     if group_size > 0:
         assert shape[-1] % group_size == 0
         w = w.reshape(-1, group_size)
-    *_, deq = quantize_pack(w.half() if w.dtype != torch.float16 else w, n_bits, want_dequant=True)
+    *_, deq = quantize_pack(w.half() if w.dtype != torch.float16 else w, n_bits, want_dequant=True, sym=sym,
+                            clip_ratio=clip_ratio)
     return deq.reshape(shape).to(w.dtype)
 
 

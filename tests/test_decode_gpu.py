@@ -262,9 +262,72 @@ def test_decode_step_under_graph_capture():
     torch.testing.assert_close(out, eager, rtol=0, atol=0)
 
 
-def test_decode_step_full_size_c2_properties():
-    """BASELINE config 2 (rank 1024/3072, gs 4, L=64k): the step vs an fp32 torch-GPU recomputation from
-    the kernels' own intermediate (scores), plus linearity of the context in V."""
+def test_decode_step_full_size_c2_vs_oracle():
+    """BASELINE config 2 at FULL size (rank 1024/3072, gs 4, 65536 cached positions): the whole HIP step
+    (palu_decode_attend_f16 + o_proj) against oracle.decode_step on the same inputs, P1 tolerance.  The oracle needs
+    ~13 s of CPU per step at this size (it is also what bench.py's cpu_baseline leg times and checks)."""
+    from palu_amd.kernel import head_parallel as hp
+    H, G, D, HID, Rk, Rv, L = 32, 8, 128, 4096, 128, 384, 65536
+    torch.manual_seed(0)
+    w = {"wq": torch.randn(H * D, HID).mul_(1 / 64).half(), "vt_k": torch.randn(G * Rk, HID).mul_(1 / 64).half(),
+         "vt_v": torch.randn(G * Rv, HID).mul_(1 / 64).half(), "b": torch.randn(H, Rk, D).mul_(Rk ** -0.5).half(),
+         "wo": torch.randn(HID, H * Rv).mul_(0.01).half()}
+    k = torch.randn(G, L, Rk).half()
+    v = torch.randn(G, L, Rv).half()
+    tok = torch.randn(HID).half()
+    with torch.no_grad():
+        ref, probs, _, _ = oracle.decode_step(tok, L, w, k, v)
+    plan = hp.make_plan(1, 0, H, G, D, Rk, Rv)
+    wd = {n: t.to(DEV) for n, t in w.items()}
+    kc = torch.zeros(G, L + 64, Rk, dtype=torch.float16, device=DEV)
+    vc = torch.zeros(G, L + 64, Rv, dtype=torch.float16, device=DEV)
+    kc[:, :L] = k.to(DEV)
+    vc[:, :L] = v.to(DEV)
+    dec = hp.HeadParallelDecoder(plan, wd, kc, vc, HID)
+    out = dec.step(tok.to(DEV), L, L)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-3, atol=1e-3)
+    # the appended latent rows equal the oracle's projections (fp16 GEMV with fp32 accumulation)
+    k_new = torch.nn.functional.linear(tok.reshape(1, -1), w["vt_k"]).reshape(G, Rk)
+    torch.testing.assert_close(kc[:, L].cpu(), k_new, rtol=2e-3, atol=2e-3)
+    assert abs(probs.float().sum(-1) - 1).max().item() < 5e-2
+
+
+def test_softmax_pv_config5_slice():
+    """BASELINE config 5, the per-GPU slice of the 8-GPU sharding: ONE latent group (G=1, gs=4), L = 262144, Rv = 384.
+    Size-independent checks: fp32 torch-GPU recomputation from the same fp16 scores, and the split-L statistics."""
+    torch.manual_seed(1)
+    H, G, L, Rv = 4, 1, 262144, 384
+    scores = (torch.randn(H, L, device=DEV) * 12).half()
+    v = torch.randn(G, L, Rv, device=DEV, dtype=torch.float16)
+    ctx, probs = softmax_pv(scores, v, want_probs=True)
+    x = (scores / math.sqrt(128.0)).float()
+    p = torch.softmax(x, dim=-1)
+    ref = torch.matmul(p.reshape(G, 4, L), v.float()).reshape(H, Rv)
+    torch.testing.assert_close(ctx.float(), ref, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(probs.float(), p, rtol=1e-3, atol=1e-3)
+    # two half ranges merged with the (max, sum) statistics == the whole range (what SplitLDecoder does across GPUs)
+    lib = _lib()
+    halves = []
+    for l0, l1 in ((0, L // 2), (L // 2, L)):
+        sc, vv = scores[:, l0:l1].contiguous(), v[:, l0:l1].contiguous()
+        ws = torch.empty(lib.lib.palu_pv_workspace_bytes(H, G, l1 - l0, Rv), dtype=torch.uint8, device=DEV)
+        c = torch.empty(H, Rv, dtype=torch.float16, device=DEV)
+        lib.check(lib.lib.palu_softmax_pv_f16(sc.data_ptr(), sc.stride(0), 0, vv.data_ptr(), vv.stride(0), vv.stride(1),
+                                              c.data_ptr(), 0, 0, ws.data_ptr(), H, G, l1 - l0, Rv, math.sqrt(128.0),
+                                              _stream()), "pv")
+        off = lib.lib.palu_pv_stats_offset(H, G, l1 - l0, Rv)
+        halves.append((c.float(), ws[off:off + H * 8].view(torch.float32).reshape(H, 2).clone()))
+    (c0, s0), (c1, s1) = halves
+    M = torch.maximum(s0[:, 0], s1[:, 0])
+    w0, w1 = s0[:, 1] * torch.exp(s0[:, 0] - M), s1[:, 1] * torch.exp(s1[:, 0] - M)
+    merged = (w0[:, None] * c0 + w1[:, None] * c1) / (w0 + w1)[:, None]
+    torch.testing.assert_close(merged, ctx.float(), rtol=2e-3, atol=2e-3)
+
+
+def test_softmax_pv_full_size_c2_properties():
+    """BASELINE config 2 (rank 1024/3072, gs 4, L=64k), the softmax.PV kernel alone: fp32 torch-GPU recomputation from
+    the same fp16 scores, plus linearity of the context in V (the full step at this size is checked against the
+    oracle in test_decode_step_full_size_c2_vs_oracle)."""
     torch.manual_seed(0)
     H, G, L, Rv = 32, 8, 65536, 384
     scores = (torch.randn(H, L, device=DEV) * 12).half()

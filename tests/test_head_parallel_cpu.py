@@ -83,6 +83,56 @@ def test_head_group_parallel_world2(tmp_path, case):
     assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
 
 
+def _worker_sharded(rank, world, port, shape, out_dir):
+    """column-sharded o_proj: every rank multiplies ITS context slice by ITS column block of W_o', the ranks all-reduce
+    the [hidden] fp32 partials (hp.reduce_partial_outputs) -- against the un-sharded oracle step AND the all-gather
+    variant, for the shard plan of `world` ranks (world 8: one latent group per rank, the BASELINE config-5 layout)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    seed, hidden, H, D, gs, rank_k, rank_v, L = shape
+    G = H // gs
+    w, k_lat, v_lat, tok, _ = gi.step_inputs(seed, hidden, H, D, gs, rank_k, rank_v, L, False)
+    full = {"wq": w["wq"].half(), "vt_k": w["vt_k"].half(), "vt_v": w["vt_v"].half(),
+            "b": oracle.build_b_from_u(w["u_k"], gs, D).half(), "wo": w["wo"].half()}
+    plan = hp.make_plan(world, rank, H, G, D, rank_k // G, rank_v // G)
+    ws = hp.shard_weights(plan, full, oproj="sharded")
+    wr = hp.shard_weights(plan, full, oproj="replicated")
+    Rv = rank_v // G
+    assert ws["wo"].shape == (hidden, H // world * Rv) and wr["wo"].shape == (hidden, H * Rv)
+    assert torch.equal(ws["wo"], full["wo"][:, plan.head0 * Rv:(plan.head0 + plan.heads_local) * Rv])
+    kl, vl = hp.shard_cache(plan, k_lat, v_lat)
+    assert kl.shape[0] == G // world == plan.groups_local
+    ctx_local = _oracle_local_context(plan, ws, kl, vl, tok, L)
+    # sharded: fp32 partial of this rank's column block, all-reduce, one rounding
+    partial = torch.nn.functional.linear(ctx_local.float().reshape(1, -1), ws["wo"].float()).reshape(-1)
+    out_s = hp.reduce_partial_outputs(partial.clone(), plan)
+    # replicated: all-gather, full GEMV
+    ctx = hp.gather_context(ctx_local, plan)
+    out_r = torch.nn.functional.linear(ctx.reshape(1, -1), full["wo"]).reshape(-1)
+    ref, _, _, _ = oracle.decode_step(tok, L, full, k_lat, v_lat)
+    torch.testing.assert_close(out_s, ref, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(out_r, ref, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(out_s, out_r, rtol=1e-3, atol=2e-4)
+    # every rank ends with the same output vector
+    allo = [torch.empty_like(out_s) for _ in range(world)]
+    dist.all_gather(allo, out_s)
+    for o in allo:
+        assert torch.equal(o, out_s)
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+
+
+@pytest.mark.parametrize("world,shape", [(2, (10, 512, 4, 128, 2, 64, 128, 96)),
+                                         (8, (21, 256, 16, 128, 2, 8 * 16, 8 * 32, 40))], ids=["world2", "world8"])
+def test_head_group_parallel_sharded_oproj(tmp_path, world, shape):
+    port = _free_port()
+    mp.spawn(_worker_sharded, args=(world, port, shape, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
+
+
 def test_plan_validation_and_layout():
     plan = hp.make_plan(4, 2, 32, 8, 128, 128, 384)
     assert (plan.groups_local, plan.heads_local, plan.group0, plan.head0, plan.ctx_local) == (2, 8, 4, 16, 8 * 384)

@@ -177,3 +177,22 @@ def test_reftest_fixture_is_lossless(golden_dir):
                                torch.from_numpy(g["vanilla_weights"]), rtol=1e-3, atol=1e-3)
     torch.testing.assert_close(torch.from_numpy(g["decode_output"]).float(),
                                torch.from_numpy(g["vanilla_output"]), rtol=1e-3, atol=1e-3)
+
+
+def test_oracle_hadamard_every_hadk_width(golden_dir):
+    """G8: every width n = K * 2^m get_hadK (hadamard_utils.py:5-83) accepts, K in {12 ... 244}, incl. the widths the
+    Fisher rank search produces (160, 224, 320, ...): oracle.apply_hadamard == the reference's matmul_hadU."""
+    g = np.load(os.path.join(golden_dir, "g8_hadk.npz"))
+    widths = sorted({int(k.split("/")[0][1:]) for k in g.files if k.startswith("n")})
+    assert len(widths) >= 40 and {160, 224, 320, 96, 384}.issubset(widths)
+    seen = set()
+    for n in widths:
+        x = torch.from_numpy(g[f"n{n}/x"])
+        hk, K = oracle.hadK_for(n)
+        assert K == int(g[f"n{n}/K"]), (n, K)
+        seen.add(K)
+        np.testing.assert_allclose(oracle.apply_hadamard(x).numpy(), g[f"n{n}/hadU"], rtol=0, atol=5e-6, err_msg=str(n))
+        if hk is not None:
+            m = hk.numpy().astype(np.int64)
+            assert np.array_equal(m @ m.T, K * np.eye(K, dtype=np.int64))
+    assert seen == set(oracle.HAD_K_ORDER)

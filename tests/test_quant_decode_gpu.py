@@ -102,6 +102,42 @@ def test_quantised_decode_step_vs_oracle(bits, rank_k, rank_v, L):
     assert ((kd2[0, :, L].cpu().float() - k2[:, L].float()).abs().amax(-1) <= step_k * 1.01 + 1e-3).all()
 
 
+def test_config3_three_bit_with_hadamard_vs_oracle():
+    """BASELINE config 3 as a whole: rank 1024/3072 (Rk = 128 = 2^7, Rv = 384 = 12 * 32 -> the had12 (x) H_32 branch),
+    3-bit packed latents AND fuse_hadamard().  The module's rotated weights are handed to the oracle
+    (oracle.decode_step(latent_bits=3) on the fake-quantised ROTATED latents): same probabilities and output (P1)."""
+    from palu_amd.kernel.palu_attention import QuantLatentCache
+    hidden, H, D, gs, rank_k, rank_v, L, bits = 4096, 32, 128, 4, 1024, 3072, 600, 3
+    G = H // gs
+    Rk, Rv = rank_k // G, rank_v // G
+    w, k_lat, v_lat, tok, _ = gi.step_inputs(31, hidden, H, D, gs, rank_k, rank_v, L, False)
+    m = _module_from_palu_weights(hidden, H, D, gs, rank_k, rank_v, w)
+    m.fuse_hadamard()
+    # the rotated latents of the prompt: rotate the un-rotated ones with the oracle's Hadamard (orthonormal, per group)
+    k_rot = oracle.apply_hadamard(k_lat.float().reshape(-1, Rk)).reshape(G, L, Rk).half()
+    v_rot = oracle.apply_hadamard(v_lat.float().reshape(-1, Rv)).reshape(G, L, Rv).half()
+    cache = QuantLatentCache(bits)
+    kd, vd = cache.update(k_rot.unsqueeze(0).to(DEV), v_rot.unsqueeze(0).to(DEV), 0)
+    kq = oracle.quantize_rows(k_rot.reshape(-1, Rk), bits)[0].reshape(G, L, Rk)
+    vq = oracle.quantize_rows(v_rot.reshape(-1, Rv), bits)[0].reshape(G, L, Rv)
+    assert torch.equal(kd[0].cpu(), kq) and torch.equal(vd[0].cpu(), vq)
+    with torch.no_grad():
+        out, probs, _ = m(tok.reshape(1, 1, hidden).to(DEV), position_ids=torch.arange(L, L + 1),
+                          past_key_value=cache, output_attentions=True)
+    wd = {"wq": m.q_proj.weight.detach().cpu().half(), "vt_k": m.k_proj.VT.weight.detach().cpu().half(),
+          "vt_v": m.v_proj.VT.weight.detach().cpu().half(), "b": m.k_proj.B.detach().cpu().half(),
+          "wo": m.o_proj.weight.detach().cpu().half()}
+    o2, p2, _, _ = oracle.decode_step(tok, L, wd, kq, vq, latent_bits=bits)
+    torch.testing.assert_close(probs.cpu().reshape(H, L + 1), p2, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(out.cpu().reshape(-1), o2, rtol=1e-3, atol=1e-3)
+    # and the rotation did what fused_hadamard_matrix promises: same step as the un-rotated module on fp16 latents
+    m0 = _module_from_palu_weights(hidden, H, D, gs, rank_k, rank_v, w)
+    b0 = oracle.build_b_from_u(w["u_k"], gs, D).half()
+    b_rot = oracle.apply_hadamard(b0.float().transpose(1, 2).reshape(-1, Rk)).reshape(H, D, Rk).transpose(1, 2)
+    torch.testing.assert_close(m.k_proj.B.detach().cpu().float(), b_rot, rtol=2e-3, atol=2e-3)
+    assert m0.k_proj.B.shape == m.k_proj.B.shape
+
+
 def test_hadamard_fusion_is_output_invariant():
     """fuse_hadamard() rotates VT / U / B / W_o' offline (svd_linear.py:156-168): same decode output."""
     from palu_amd.kernel.palu_attention import LatentCache

@@ -80,15 +80,89 @@ def test_quantizer_random_rows_bit_exact_vs_oracle():
         np.testing.assert_array_equal(q.unpack_codes(codes, bits, R).cpu().numpy(), ocodes.numpy().astype(np.uint8))
 
 
+@pytest.mark.parametrize("R", [32, 64, 128, 384])
+@pytest.mark.parametrize("bits", [3, 4])
+def test_quantizer_sym_and_clip_bit_exact_vs_reference(golden_dir, R, bits):
+    """The non-default modes of quantize_tensor (quant.py:18-36: lt_sym, lt_clip_ratio < 1) against the reference's
+    own outputs (golden G5): dequantised values bit for bit; codes / scale / zero against the oracle; symmetric rows are
+    stored in offset binary and decode through the ordinary unpack_dequant."""
+    from palu_amd.kernel import quant as q
+    g = np.load(os.path.join(golden_dir, "g5_quant.npz"))
+    x = gi.quant_inputs(0, R)
+    assert gi.digest(x) == str(g[f"R{R}/digest"])
+    for sym, gsz, clip in ((True, 0, 1.0), (False, 0, 0.9), (True, 32, 1.0)):
+        key = f"R{R}/b{bits}_sym{int(sym)}_g{gsz}_c{clip}"
+        if key not in g.files:
+            continue
+        ref = g[key]
+        got = q.quantize_tensor(x.cuda(), bits, gsz, sym, clip)
+        np.testing.assert_array_equal(got.cpu().numpy().view(np.uint16), ref.view(np.uint16), err_msg=key)
+        if gsz == 0:
+            codes, meta, deq = q.quantize_pack(x.cuda(), bits, want_dequant=True, sym=sym, clip_ratio=clip)
+            _, ocodes, oscale, ozero = oracle.quantize_rows(x.clone(), bits, 0, sym, clip)
+            offs = 2 ** (bits - 1) if sym else 0
+            np.testing.assert_array_equal(q.unpack_codes(codes, bits, R).cpu().numpy().astype(np.int16) - offs, ocodes.numpy())
+            np.testing.assert_array_equal(meta[:, 0].cpu().numpy().view(np.uint16), oscale.reshape(-1).numpy().view(np.uint16))
+            np.testing.assert_array_equal(meta[:, 1].cpu().numpy() - offs, ozero.reshape(-1).numpy())
+            np.testing.assert_array_equal(q.unpack_dequant(codes, meta, bits, R).cpu().numpy().view(np.uint16), ref.view(np.uint16))
+    qz = q.Quantizer(bits, 0, True, 1.0)
+    ref = g[f"R{R}/b{bits}_sym1_g0_c1.0"]
+    np.testing.assert_array_equal(qz(x.cuda()).cpu().numpy().view(np.uint16), ref.view(np.uint16))
+
+
 def test_quantizer_unsupported_modes_raise():
     from palu_amd.kernel import quant as q
     x = torch.zeros(4, 64, dtype=torch.float16, device="cuda")
     with pytest.raises(NotImplementedError):
-        q.quantize_tensor(x, 4, 0, True)
-    with pytest.raises(NotImplementedError):
-        q.quantize_tensor(x, 4, 0, False, 0.9)
+        q.quantize_tensor(x, 8, 0, False)              # only the packed-cache bit widths
+    with pytest.raises(ValueError):
+        q.quantize_tensor(x, 4, 0, False, 1.5)
     with pytest.raises(ValueError):
         q.quantize_pack(x[:, :40], 3)
+
+
+def test_hadamard_every_hadk_width_vs_reference(golden_dir):
+    """N4: apply_hadamard accepts every width get_hadK accepts (K * 2^m, K = 12 ... 244), against the reference's own
+    matmul_hadU outputs (golden G8), in both orientations; tables are the packed data file of the package."""
+    from palu_amd.kernel import hadamard_utils as hu
+    g = np.load(os.path.join(golden_dir, "g8_hadk.npz"))
+    widths = sorted({int(k.split("/")[0][1:]) for k in g.files if k.startswith("n")})
+    for n in widths:
+        x = torch.from_numpy(g[f"n{n}/x"]).cuda()
+        hk, K = hu.get_hadK(n)
+        assert K == int(g[f"n{n}/K"])
+        np.testing.assert_allclose(hu.apply_hadamard(x).cpu().numpy(), g[f"n{n}/hadU"], rtol=0, atol=1e-5, err_msg=str(n))
+        np.testing.assert_allclose(hu.apply_hadamard(x, transpose=True).cpu().numpy(), g[f"n{n}/hadUt"], rtol=0, atol=1e-5)
+    # orthonormal: applying the transform and its transpose returns the input
+    x = torch.randn(5, 320, device="cuda")
+    np.testing.assert_allclose(hu.apply_hadamard(hu.apply_hadamard(x), transpose=True).cpu().numpy(), x.cpu().numpy(), atol=2e-5)
+    with pytest.raises(ValueError):
+        hu.get_hadK(24 * 5)
+
+
+def test_fuse_hadamard_at_rank_search_widths():
+    """Ranks 160 / 224 per group (Fisher rank search widths, K = 40 and 28): fuse_hadamard() keeps the decode output."""
+    from palu_amd.kernel.palu_attention import LatentCache
+    from tests.test_decode_gpu import _module_from_palu_weights
+    hidden, H, D, gs, L = 1024, 8, 128, 4, 200
+    G = H // gs
+    rank_k, rank_v = 160 * G, 224 * G
+    w, k_lat, v_lat, tok, _ = gi.step_inputs(9, hidden, H, D, gs, rank_k, rank_v, L, False)
+    m = _module_from_palu_weights(hidden, H, D, gs, rank_k, rank_v, w)
+    x = torch.from_numpy(np.random.default_rng(2).standard_normal((1, L, hidden)).astype(np.float16)).cuda()
+
+    def run(mod):
+        cache = LatentCache()
+        with torch.no_grad():
+            mod(x, past_key_value=cache, position_ids=torch.arange(L).unsqueeze(0))
+            out, probs, _ = mod(tok.reshape(1, 1, hidden).cuda(), position_ids=torch.arange(L, L + 1),
+                                past_key_value=cache, output_attentions=True)
+        return out, probs
+    o0, p0 = run(m)
+    m.fuse_hadamard()
+    o1, p1 = run(m)
+    torch.testing.assert_close(p1, p0, rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(o1, o0, rtol=2e-3, atol=2e-3)
 
 
 def test_hadamard_vs_reference(golden_dir):
@@ -113,5 +187,6 @@ def test_hadamard_vs_reference(golden_dir):
     np.testing.assert_allclose(vt1.cpu().numpy(), g["fuse/vt1"], rtol=0, atol=5e-6)
     for a, b in zip(u1, g["fuse/u1"]):
         np.testing.assert_allclose(a.cpu().numpy(), b, rtol=0, atol=5e-6)
-    with pytest.raises(NotImplementedError):
-        hu.apply_hadamard(torch.zeros(2, 160, device="cuda"))
+    with pytest.raises(ValueError):
+        hu.apply_hadamard(torch.zeros(2, 120, device="cuda"))      # 120 = 60 * 2 is fine; 24 * 5 is not: no table -> refuse
+

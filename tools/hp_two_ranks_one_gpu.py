@@ -13,6 +13,9 @@ import torch.multiprocessing as mp
 H, G, D, HIDDEN, RK, RV, LP = 32, 8, 128, 4096, 1024, 3072, 4096
 
 
+OPROJ = "replicated"
+
+
 def build(world, rank, dev):
     from palu_amd.kernel import head_parallel as hp
     torch.manual_seed(1234)
@@ -27,12 +30,14 @@ def build(world, rank, dev):
     v_all = torch.randn(G, cap, Rv, device=dev, dtype=torch.float16)
     hidden = torch.randn(HIDDEN, device=dev, dtype=torch.float16)
     plan = hp.make_plan(world, rank, H, G, D, Rk, Rv)
-    w = {k: v.contiguous() for k, v in hp.shard_weights(plan, full).items()}
+    w = {k: v.contiguous() if k != "wo" else v for k, v in hp.shard_weights(plan, full, oproj=OPROJ).items()}
     kc, vc = hp.shard_cache(plan, k_all, v_all)
     return hp.HeadParallelDecoder(plan, w, kc.contiguous(), vc.contiguous(), HIDDEN), hidden
 
 
-def worker(rank, world, port, q):
+def worker(rank, world, port, q, oproj):
+    global OPROJ
+    OPROJ = oproj
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
@@ -46,6 +51,14 @@ def worker(rank, world, port, q):
         orig(o, i, group=group)
         out.copy_(o)
     dist.all_gather_into_tensor = via_host
+    orig_ar = dist.all_reduce
+
+    def ar_via_host(t, op=dist.ReduceOp.SUM, group=None):
+        h = t.cpu()
+        orig_ar(h, op=op, group=group)
+        t.copy_(h)
+    dist.all_reduce = ar_via_host
+    assert dec.oproj_sharded == (oproj == "sharded")
     out = dec.step(hidden, LP, LP).float().cpu()
     torch.cuda.synchronize()
     if rank == 0:
@@ -54,24 +67,32 @@ def worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def main():
+def run_world2(oproj):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=worker, args=(r, 2, port, q, oproj)) for r in range(2)]
     for p in procs:
         p.start()
     sharded = q.get(timeout=300)
     for p in procs:
         p.join(timeout=300)
+    return sharded
+
+
+def main():
+    ok = True
     dec, hidden = build(1, 0, torch.device("cuda", 0))
     ref = dec.step(hidden, LP, LP).float().cpu()
-    err = (sharded - ref).abs().max().item()
-    print(f"world 2 on one GPU vs unsharded: max|diff| = {err:.3e} (scale {ref.abs().max().item():.3e})")
-    sys.exit(0 if err <= 1e-3 * max(1.0, ref.abs().max().item()) else 1)
+    for oproj in ("replicated", "sharded"):
+        sharded = run_world2(oproj)
+        err = (sharded - ref).abs().max().item()
+        print(f"world 2 on one GPU ({oproj} o_proj) vs unsharded: max|diff| = {err:.3e} (scale {ref.abs().max().item():.3e})")
+        ok &= err <= 1e-3 * max(1.0, ref.abs().max().item())
+    sys.exit(0 if ok else 1)
 
 
 if __name__ == "__main__":
