@@ -16,6 +16,15 @@ namespace {
 
 static __device__ __forceinline__ float r16(float x) { return (float)(h16)x; }  // round to fp16, keep as float
 
+// fp16 value * fp32 scalar the way torch does it: the product is rounded to fp32 FIRST, then to fp16.  Left to the
+// compiler, (h16)(a * b) becomes one v_fma_mixlo_f16 (a single rounding of the exact product), which differs whenever
+// the fp32-rounded product lands on an fp16 tie (seen on golden G5: 3.115234375 * 0.9f).
+static __device__ __forceinline__ float mul_r32_r16(float a, float b) {
+  float p = a * b;
+  asm volatile("" : "+v"(p));
+  return r16(p);
+}
+
 struct QpTensor {
   const h16* x;  int64_t sx_g, sx_l;
   unsigned char* codes; int64_t sc_g, sc_l;
@@ -50,14 +59,15 @@ static __device__ __forceinline__ void quantize_row(const QpTensor& t, int g, in
   if (SYM) {
     // quant.py:18-24: w_max = amax|w|.clamp(min=1e-5) [* clip]; scales = w_max / q_max; base = 0
     float top = fmaxf(fmaxf(mx, -mn), floor16);
-    if (t.clip < 1.0f) top = r16(top * t.clip);
+    // Half tensor * Python scalar: fp32 product of the fp16 value and (float)clip, rounded once (torch semantics)
+    if (t.clip < 1.0f) top = mul_r32_r16(top, t.clip);
     scale = r16(top / QMAX);
     zero = 0.f;
   } else {
     // quant.py:29-38: [max, min *= clip]; scales = (max-min).clamp(min=1e-5)/q_max ; base = round(-min/scales).clamp(0, q_max)
     if (t.clip < 1.0f) {
-      mx = r16(mx * t.clip);
-      mn = r16(mn * t.clip);
+      mx = mul_r32_r16(mx, t.clip);
+      mn = mul_r32_r16(mn, t.clip);
     }
     float range = r16(mx - mn);
     range = fmaxf(range, floor16);

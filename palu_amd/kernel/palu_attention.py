@@ -455,6 +455,13 @@ class LlamaPaluAttention(nn.Module):
         x = hidden_states.reshape(-1)
         if not x.is_contiguous():
             x = x.contiguous()
+        if probs is None:
+            # through the dispatcher (torch.ops.palu.decode_step, palu_amd/ops.py): torch.compile / export see one node
+            from .. import ops as _ops  # noqa: F401  (registers the ops on first use)
+            o = torch.ops.palu.decode_step(x, wq, vtk, vtv, frag, wo, kbuf[0], vbuf[0], inv, ws, self._ws_cap, H, n, int(pos),
+                                           attention_mask)
+            cache.advance(li, 1)
+            return o.view(1, 1, self.hidden_size), None
         _lib.check(_lib.lib.palu_decode_step_f16(
             x.data_ptr(), wq.data_ptr(), wq.stride(0), vtk.data_ptr(), vtk.stride(0), vtv.data_ptr(), vtv.stride(0),
             frag.data_ptr(), wo.data_ptr(), wo.stride(0),
@@ -490,6 +497,12 @@ class LlamaPaluAttention(nn.Module):
         wq, vtk, vtv, wo = self.q_proj.weight, self.k_proj.VT.weight, self.v_proj.VT.weight, self.o_proj.weight
         x = hidden_states.reshape(-1).contiguous()
         kc, km, vc, vm = st["kc"], st["km"], st["vc"], st["vm"]
+        if probs is None:
+            from .. import ops as _ops  # noqa: F401
+            o = torch.ops.palu.decode_step_q(x, wq, vtk, vtv, frag, wo, kc[0], km[0], vc[0], vm[0], inv, ws, self._ws_cap, H,
+                                             self.group_rank_k, self.group_rank_v, cache.n_bits, n, int(pos), attention_mask)
+            cache.advance(li, 1)
+            return o.view(1, 1, self.hidden_size), None
         _lib.check(_lib.lib.palu_decode_step_q(
             x.data_ptr(), wq.data_ptr(), wq.stride(0), vtk.data_ptr(), vtk.stride(0), vtv.data_ptr(), vtv.stride(0),
             frag.data_ptr(), wo.data_ptr(), wo.stride(0),

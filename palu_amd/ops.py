@@ -9,6 +9,12 @@ dispatcher (torch.compile / export see opaque ops with fake kernels).  Importing
     palu::hadamard_transform(x, scale) -> Tensor                      fast_hadamard_transform.hadamard_transform
     palu::rope_(x, pos0, theta=1e4) -> ()   (in place)                 rotary_emb + apply_rotary_pos_emb (:204-205)
     palu::prefill_attn(q, k, v_lat, past, causal, scale) -> Tensor    prompt branch :205-255, flash-style
+    palu::decode_step(hidden, wq, vt_k, vt_v, bfrag, wo, k_cache!, v_cache!, inv_freq, workspace!, ...) -> Tensor
+                                                                      the decode branch :207-257 in one node (! = mutated)
+    palu::decode_step_q(... k_codes!, k_meta!, v_codes!, v_meta! ...) -> Tensor   the same on a packed 3/4-bit cache
+    palu::decode_attn(q, bfrag, k, v, inv_freq, workspace!, H, L, pos0) -> Tensor  single-kernel scores+softmax+P.V
+    palu::lowrank_project_gemm(x, w, cache!, row0) -> ()              prefill down-projection into the cache rows
+    palu::pack_codes(codes, bits) / palu::unpack_codes(packed, bits, rank)
 
 All run on the current stream and allocate only through torch's caching allocator (graph-capturable).
 """
@@ -148,3 +154,136 @@ def prefill_attn(q: torch.Tensor, k: torch.Tensor, v_lat: torch.Tensor, past: in
 @prefill_attn.register_fake
 def _(q, k, v_lat, past=0, causal=True, scale=1.0 / math.sqrt(128.0)):
     return q.new_empty((q.shape[1], q.shape[0] * v_lat.shape[2]))
+
+
+# ------------------------------------------------------------------------------------------------------------
+# The decode step itself as dispatcher ops (SURVEY.md 8(b) "new ops"): the caches and the workspace are mutated in
+# place (mutates_args), so torch.compile / export see ONE opaque node per token and functionalisation keeps the
+# in-place cache append.  LlamaPaluAttention._decode_fused / _decode_fused_q call these.
+@torch.library.custom_op("palu::decode_step", mutates_args=("k_cache", "v_cache", "workspace"))
+def decode_step(hidden: torch.Tensor, wq: torch.Tensor, vt_k: torch.Tensor, vt_v: torch.Tensor, bfrag: torch.Tensor,
+                wo: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, inv_freq: torch.Tensor,
+                workspace: torch.Tensor, ws_capacity: int, num_heads: int, cache_len: int, pos: int,
+                mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One decode token on an fp16 latent cache (palu_decode_step_f16; kernel/palu_attention.py:207-257).
+    hidden [hidden_size]; k_cache [G, cap, Rk] / v_cache [G, cap, Rv] hold cache_len rows and receive row cache_len;
+    bfrag from palu_abx_prepare_b; workspace of palu_decode_workspace_bytes(H, G, D, ws_capacity, Rv) bytes."""
+    G, cap, Rk = k_cache.shape
+    Rv = v_cache.shape[2]
+    hidden_size = wq.shape[1]
+    D = wq.shape[0] // num_heads
+    x = hidden.reshape(-1).contiguous()
+    out = torch.empty(hidden_size, dtype=torch.float16, device=hidden.device)
+    m = None if mask is None else mask.reshape(-1).to(torch.float16).contiguous()
+    with _lib.on_device(hidden):
+        _lib.check(_lib.lib.palu_decode_step_f16(
+            x.data_ptr(), wq.data_ptr(), wq.stride(0), vt_k.data_ptr(), vt_k.stride(0), vt_v.data_ptr(), vt_v.stride(0),
+            bfrag.data_ptr(), wo.data_ptr(), wo.stride(0),
+            k_cache.data_ptr(), k_cache.stride(0), k_cache.stride(1), v_cache.data_ptr(), v_cache.stride(0), v_cache.stride(1),
+            0 if m is None else m.data_ptr(), inv_freq.data_ptr(), out.data_ptr(), 0, 0,
+            workspace.data_ptr(), int(ws_capacity), num_heads, G, D, hidden_size, Rk, Rv, int(cache_len), int(pos),
+            _lib.current_stream()), "palu_decode_step_f16")
+    return out
+
+
+@decode_step.register_fake
+def _(hidden, wq, vt_k, vt_v, bfrag, wo, k_cache, v_cache, inv_freq, workspace, ws_capacity, num_heads, cache_len, pos,
+      mask=None):
+    return hidden.new_empty((wq.shape[1],))
+
+
+@torch.library.custom_op("palu::decode_step_q", mutates_args=("k_codes", "k_meta", "v_codes", "v_meta", "workspace"))
+def decode_step_q(hidden: torch.Tensor, wq: torch.Tensor, vt_k: torch.Tensor, vt_v: torch.Tensor, bfrag: torch.Tensor,
+                  wo: torch.Tensor, k_codes: torch.Tensor, k_meta: torch.Tensor, v_codes: torch.Tensor,
+                  v_meta: torch.Tensor, inv_freq: torch.Tensor, workspace: torch.Tensor, ws_capacity: int,
+                  num_heads: int, rank_k: int, rank_v: int, bits: int, cache_len: int, pos: int,
+                  mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One decode token on a packed 3/4-bit latent cache (palu_decode_step_q): codes [G, cap, R*bits/8] uint8,
+    meta [G, cap, 2] fp16 = (scale, zero); the new latent rows are quantised + packed into row cache_len."""
+    G = k_codes.shape[0]
+    hidden_size = wq.shape[1]
+    D = wq.shape[0] // num_heads
+    x = hidden.reshape(-1).contiguous()
+    out = torch.empty(hidden_size, dtype=torch.float16, device=hidden.device)
+    m = None if mask is None else mask.reshape(-1).to(torch.float16).contiguous()
+    with _lib.on_device(hidden):
+        _lib.check(_lib.lib.palu_decode_step_q(
+            x.data_ptr(), wq.data_ptr(), wq.stride(0), vt_k.data_ptr(), vt_k.stride(0), vt_v.data_ptr(), vt_v.stride(0),
+            bfrag.data_ptr(), wo.data_ptr(), wo.stride(0),
+            k_codes.data_ptr(), k_codes.stride(0), k_codes.stride(1), k_meta.data_ptr(), k_meta.stride(0), k_meta.stride(1),
+            v_codes.data_ptr(), v_codes.stride(0), v_codes.stride(1), v_meta.data_ptr(), v_meta.stride(0), v_meta.stride(1),
+            0 if m is None else m.data_ptr(), inv_freq.data_ptr(), out.data_ptr(), 0, 0,
+            workspace.data_ptr(), int(ws_capacity), num_heads, G, D, hidden_size, int(rank_k), int(rank_v), int(bits),
+            int(cache_len), int(pos), _lib.current_stream()), "palu_decode_step_q")
+    return out
+
+
+@decode_step_q.register_fake
+def _(hidden, wq, vt_k, vt_v, bfrag, wo, k_codes, k_meta, v_codes, v_meta, inv_freq, workspace, ws_capacity, num_heads,
+      rank_k, rank_v, bits, cache_len, pos, mask=None):
+    return hidden.new_empty((wq.shape[1],))
+
+
+@torch.library.custom_op("palu::lowrank_project_gemm", mutates_args=("cache",))
+def lowrank_project_gemm(x: torch.Tensor, w: torch.Tensor, cache: torch.Tensor, row0: int) -> None:
+    """Prefill down-projection (MFMA GEMM) written into the latent-cache layout: cache[g, row0 + m, :] = x[m] . w[g*R:(g+1)*R]^T
+    for x [M, K], w = VT [G*R, K], cache [G, cap, R] (HeadwiseLowRankModule.project_to_latent, :59-65, :167-168)."""
+    M, K = x.shape
+    N = w.shape[0]
+    G, cap, R = cache.shape
+    assert N == G * R and row0 + M <= cap and x.dtype == w.dtype == cache.dtype == torch.float16
+    if x.stride(1) != 1 or x.stride(0) % 8:
+        x = x.contiguous()
+    with _lib.on_device(x):
+        _lib.check(_lib.lib.palu_lowrank_project_gemm(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), cache.data_ptr(),
+                                                      cache.stride(0), cache.stride(1), M, N, K, R, int(row0),
+                                                      _lib.current_stream()), "palu_lowrank_project_gemm")
+
+
+@lowrank_project_gemm.register_fake
+def _(x, w, cache, row0):
+    return None
+
+
+@torch.library.custom_op("palu::pack_codes", mutates_args=())
+def pack_codes(codes_u8: torch.Tensor, bits: int) -> torch.Tensor:
+    return _quant.pack_codes(codes_u8, bits)
+
+
+@pack_codes.register_fake
+def _(codes_u8, bits):
+    return codes_u8.new_empty((*codes_u8.shape[:-1], codes_u8.shape[-1] * bits // 8))
+
+
+@torch.library.custom_op("palu::unpack_codes", mutates_args=())
+def unpack_codes(packed: torch.Tensor, bits: int, rank: int) -> torch.Tensor:
+    return _quant.unpack_codes(packed, bits, rank)
+
+
+@unpack_codes.register_fake
+def _(packed, bits, rank):
+    return packed.new_empty((*packed.shape[:-1], rank))
+
+
+@torch.library.custom_op("palu::decode_attn", mutates_args=("workspace",))
+def decode_attn(q: torch.Tensor, bfrag: torch.Tensor, k: torch.Tensor, v: torch.Tensor, inv_freq: torch.Tensor,
+                workspace: torch.Tensor, num_heads: int, length: int, pos0: int = 0) -> torch.Tensor:
+    """Single-kernel attention core (palu_decode_attn_f16): scores -> /sqrt(D) -> softmax -> latent P.V over the first
+    `length` rows of k [G, cap, Rk] / v [G, cap, Rv]; q [H, D] rotated query -> ctx [H, Rv]."""
+    G, _, Rk = k.shape
+    Rv = v.shape[2]
+    D = q.shape[-1]
+    q2 = q.reshape(num_heads, D)
+    ctx = torch.empty((num_heads, Rv), dtype=torch.float16, device=q.device)
+    with _lib.on_device(q):
+        _lib.check(_lib.lib.palu_decode_attn_f16(q2.data_ptr(), q2.stride(0), q2.stride(1), bfrag.data_ptr(), k.data_ptr(),
+                                                 k.stride(0), k.stride(1), v.data_ptr(), v.stride(0), v.stride(1),
+                                                 ctx.data_ptr(), workspace.data_ptr(), num_heads, G, int(length), Rk, Rv, D,
+                                                 inv_freq.data_ptr(), int(pos0), math.sqrt(D), _lib.current_stream()),
+                   "palu_decode_attn_f16")
+    return ctx
+
+
+@decode_attn.register_fake
+def _(q, bfrag, k, v, inv_freq, workspace, num_heads, length, pos0=0):
+    return q.new_empty((num_heads, v.shape[2]))

@@ -137,7 +137,7 @@ def test_hadamard_every_hadk_width_vs_reference(golden_dir):
     x = torch.randn(5, 320, device="cuda")
     np.testing.assert_allclose(hu.apply_hadamard(hu.apply_hadamard(x), transpose=True).cpu().numpy(), x.cpu().numpy(), atol=2e-5)
     with pytest.raises(ValueError):
-        hu.get_hadK(24 * 5)
+        hu.get_hadK(40 * 5)
 
 
 def test_fuse_hadamard_at_rank_search_widths():
@@ -188,5 +188,5 @@ def test_hadamard_vs_reference(golden_dir):
     for a, b in zip(u1, g["fuse/u1"]):
         np.testing.assert_allclose(a.cpu().numpy(), b, rtol=0, atol=5e-6)
     with pytest.raises(ValueError):
-        hu.apply_hadamard(torch.zeros(2, 120, device="cuda"))      # 120 = 60 * 2 is fine; 24 * 5 is not: no table -> refuse
+        hu.apply_hadamard(torch.zeros(2, 200, device="cuda"))      # 200 = 40 * 5: not K * 2^m (the reference asserts too)
 
