@@ -71,6 +71,15 @@ int palu_abx_rope_f16(const void* a, int64_t sa_h, int64_t sa_d,
                       int H, int G, int L, int R, int D,
                       const float* inv_freq, int pos0, palu_stream_t stream);
 
+/* Shared-B fast path: when b[h] is identical for the gs heads of every group (true-GQA checkpoints,
+ * palu/model/svd_mistral/modeling_palu_mistral.py:37-59) the keys are reconstructed once per group instead of once per
+ * head -- a quarter of the MFMA work, which makes the kernel VALU/HBM- instead of MFMA-bound.  bfrag_shared =
+ * palu_abx_prepare_b(b_g [G, R, D], H := G, G) of palu_abx_bfrag_bytes(G, G, R) bytes.  Same output as
+ * palu_abx_rope_f16 with b[h] = b_g[h / gs] (q is kept in fp32, like palu_abx_set_fold(0)).  R in {32,64,128}, gs 2..4. */
+int palu_abx_rope_shared_f16(const void* a, int64_t sa_h, int64_t sa_d, const void* bfrag_shared,
+                             const void* x, int64_t sx_g, int64_t sx_l, void* out, int64_t so_h,
+                             int H, int G, int L, int R, int D, const float* inv_freq, int pos0, palu_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * softmax + latent-space P.V   (replaces kernel/palu_attention.py:219 "/sqrt(D)", :229-234 mask,
  * :238 softmax(fp32)->fp16, :246-251 attn[1,G,gs,L] @ V_lat[1,G,L,Rv])

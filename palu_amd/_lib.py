@@ -41,6 +41,7 @@ SIGNATURES = {
     "palu_abx_set_fold": (i32, [i32]),
     "palu_abx_prepare_b": (i32, [vp, i64, i64, i64, i32, i32, i32, i32, vp, vp]),
     "palu_abx_rope_f16": (i32, [vp, i64, i64, vp, vp, i64, i64, vp, i64, i32, i32, i32, i32, i32, vp, i32, vp]),
+    "palu_abx_rope_shared_f16": (i32, [vp, i64, i64, vp, vp, i64, i64, vp, i64, i32, i32, i32, i32, i32, vp, i32, vp]),
     "palu_pv_nsplit": (i32, [i32, i32]),
     "palu_pv_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "palu_pv_stats_offset": (sz, [i32, i32, i32, i32]),

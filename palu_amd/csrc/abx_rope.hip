@@ -23,6 +23,16 @@ int launch_abx_generic(const AbxParams& p, int nwg, hipStream_t stream) {
 
 int g_abx_fold = 1;
 
+template <int NKS, int NMB>
+int launch_abx_shared(const AbxParams& p, int nwg, hipStream_t stream) {
+  if ((int64_t)p.pos0 + p.L > 262144) {
+    static bool attr_done2 = false;
+    return launch_kernel(abx_rope_kernel<NKS, NMB, false, false, 0, true, true>, abx_smem_fast(NKS), &attr_done2, p, nwg, stream);
+  }
+  static bool attr_done = false;
+  return launch_kernel(abx_rope_kernel<NKS, NMB, false, false, 0, false, true>, abx_smem_fast(NKS), &attr_done, p, nwg, stream);
+}
+
 }  // namespace
 
 extern "C" int palu_abx_set_fold(int enable) {
@@ -114,4 +124,43 @@ extern "C" int palu_abx_rope_f16_timed(const void* a, int64_t sa_h, int64_t sa_d
   if (nwg_out) *nwg_out = nwg;
   static bool attr_done = false;
   return launch_kernel(abx_rope_kernel<8, 2, true, true>, abx_smem_fast(8), &attr_done, p, nwg, (hipStream_t)stream);
+}
+
+// abx when every head of a latent group uses the same B (true-GQA: the query heads of a group share one KV head):
+// bfrag = palu_abx_prepare_b of the shared factor b_g [G, R, D] (as H = G heads in G groups).  Same math and output as
+// palu_abx_rope_f16 with b[h] = b_g[h / gs]; K is reconstructed once per group.  R in {32, 64, 128}, gs in {2, 3, 4}.
+extern "C" int palu_abx_rope_shared_f16(const void* a, int64_t sa_h, int64_t sa_d, const void* bfrag_shared, const void* x,
+                                        int64_t sx_g, int64_t sx_l, void* out, int64_t so_h, int H, int G, int L, int R,
+                                        int D, const float* inv_freq, int pos0, palu_stream_t stream) {
+  AbxPlan pl;
+  PALU_REQUIRE(abx_plan(H, G, R, &pl), PALU_ERR_ARG, "abx_shared: bad shape H=%d G=%d R=%d", H, G, R);
+  PALU_REQUIRE(D == HEAD_DIM, PALU_ERR_UNSUPPORTED, "abx_shared: head_dim must be 128 (got %d)", D);
+  PALU_REQUIRE(!pl.chunked && pl.gs >= 2 && pl.gs <= 4, PALU_ERR_UNSUPPORTED,
+               "abx_shared: needs R in {32,64,128} and 2..4 heads per group (R=%d gs=%d)", R, pl.gs);
+  PALU_REQUIRE(L >= 0, PALU_ERR_ARG, "abx_shared: negative L");
+  if (L == 0) return PALU_OK;
+  PALU_REQUIRE(a && bfrag_shared && x && out && inv_freq, PALU_ERR_ARG, "abx_shared: null pointer");
+  PALU_REQUIRE(((uintptr_t)x & 15) == 0 && sx_g % 8 == 0 && sx_l % 8 == 0 && sx_l >= R, PALU_ERR_ARG,
+               "abx_shared: x rows must be 16-byte aligned and contiguous");
+  PALU_REQUIRE(((int64_t)L + 3 * 128) * sx_l * 2 < ((int64_t)1 << 32), PALU_ERR_ARG,
+               "abx_shared: one group's latent slab must stay below 4 GiB");
+  PALU_REQUIRE(((uintptr_t)bfrag_shared & 15) == 0, PALU_ERR_ARG, "abx_shared: bfrag must be 16-byte aligned");
+  PALU_REQUIRE((int64_t)pos0 + L < (1 << 24), PALU_ERR_UNSUPPORTED, "abx_shared: positions must stay below 2^24");
+  const int64_t ob = ((int64_t)(H - 1) * so_h + L) * 2;
+  PALU_REQUIRE(ob > 0 && ob < 0xFFFFFFF0ll, PALU_ERR_UNSUPPORTED, "abx_shared: out extent must be < 4 GiB");
+  AbxParams p = {};
+  p.a = (const h16*)a; p.sa_h = sa_h; p.sa_d = sa_d;
+  p.bfrag = (const u32x4*)bfrag_shared;
+  p.x = (const h16*)x; p.sx_g = sx_g; p.sx_l = sx_l;
+  p.out = (h16*)out; p.so_h = so_h; p.out_bytes = (unsigned)ob;
+  p.inv_freq = inv_freq;
+  const int nwg = abx_fill_params(p, pl, H, G, L, R, pos0);
+  hipStream_t s = (hipStream_t)stream;
+#define PALU_ABX_SH(NKS) (pl.nmb == 2 ? launch_abx_shared<NKS, 2>(p, nwg, s) : launch_abx_shared<NKS, 1>(p, nwg, s))
+  switch (R) {
+    case 32: return PALU_ABX_SH(2);
+    case 64: return PALU_ABX_SH(4);
+    default: return PALU_ABX_SH(8);
+  }
+#undef PALU_ABX_SH
 }

@@ -367,10 +367,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_generic_kernel(AbxParams
 // independent instruction streams in one basic block (two accumulator sets), so the matrix pipe
 // and the VALU overlap inside a wave as well as across the two waves of a SIMD.
 // ORDER2: keep the lo^2/2 term of the angle correction (needed once positions exceed 2^18, see chunk t == 0).
-template <int NKS, int NMB, bool FOLD, bool TIMING = false, int QBITS = 0, bool ORDER2 = false>
+// SHARED: all heads of a latent group use the SAME B (true-GQA checkpoints: the query heads of a group share one KV
+// head, palu/model/svd_mistral/modeling_palu_mistral.py:37-59).  K is then reconstructed ONCE per group -- one M-block
+// per wave (half of its rows unused) instead of one per head pair, a quarter of the useful MFMA work -- and the 2*NMB
+// query heads are applied in the epilogue: rotate (k_i, k_i+64) once per pair, two FMAs per head.  The fragments come
+// from palu_abx_prepare_b on the [G, R, D] shared factor (one head per group); FOLD is not used.
+template <int NKS, int NMB, bool FOLD, bool TIMING = false, int QBITS = 0, bool ORDER2 = false, bool SHARED = false>
 __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
   using Geo = LdsGeom<NKS>;
+  static_assert(!SHARED || !FOLD, "the shared-B variant keeps q in the epilogue");
   constexpr int HPW = 2 * NMB;
+  constexpr int NMM = SHARED ? 1 : NMB;      // M-blocks per wave on the matrix pipe
   constexpr int NRING = 3;                // X tiles resident in LDS
   constexpr int RED_STRIDE = 8 * 4 * TL;  // floats per red buffer: [8 waves][4 slots][TL]
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -505,10 +512,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
   }
 
   // ---- B fragments (issued early; consumed by the fold / first MFMA)
-  const u32x4* bf_base = p.bfrag + ((int64_t)(gb * 8 + w) * NMB) * NKS * 64 + lane;
-  h16x8 bf[NMB][NKS];
+  const u32x4* bf_base = p.bfrag + ((int64_t)(gb * 8 + w) * NMM) * NKS * 64 + lane;
+  h16x8 bf[NMM][NKS];
 #pragma unroll
-  for (int mb = 0; mb < NMB; ++mb)
+  for (int mb = 0; mb < NMM; ++mb)
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
       u32x4 v = bf_base[(int64_t)(mb * NKS + ks) * 64];
@@ -635,11 +642,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
   //      KIND 0 also carries the LDS-DMA pieces of tile stt into ring slot sslot (or the quantised staging),
   //      KIND 1 the reduce/store of tile stt (partials in red[sslot]); LAST = block 3: the fragment prefetch
   //      crosses into block 0 of the next tile (ring distance nd bytes); KIND 3 = drain (epilogue only).
-  auto region = [&](auto kind_c, auto last_c, f32x16 (&acN)[NMB], int blk, int erslot, int eblk,
-                    const f32x16 (&acP)[NMB], int stt, int sslot, unsigned nd) {
+  auto region = [&](auto kind_c, auto last_c, f32x16 (&acN)[NMM], int blk, int erslot, int eblk,
+                    const f32x16 (&acP)[NMM], int stt, int sslot, unsigned nd) {
     constexpr int KIND = decltype(kind_c)::value;
     constexpr bool LAST = decltype(last_c)::value;
-    constexpr int GAPS = NKS * NMB;
+    constexpr int GAPS = NKS * NMM;
     // chunks per pair j: [ang, lo, cc, ss] | per M-block: 2 FMAs x 2 heads | [advance cos, sin by 32 positions].
     // (Packed fp32 -- v_pk_fma_f32 over head pairs -- was measured and is an anti-lever beside MFMAs on gfx950:
     //  75.5 vs 69 us; hipcc itself unpacks half of them again in the MFMA shadow.)
@@ -647,13 +654,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
     constexpr int NC = 4 * CPP;
     constexpr int CPG = (NC + GAPS - 1) / GAPS;
 #pragma unroll
-    for (int mb = 0; mb < NMB; ++mb)
+    for (int mb = 0; mb < NMM; ++mb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acN[mb][e] = 0.f;
     float part[HPW];
 #pragma unroll
     for (int s = 0; s < HPW; ++s) part[s] = 0.f;
-    float cc = 0.f, ss = 0.f;
+    float cc = 0.f, ss = 0.f, kr1 = 0.f, kr2 = 0.f;
     auto chunk = [&](int c) {
       const int j = c / CPP, t = c % CPP;
       if (t == 0) {
@@ -673,6 +680,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
         asm volatile("" : "+v"(cc), "+v"(ss));
       } else if (t <= NMB) {
         const int mb = t - 1;
+        if (SHARED) {
+          // one reconstructed key per group: rotate the pair once (first chunk of the pair), two FMAs per head
+          if (mb == 0) {
+            const float k1 = acP[0][4 * j], k2 = acP[0][4 * j + 2];
+            kr1 = fmaf(-ss, k2, cc * k1);
+            kr2 = fmaf(ss, k1, cc * k2);
+            asm volatile("" : "+v"(kr1), "+v"(kr2));
+          }
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const int s = 2 * mb + h2;
+            part[s] = fmaf(q1[s][j], kr1, fmaf(q2[s][j], kr2, part[s]));
+            asm volatile("" : "+v"(part[s]));
+          }
+        } else
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
           const float k1 = acP[mb][4 * j + h2], k2 = acP[mb][4 * j + 2 + h2];
@@ -697,8 +719,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
 #pragma unroll
-      for (int mb = 0; mb < NMB; ++mb) {
-        const int gap = ks * NMB + mb;
+      for (int mb = 0; mb < NMM; ++mb) {
+        const int gap = ks * NMM + mb;
         if (KIND != 3) {
           acN[mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[mb][ks], xf[ks % XD], acN[mb], 0, 0, 0);
           asm volatile("" : "+v"(acN[mb]));    // empty volatile asm = ordering pin (arithmetic floats across sched_barrier)
@@ -706,7 +728,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
 #pragma unroll
         for (int q = 0; q < CPG; ++q)
           if (gap * CPG + q < NC) chunk(gap * CPG + q);
-        if (KIND != 3 && mb == NMB - 1) {
+        if (KIND != 3 && mb == NMM - 1) {
           // refill the ring entry just consumed with the fragment XD k-steps ahead
           const int r = ks + XD;
           if (r < NKS) {
@@ -725,8 +747,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
             }
           }
         }
-        if (KIND == 0 && QBITS == 0 && gap % (2 * NMB) == 1 && gap / (2 * NMB) < Geo::SPT)
-          dma_piece(stt, sslot, gap / (2 * NMB));
+        if (KIND == 0 && QBITS == 0 && gap % (2 * NMM) == 1 && gap / (2 * NMM) < Geo::SPT)
+          dma_piece(stt, sslot, gap / (2 * NMM));
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -748,9 +770,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  f32x16 accA[NMB], accB[NMB];
+  f32x16 accA[NMM], accB[NMM];
 #pragma unroll
-  for (int mb = 0; mb < NMB; ++mb)
+  for (int mb = 0; mb < NMM; ++mb)
 #pragma unroll
     for (int e = 0; e < 16; ++e) accB[mb][e] = 0.f;
 

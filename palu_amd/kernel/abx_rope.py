@@ -44,8 +44,10 @@ def invalidate_b(b: torch.Tensor | None = None) -> None:
     that mutates B that way calls this afterwards (LlamaPaluAttention.fuse_hadamard / load_state_dict hooks do)."""
     if b is None:
         _bfrag_cache.clear()
+        _shared_cache.clear()
     else:
         _bfrag_cache.pop(id(b), None)
+        _shared_cache.pop(id(b), None)
 
 
 def prepare_b(b: torch.Tensor, num_groups: int) -> torch.Tensor:
@@ -73,6 +75,32 @@ def prepare_b(b: torch.Tensor, num_groups: int) -> torch.Tensor:
     return frag
 
 
+_shared_cache: dict = {}
+
+
+def shared_b(b: torch.Tensor, num_groups: int):
+    """If B [H,R,D] is identical for the heads of every latent group (true-GQA: the query heads of a group share one KV
+    head), return the [G,R,D] shared factor, else None.  Cached per tensor like prepare_b (one device comparison per
+    weight); shapes the shared kernel does not cover return None."""
+    H, R, D = b.shape
+    gs = H // num_groups
+    if gs < 2 or gs > 4 or R not in (32, 64, 128) or H % num_groups:
+        return None
+    key = id(b)
+    hit = _shared_cache.get(key)
+    if hit is not None:
+        ref, ver, ptr, G, res = hit
+        if ref() is b and ver == b._version and ptr == b.data_ptr() and G == num_groups:
+            return res
+    bg = b.view(num_groups, gs, R, D)
+    res = bg[:, 0].contiguous() if bool((bg == bg[:, :1]).all()) else None
+    if len(_shared_cache) > 256:
+        for k in [k for k, v in list(_shared_cache.items()) if v[0]() is None]:
+            del _shared_cache[k]
+    _shared_cache[key] = (weakref.ref(b), b._version, b.data_ptr(), num_groups, res)
+    return res
+
+
 def abx(a: torch.Tensor, b: torch.Tensor, x: torch.Tensor, *, theta: float = 10000.0,
         pos_offset: int = 0, out: torch.Tensor | None = None) -> torch.Tensor:
     assert a.dim() == 3
@@ -90,12 +118,21 @@ def abx(a: torch.Tensor, b: torch.Tensor, x: torch.Tensor, *, theta: float = 100
     if x.stride(2) != 1 or x.stride(1) % 8 or x.stride(0) % 8 or x.data_ptr() % 16:
         x = x.contiguous()
     with _lib.on_device(x):                 # launches go to the current device: make it the tensors' GPU
-        frag = prepare_b(b, G)
         if out is None:
             out = torch.empty((H, 1, L), dtype=x.dtype, device=x.device)
         else:
             assert out.shape == (H, 1, L) and out.dtype == torch.float16 and out.stride(2) == 1
         inv = rope_inv_freq(x.device, D, theta)
+        bg = shared_b(b, G)
+        if bg is not None:
+            # every head of a group uses the same B: reconstruct the keys once per group (a quarter of the MFMA work)
+            frag = prepare_b(bg, G)
+            _lib.check(_lib.lib.palu_abx_rope_shared_f16(a.data_ptr(), a.stride(0), a.stride(2), frag.data_ptr(),
+                                                         x.data_ptr(), x.stride(0), x.stride(1), out.data_ptr(),
+                                                         out.stride(0), H, G, L, R, D, inv.data_ptr(), int(pos_offset),
+                                                         _lib.current_stream()), "palu_abx_rope_shared_f16")
+            return out
+        frag = prepare_b(b, G)
         _lib.check(_lib.lib.palu_abx_rope_f16(a.data_ptr(), a.stride(0), a.stride(2), frag.data_ptr(),
                                               x.data_ptr(), x.stride(0), x.stride(1),
                                               out.data_ptr(), out.stride(0), H, G, L, R, D,

@@ -141,6 +141,45 @@ def test_abx_positions_beyond_2_18(R):
     assert err <= 1.5 * err0 + 1e-5, (err, err0)
 
 
+@pytest.mark.parametrize("H,gs,R,L", [(32, 4, 128, 2049), (32, 4, 64, 700), (8, 2, 32, 333), (24, 3, 128, 1000), (32, 4, 128, 65537)])
+def test_abx_shared_b_fast_path(H, gs, R, L):
+    """N3: when the heads of a group share B (true-GQA checkpoints) abx reconstructs the keys once per group
+    (palu_abx_rope_shared_f16, picked automatically by `abx`).  Against the oracle with the tied B, and against the
+    per-head kernel fed the same tied B through the C ABI."""
+    from palu_amd import _lib
+    from palu_amd.kernel.abx_rope import prepare_b, rope_inv_freq, shared_b
+    rng = np.random.default_rng(H + R + L)
+    G = H // gs
+    a = torch.from_numpy(rng.standard_normal((H, 1, 128)).astype(np.float16))
+    bg = torch.from_numpy((rng.standard_normal((G, 1, R, 128)) / np.sqrt(R)).astype(np.float16))
+    b = bg.expand(G, gs, R, 128).reshape(H, R, 128).contiguous()
+    x = torch.from_numpy(rng.standard_normal((G, L, R)).astype(np.float16))
+    ad, bd, xd = a.cuda(), b.cuda(), x.cuda()
+    assert shared_b(bd, G) is not None
+    got = _abx()(ad, bd, xd)
+    # the per-head kernel on the same operands (q kept in fp32 like the shared kernel: fold off is the closest twin)
+    frag = prepare_b(bd.clone(), G)
+    inv = rope_inv_freq(xd.device)
+    ref_k = torch.empty(H, 1, L, dtype=torch.float16, device="cuda")
+    _lib.check(_lib.lib.palu_abx_rope_f16(ad.data_ptr(), ad.stride(0), ad.stride(2), frag.data_ptr(), xd.data_ptr(),
+                                          xd.stride(0), xd.stride(1), ref_k.data_ptr(), ref_k.stride(0), H, G, L, R, 128,
+                                          inv.data_ptr(), 0, torch.cuda.current_stream().cuda_stream), "abx")
+    scale = ref_k.float().abs().max().item()
+    assert (got.float() - ref_k.float()).abs().max().item() <= 1e-3 * scale
+    if L <= 4096:
+        o = oracle.abx_scores(a, b, x)
+        exact = oracle.abx_scores_f64(a, b, x)
+        sc = exact.abs().max().item()
+        assert (got.cpu().double() - o.double()).abs().max().item() <= 1e-3 * sc
+        e_mine = (got.cpu().double() - exact).abs().max().item() / sc
+        e_ref = (o.double() - exact).abs().max().item() / sc
+        assert e_mine <= max(1.5 * e_ref, 2.0 ** -10), (e_mine, e_ref)
+    # a B that differs in one head is not "shared"
+    b2 = bd.clone()
+    b2[1, 0, 0] += 1
+    assert shared_b(b2, G) is None
+
+
 def test_abx_full_size_c2_properties():
     """BASELINE config 2 shape (H=32, R=128, L=65536): size-independent properties.
     (1) linearity in a; (2) tile independence: scores of rows [s, e) computed on the slice with

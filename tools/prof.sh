@@ -23,3 +23,5 @@ done
 cd $ROOT
 python tools/prof_summary.py $OUT "$PAT" > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
+# the rocpd databases are large (gpurun_out is capped at 64 MiB): keep the summary only unless PROF_KEEP_DB=1
+if [ "${PROF_KEEP_DB:-0}" != "1" ]; then find $OUT -name "*.db" -delete; fi
