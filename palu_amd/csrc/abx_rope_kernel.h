@@ -884,7 +884,13 @@ inline int abx_fill_params(AbxParams& p, const AbxPlan& pl, int H, int G, int L,
     p.exp_flags = e ? atoi(e) : 0;
   }
   const int ngb = G * pl.hb;
-  int nch = palu_num_cus() / ngb;   // one 8-wave workgroup per CU
+  static int cu_cap = -1;           // PALU_ABX_CUS: experiments that leave part of the GPU to another kernel
+  if (cu_cap < 0) {
+    const char* e = getenv("PALU_ABX_CUS");
+    cu_cap = e ? atoi(e) : 0;
+  }
+  const int cus = (cu_cap > 0 && cu_cap < palu_num_cus()) ? cu_cap : palu_num_cus();
+  int nch = cus / ngb;              // one 8-wave workgroup per CU
   if (nch < 1) nch = 1;
   if (nch > p.nt_total) nch = p.nt_total;
   p.nch = nch;

@@ -1,0 +1,134 @@
+"""Whole-model decode with latent caches: the bridge between `LlamaPaluAttention` (which speaks the transformers-4.37.2
+cache protocol the reference pins: `get_usable_length` / `update`, kernel/palu_attention.py:147-263) and the transformers
+release installed here (5.x: `past_key_values=Cache`, `position_embeddings`, mask built by `create_causal_mask`).
+
+SURVEY.md 8(f) N2: in the reference the L4 models (`palu/model/svd_llama/modeling_palu_llama.py:7-35`) reconstruct full
+K/V and never reach the kernel path; this module is what lets a whole `LlamaForCausalLM` decode through the HIP step:
+
+    model = convert_llama_to_palu(model, rank_k=1024, rank_v=3072, group_size=4)      # per layer: from_attention + adapter
+    cache = PaluCacheHF(bits=16)                                                      # or bits=4 / 3: packed latents
+    out = model(input_ids, past_key_values=cache, use_cache=True)                     # prompt pass fills the latent caches
+    out = model(next_token, past_key_values=cache, use_cache=True)                    # one HIP decode step per layer
+
+`PaluCacheHF` is a `transformers.Cache` (so `get_seq_length` / `get_mask_sizes` serve HF's mask and position logic) that
+carries one `LatentCache` or `QuantLatentCache` for all layers; K/V never exist in reconstructed form.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from .kernel.palu_attention import LatentCache, LlamaPaluAttention, QuantLatentCache
+
+try:                                   # transformers is an optional dependency of this bridge only
+    from transformers.cache_utils import Cache as _HFCache
+except Exception:                      # noqa: BLE001
+    _HFCache = object
+
+
+class PaluCacheHF(_HFCache):
+    """`transformers.Cache` facade over the latent caches of every layer.  The attention modules never call `update`
+    with reconstructed K/V (there are none): they append latent rows through `self.latent`."""
+
+    def __init__(self, bits: int = 16, capacity: int = 0, headroom: int = 256):
+        if _HFCache is not object:
+            try:
+                super().__init__(layers=[])
+            except TypeError:          # older Cache.__init__ without arguments
+                super().__init__()
+        self.latent = LatentCache(capacity, headroom) if bits >= 16 else QuantLatentCache(bits, capacity, headroom)
+        self.bits = bits
+
+    # -- what transformers' model code asks a cache ------------------------------------------------------------
+    def get_seq_length(self, layer_idx: int = 0) -> int:
+        return self.latent.get_seq_length(layer_idx)
+
+    def get_mask_sizes(self, query_length, layer_idx: int = 0):
+        q = int(query_length.shape[0]) if isinstance(query_length, torch.Tensor) else int(query_length)
+        return self.get_seq_length(layer_idx) + q, 0
+
+    def get_max_cache_shape(self, layer_idx: int = 0) -> int:
+        return -1
+
+    def get_max_length(self):
+        return None
+
+    @property
+    def is_compileable(self) -> bool:
+        return False
+
+    def update(self, key_states, value_states, layer_idx, cache_kwargs=None):
+        raise RuntimeError("PaluCacheHF holds LATENT rows: it is updated by LlamaPaluAttention, not with reconstructed K/V")
+
+    def reset(self):
+        self.latent = LatentCache() if self.bits >= 16 else QuantLatentCache(self.bits)
+
+    def __len__(self):
+        return len(getattr(self.latent, "_state", {})) if hasattr(self.latent, "_state") else 0
+
+
+class PaluAttentionHF(nn.Module):
+    """`LlamaPaluAttention` behind the forward signature transformers 5.x decoder layers call
+    (`hidden_states, position_embeddings, attention_mask, past_key_values, position_ids, ...`) -> (output, weights)."""
+
+    def __init__(self, inner: LlamaPaluAttention):
+        super().__init__()
+        self.inner = inner
+        self.layer_idx = inner.layer_idx
+        self.config = inner.config
+
+    def forward(self, hidden_states: torch.Tensor, position_embeddings=None, attention_mask: Optional[torch.Tensor] = None,
+                past_key_values=None, position_ids: Optional[torch.LongTensor] = None, **kwargs):
+        cache = past_key_values.latent if isinstance(past_key_values, PaluCacheHF) else past_key_values
+        q_len = hidden_states.shape[1]
+        if q_len == 1:
+            # one token attends to the whole cache: a mask of zeros carries no information; dropping it keeps the step on
+            # the un-masked kernels (an additive mask that really masks something is passed through)
+            if attention_mask is not None and not bool((attention_mask != 0).any()):
+                attention_mask = None
+        elif attention_mask is not None and attention_mask.dtype == torch.bool:
+            attention_mask = torch.zeros(attention_mask.shape, dtype=hidden_states.dtype, device=hidden_states.device
+                                         ).masked_fill_(~attention_mask, torch.finfo(hidden_states.dtype).min)
+        out, weights, _ = self.inner(hidden_states, attention_mask=attention_mask, position_ids=position_ids,
+                                     past_key_value=cache, output_attentions=bool(kwargs.get("output_attentions", False)),
+                                     is_causal=True if q_len > 1 else None)
+        return out, weights
+
+
+def palu_config_from(config, rank_k: int, rank_v: int, group_size: int):
+    """The config fields LlamaPaluAttention reads (kernel/palu_attention.py:132-145) on top of the model's own config."""
+    import copy
+    c = copy.copy(config)
+    heads = config.num_attention_heads
+    if getattr(config, "num_key_value_heads", heads) != heads:
+        raise ValueError("the kernel-path module is MHA-only (kernel/palu_attention.py:143,201)")
+    if heads % group_size:
+        raise ValueError("num_attention_heads must be divisible by group_size")
+    c.group_size = group_size
+    c.num_groups = heads // group_size
+    c.total_rank_k, c.total_rank_v = rank_k, rank_v
+    if not hasattr(c, "attention_bias"):
+        c.attention_bias = False
+    return c
+
+
+@torch.no_grad()
+def convert_llama_to_palu(model, rank_k: int, rank_v: int, group_size: int = 4, hadamard: bool = False):
+    """Replace every `self_attn` of a `LlamaForCausalLM` / `LlamaModel` by the low-rank module
+    (`LlamaPaluAttention.from_attention`: group-wise SVD of k/v projections, U_v folded into o_proj) behind the
+    transformers-5 adapter.  Returns the same model object."""
+    base = getattr(model, "model", model)
+    cfg = palu_config_from(base.config, rank_k, rank_v, group_size)
+    for layer in base.layers:
+        att = layer.self_attn
+        if isinstance(att, PaluAttentionHF):
+            continue
+        inner = LlamaPaluAttention.from_attention(att, cfg)
+        inner.layer_idx = getattr(att, "layer_idx", inner.layer_idx)
+        inner = inner.to(device=att.q_proj.weight.device, dtype=att.q_proj.weight.dtype)
+        if hadamard:
+            inner.fuse_hadamard()
+        layer.self_attn = PaluAttentionHF(inner)
+    return model

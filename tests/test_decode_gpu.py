@@ -395,3 +395,46 @@ def test_split_l_decoders_merge_to_full_step():
     merged = hp.merge_partials(ctx, st[..., 0], st[..., 1]).half()
     out = torch.nn.functional.linear(merged.reshape(1, -1).cpu(), full["wo"]).reshape(-1)
     torch.testing.assert_close(out, ref, rtol=2e-3, atol=1e-3)
+
+
+def test_whole_llama_model_decodes_through_latent_caches():
+    """a whole transformers-5 LlamaForCausalLM with every attention replaced by the low-rank module
+    (palu_amd.hf.convert_llama_to_palu) and ONE PaluCacheHF carrying the latent caches of all layers.  With full ranks
+    the decomposition is exact up to fp16, so prompt logits and three decode steps must agree with the vanilla model
+    (the reference's own check, test_palu_attention.py:158-195, lifted to the model level); then the same with a packed
+    4-bit latent cache at reduced ranks runs end to end."""
+    transformers = pytest.importorskip("transformers")
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from palu_amd.hf import PaluCacheHF, convert_llama_to_palu, PaluAttentionHF
+    torch.manual_seed(0)
+    cfg = LlamaConfig(vocab_size=128, hidden_size=512, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=4, head_dim=128, max_position_embeddings=512, rope_theta=10000.0,
+                      attention_bias=False, tie_word_embeddings=False)
+    cfg._attn_implementation = "eager"
+    ref = LlamaForCausalLM(cfg).to(DEV, torch.float16).eval()
+    import copy
+    palu = convert_llama_to_palu(copy.deepcopy(ref), rank_k=512, rank_v=512, group_size=2)      # full rank: gs * D = 256 per group
+    assert all(isinstance(l.self_attn, PaluAttentionHF) for l in palu.model.layers)
+    ids = torch.randint(0, 128, (1, 37), device=DEV)
+    with torch.no_grad():
+        r = ref(ids, use_cache=True)
+        cache = PaluCacheHF(bits=16)
+        p = palu(ids, past_key_values=cache, use_cache=True)
+    torch.testing.assert_close(p.logits.float(), r.logits.float(), rtol=3e-2, atol=3e-2)
+    assert cache.get_seq_length() == 37
+    rc = r.past_key_values
+    tok = r.logits[:, -1:].argmax(-1)
+    for step in range(3):
+        with torch.no_grad():
+            r = ref(tok, past_key_values=rc, use_cache=True)
+            p = palu(tok, past_key_values=cache, use_cache=True)
+        torch.testing.assert_close(p.logits.float(), r.logits.float(), rtol=3e-2, atol=3e-2)
+        assert cache.get_seq_length() == 38 + step
+        tok = r.logits[:, -1:].argmax(-1)
+    # packed 4-bit latents at reduced rank: runs through prompt + decode (accuracy is the compression's, not checked here)
+    small = convert_llama_to_palu(copy.deepcopy(ref), rank_k=128, rank_v=256, group_size=2)
+    qc = PaluCacheHF(bits=4)
+    with torch.no_grad():
+        o = small(ids, past_key_values=qc, use_cache=True)
+        o2 = small(tok, past_key_values=qc, use_cache=True)
+    assert qc.get_seq_length() == 38 and torch.isfinite(o2.logits).all() and o.logits.shape == (1, 37, 128)
