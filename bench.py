@@ -247,7 +247,7 @@ def bench_c5_slice(steps, dev):
     return {"workload": "config-5 per-GPU slice: G=1 H=4 rank_k=1024/8 rank_v=3072/8 prompt_len=262144 fp16 (qkv + attention "
                         "core of one rank, before the all-gather)",
             "attend_us": round(us, 2), "algorithmic_bytes": byt, "hbm_frac": round(byt / us * 1e-3 / HBM_PEAK_GBPS, 4),
-            "fused_attention_core": bool(_lib.lib.palu_decode_attn_preferred(4, 1, Rk, Rv, D))}
+            "fused_attention_core": bool(_lib.lib.palu_decode_attn_preferred(4, 1, L, Rk, Rv, D))}
 
 
 def main():

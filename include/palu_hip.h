@@ -113,13 +113,13 @@ int palu_softmax_pv_f16(const void* scores, int64_t ss_h, const void* mask,
  *   aligned rows), ctx [H, Rv] fp16, key row l at position pos0 + l, no mask, no attention weights.
  * palu_decode_attn_supported() != 0 for the shapes the kernel covers (D = 128, gs in {3,4}, Rk in {64,128},
  * Rv in {128,192,256,384}); palu_decode_attn_preferred() != 0 where palu_decode_step_f16 / palu_decode_attend_f16
- * pick it over the two-kernel path (measured: one latent group per GPU, i.e. the head-group shard of an 8-GPU node;
- * PALU_FUSED_ATTN=1 / 0 in the environment forces it on for every covered shape / off).  workspace:
+ * pick it over the two-kernel path (measured: G * L <= ~300k rows, i.e. the head-group shards of a multi-GPU run and
+ * short caches; PALU_FUSED_ATTN=1 / 0 in the environment forces it on for every covered shape / off).  workspace:
  * palu_pv_workspace_bytes(H, G, L, Rv) bytes; the per-head (max, sum) statistics are left at
  * palu_decode_attn_stats_offset() like palu_softmax_pv_f16 leaves them at palu_pv_stats_offset().
  */
 int palu_decode_attn_supported(int H, int G, int Rk, int Rv, int D);
-int palu_decode_attn_preferred(int H, int G, int Rk, int Rv, int D);
+int palu_decode_attn_preferred(int H, int G, int L, int Rk, int Rv, int D);
 int palu_decode_attn_nsplit(int G, int L);
 size_t palu_decode_attn_stats_offset(int H, int G, int L, int Rv);
 int palu_decode_attn_f16(const void* q, int64_t sq_h, int64_t sq_d, const void* bfrag,

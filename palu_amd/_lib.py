@@ -47,7 +47,7 @@ SIGNATURES = {
     "palu_pv_stats_offset": (sz, [i32, i32, i32, i32]),
     "palu_softmax_pv_f16": (i32, [vp, i64, vp, vp, i64, i64, vp, vp, i64, vp, i32, i32, i32, i32, f32, vp]),
     "palu_decode_attn_supported": (i32, [i32, i32, i32, i32, i32]),
-    "palu_decode_attn_preferred": (i32, [i32, i32, i32, i32, i32]),
+    "palu_decode_attn_preferred": (i32, [i32, i32, i32, i32, i32, i32]),
     "palu_decode_attn_nsplit": (i32, [i32, i32]),
     "palu_decode_attn_stats_offset": (sz, [i32, i32, i32, i32]),
     "palu_decode_attn_f16": (i32, [vp, i64, i64, vp, vp, i64, i64, vp, i64, i64, vp, vp, i32, i32, i32, i32, i32, i32,

@@ -56,9 +56,12 @@ int fused_prio_mode() {   // 0 none, 2 score-block alternation (abx_rope_kernel.
 }
 
 // PALU_FUSED_ATTN: 0 = never, 1 = whenever the shape is covered, unset = auto.  Measured on MI355X (same box, interleaved,
-// tools/bench_fused_variants.py): the fused kernel wins when one latent group has the whole GPU (G = 1, the per-GPU slice
-// of the 8-GPU head-group sharding: 88 vs 98 us at L = 256k) and loses at G = 8, L = 64k (145-157 vs 141 us): there the
-// 160 KB of LDS cannot hold enough latent rows in flight next to the score kernel's tiles.
+// tools/bench_fused_variants.py, profiles/r02_fused_vs_two_kernel_policy_sweep.txt), fused vs two kernels in us:
+//   G=1 L=16k 23.7/25.5   G=1 L=64k 37.4/42.4   G=2 L=64k 51.4/58.5   G=1 L=256k 88/98   G=4 L=64k 84.0/86.1 (tie)
+//   G=2 L=256k 154/146.5  G=8 L=64k 144.5/137.4
+// i.e. it wins while a CU streams few rows (G*L <= ~262k: the head-group shards of a multi-GPU run) and loses once the
+// steady state dominates, where the 160 KB of LDS cannot hold enough latent rows in flight next to the score kernel's
+// tiles.
 int fused_mode() {
   static int m = -2;
   if (m == -2) {
@@ -84,10 +87,10 @@ extern "C" int palu_decode_attn_supported(int H, int G, int Rk, int Rv, int D) {
   return (gs == 3 || gs == 4) && (Rk == 64 || Rk == 128) && fused_col_plan(Rv, &nts, &ntl);
 }
 
-extern "C" int palu_decode_attn_preferred(int H, int G, int Rk, int Rv, int D) {
-  if (!palu_decode_attn_supported(H, G, Rk, Rv, D)) return 0;
+extern "C" int palu_decode_attn_preferred(int H, int G, int L, int Rk, int Rv, int D) {
+  if (!palu_decode_attn_supported(H, G, Rk, Rv, D) || L <= 0) return 0;
   const int m = fused_mode();
-  return m >= 0 ? m : (G == 1);
+  return m >= 0 ? m : ((int64_t)G * L <= 300000);
 }
 
 extern "C" int palu_decode_attn_nsplit(int G, int L) {

@@ -2,7 +2,7 @@
 // stream (hipGraph-capturable): the drop-in for the decode branch of LlamaPaluAttention.forward
 // (kernel/palu_attention.py:147-263, branch :207-219).
 //   qkv GEMV + q-RoPE + cache append -> abx scores -> softmax.PV + split merge -> o_proj            (5 launches)
-// or, where palu_decode_attn_preferred() says the single-kernel attention core is faster (one latent group per GPU,
+// or, where palu_decode_attn_preferred() says the single-kernel attention core is faster (few rows per CU: G * L <= 300k,
 // no mask, no attention weights):  qkv -> fused scores/softmax/P.V (decode_fused.hip) + split merge -> o_proj.
 #include "palu_common.h"
 
@@ -49,7 +49,7 @@ extern "C" int palu_decode_step_f16(const void* hidden, const void* wq, int64_t 
   int rc = palu_decode_qkv_f16(wq, ldq, vtk, ldk, vtv, ldv, hidden, q, k_cache, sk_g, sk_l, v_cache, sv_g, sv_l,
                                inv_freq, H, D, hidden_size, G, Rk, Rv, pos, cache_len, stream);
   if (rc) return rc;
-  if (!mask && !probs && palu_decode_attn_preferred(H, G, Rk, Rv, D)) {
+  if (!mask && !probs && palu_decode_attn_preferred(H, G, L, Rk, Rv, D)) {
     rc = palu_decode_attn_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, v_cache, sv_g, sv_l, ctx, pvws, H, G, L, Rk, Rv, D,
                               inv_freq, 0, sqrtf((float)D), stream);
   } else {
@@ -81,7 +81,7 @@ extern "C" int palu_decode_attend_f16(const void* hidden, const void* wq, int64_
   int rc = palu_decode_qkv_f16(wq, ldq, vtk, ldk, vtv, ldv, hidden, q, k_cache, sk_g, sk_l, v_cache, sv_g, sv_l,
                                inv_freq, H, D, hidden_size, G, Rk, Rv, pos, cache_len, stream);
   if (rc) return rc;
-  if (!mask && palu_decode_attn_preferred(H, G, Rk, Rv, D))
+  if (!mask && palu_decode_attn_preferred(H, G, L, Rk, Rv, D))
     return palu_decode_attn_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, v_cache, sv_g, sv_l, ctx, pvws, H, G, L, Rk, Rv, D,
                                 inv_freq, 0, sqrtf((float)D), stream);
   rc = palu_abx_rope_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, scores, ss_h, H, G, L, Rk, D, inv_freq, 0, stream);

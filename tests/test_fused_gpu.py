@@ -185,7 +185,7 @@ dec = hp.HeadParallelDecoder(plan, wd, kc, vc, HID)
 out = dec.step(tok.cuda(), L, L)
 torch.cuda.synchronize()
 err = (out.cpu().float() - ref.float()).abs().max().item()
-print("preferred", _lib.lib.palu_decode_attn_preferred(H, G, Rk, Rv, D), "err", err)
+print("preferred", _lib.lib.palu_decode_attn_preferred(H, G, L + 1, Rk, Rv, D), "err", err)
 torch.testing.assert_close(out.cpu(), ref, rtol=1e-3, atol=1e-3)
 ''' % root
     env = dict(os.environ, PALU_FUSED_ATTN=str(fused))
