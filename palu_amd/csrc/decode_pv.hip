@@ -238,6 +238,7 @@ struct PvQParams {
   int G, gs, L, Rv, nsplit, rps;
   float inv_scale;
   int exp_flags;   // PALU_PVQ_EXP (timing experiments of the matrix-core kernel; results are wrong when set)
+  int qr_nsl, qr_ncw, qr_s;   // register-direct kernel: column slices, chunks per slice, row sets per unit
 };
 
 // one thread owns a 16-code column chunk (8 bytes at 4 bit, 6 bytes at 3 bit) and walks the rows in PAIRS:
@@ -675,6 +676,375 @@ __global__ __launch_bounds__(64 * NCS * NRH) void pv_partial_qm_kernel(PvQParams
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Quantised V latents, register-direct: packed rows go HBM -> VGPRs -> MFMA operands with no LDS, no barrier and no
+// transpose read in between (pv_partial_qm_kernel above pays a ds_write + barrier + ds_read_tr round trip per 32 rows
+// and is latency-bound at 3 waves per SIMD).  The MFMA contracts over ROWS, and which row sits in which k-slot is
+// ours to choose as long as both operands agree:
+//   v_mfma_f32_16x16x32_f16: D[m, n] += sum_k A[m, k] B[k, n];   lane = (m or n = lane % 16, q = lane / 16) holds
+//   the 8 k-slots e = 0..7 of k-group q.  k-slot (q, e) <-> row 4e + q of a 32-row set, so
+//   A: lane (m, q) loads ITS OWN 8 rows x one 32-code chunk (8 dwordx3 / dwordx4 buffer loads; instruction e covers
+//      rows 4e..4e+3 of the set: whole consecutive rows, coalesced) and turns them into 32 operands (one per code
+//      column j of the chunk) with byte permutes that pair rows (2p, 2p+1) plus one v_and_or per code pair: the code
+//      stays where it is inside the 16-bit half and the fp16 exponent is chosen for that bit position --
+//      ((w & (7 << s)) | fp16(2^(10-s)))  ==  2^(10-s) + code  for s <= 7 -- so most codes need no shift
+//      (0.75-0.8 VALU per code instead of 1.5 + the LDS traffic);
+//   B: lane (n, q) reads the 8 weights w = fp16(e^(x-m) * scale_row) of its rows with one ds_read_b128 (the weight
+//      rows are stored in k-slot order by phase A).
+// m = (row set s, chunk c), n = (row set s, head h): with Rv/32 = 12 chunks one set of 32 rows fills 12 of the 16 m
+// lanes, with 6 or 8 chunks two sets, with 4 chunks four; D[(s,c), (s',h)] is meaningful for s == s' and ignored
+// otherwise.  32 accumulators (one per code column of the chunk) live in registers for the whole range, the per-column
+// offsets 2^(10-s) and the zero points leave at the end:  out = acc - sum_l w_l z_l - off_j sum_l w_l.
+// Wider rows (Rv > 512) are cut into column slices handled by different waves.  Waves walk their units independently
+// (no barrier inside the loop); NSET units are in flight per wave in named register sets.
+template <int BITS>
+struct QrDecode {
+  // offsets of the decoded columns (fp16 value = off + code), in MFMA order j % 8 (3 bit) or j % 4 (4 bit)
+  static __device__ __forceinline__ float off(int j) {
+    if (BITS == 3) {
+      const int k = j & 7;
+      return (k == 0 || k == 3 || k == 6) ? 1024.f : (k == 1 || k == 4 || k == 7) ? 128.f : (k == 2) ? 16.f : 8.f;
+    }
+    return (j & 1) ? 64.f : 1024.f;
+  }
+};
+
+// (a & mask) | magic in ONE instruction: gfx9 VOP3 takes no literals and one scalar operand, and with literal operands
+// hipcc selects v_and_b32 + v_or_b32 (twice the VALU work).  The masks are therefore handed to the compiler as opaque
+// SGPR values and the magics as opaque VGPR values: the plain C expression then selects v_and_or_b32 v, v, s, v.
+// (Writing the instruction as inline asm is NOT an option: the hazard recogniser does not see an asm as a VALU write and
+//  leaves out the wait states an MFMA reading the result needs -- measured: sporadic NaNs in one code column.)
+static __device__ __forceinline__ float wave_sum_dpp(float v) {
+#define PALU_DPP_ADD(CTRL, ROWMASK)                                                                                    \
+  v += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, ROWMASK, 0xF, true))
+  PALU_DPP_ADD(0xB1, 0xF);    // quad_perm [1,0,3,2]
+  PALU_DPP_ADD(0x4E, 0xF);    // quad_perm [2,3,0,1]
+  PALU_DPP_ADD(0x141, 0xF);   // row_half_mirror
+  PALU_DPP_ADD(0x140, 0xF);   // row_mirror
+  PALU_DPP_ADD(0x142, 0xA);   // row_bcast:15 -> rows 1 and 3
+  PALU_DPP_ADD(0x143, 0xC);   // row_bcast:31 -> rows 2 and 3
+#undef PALU_DPP_ADD
+  return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
+}
+static __device__ __forceinline__ unsigned and_or(unsigned a, unsigned mask_sgpr, unsigned magic_vgpr) {
+  return (a & mask_sgpr) | magic_vgpr;
+}
+static __device__ __forceinline__ unsigned vgpr_const(unsigned c) {
+  unsigned d;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(d) : "s"(c));
+  return d;
+}
+static __device__ __forceinline__ unsigned sgpr_const(unsigned c) {
+  unsigned d;
+  asm volatile("s_mov_b32 %0, %1" : "=s"(d) : "i"(c));
+  return d;
+}
+
+template <int GS, int BITS>
+__global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
+  constexpr int NW = 8, NSET = 2, NJ = 32, MAXR = 5;     // MAXR * 64 = 320 rows per wave at most
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const unsigned smem_lds = (unsigned)reinterpret_cast<uintptr_t>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = blockIdx.x % p.G;
+  const int split = blockIdx.x / p.G;
+  const int l0 = split * p.rps;
+  const int n = max(0, min(p.L - l0, p.rps));
+  long long tstamp[5];
+  tstamp[0] = wall_clock64();
+
+  // ---- geometry (uniform): column slices of <= 16 chunks, S row sets per unit, every wave owns rpw consecutive rows
+  const int nch = p.Rv >> 5;
+  const int nsl = p.qr_nsl, ncw = p.qr_ncw, S = p.qr_s;          // slices, chunks per slice, row sets (host plan)
+  const int RU = 32 * S;
+  const int sl = wv % nsl, wph = wv / nsl, nws = NW / nsl;       // this wave: slice, row phase; waves per slice
+  const int rpw = p.rps / nws;                                   // rows per wave: a multiple of RU, <= 320
+  const int r0 = wph * rpw;
+  const int nw = max(0, min(n - r0, rpw));                       // valid rows of this wave
+  const int nwlast = max(nw - 1, 0);
+  const int nunit = (nw + RU - 1) / RU;
+  const int m = lane & 15, q = lane >> 4;
+  float* ml = p.ml + ((size_t)(g * p.nsplit + split) * GS) * 2;
+  float* part = p.part + (size_t)(g * p.nsplit + split) * GS * p.Rv;
+  // LDS: per-wave weight rows [4][WS] fp16 | per-wave red [S * ncw][33][4 heads] fp32 (the accumulators on their way
+  // out) | stat [NW][GS][4] fp32 (max, sum, zero-point term, weight sum)
+  const int WS = 320 + 8;
+  const unsigned wl_wave = smem_lds + (unsigned)(wv * 4 * WS * sizeof(h16));
+  h16* wl = reinterpret_cast<h16*>(smem_raw) + (size_t)wv * 4 * WS;
+  float* red_all = reinterpret_cast<float*>(smem_raw + (size_t)NW * 4 * WS * sizeof(h16));
+  float* red = red_all + (size_t)wv * (16 * 33 * 4);
+  float* stat = red_all + (size_t)NW * (16 * 33 * 4);
+  // V operand lanes: n = (row set sA, chunk cA)
+  const int sA = m / ncw, cA = m - sA * ncw, chunk = sl * ncw + cA;
+  const bool actA = sA < S && chunk < nch;
+  const unsigned long long cbase = reinterpret_cast<unsigned long long>(p.codes + (int64_t)g * p.sc_g);
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<void*>(cbase), 0, (int)((int64_t)(p.L - 1) * p.sc_l + (int64_t)p.Rv * BITS / 8), 0x00020000);
+  // per-lane byte offset of (row l0 + r0 + 32 sA + q, chunk); inactive lanes sit past the descriptor (zeros, no traffic)
+  const unsigned sc_l = (unsigned)p.sc_l;
+  const unsigned voff0 = actA ? (unsigned)(l0 + r0 + 32 * sA + q) * sc_l + (unsigned)(chunk * 4 * BITS) : 0x80000000u;
+
+  unsigned raw[NSET][8][BITS];
+  auto load_unit = [&](unsigned (&r)[8][BITS], int u) {
+    // (units past this wave's range belong to the next split: sent past the descriptor, they cost no traffic)
+    const unsigned vo = u < nunit ? voff0 + (unsigned)(u * RU) * sc_l : 0x80000000u;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (BITS == 3) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b96(rs, vo + (unsigned)(4 * e) * sc_l, 0, 0);
+        r[e][0] = v[0]; r[e][1] = v[1]; r[e][2] = v[2];
+      } else {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + (unsigned)(4 * e) * sc_l, 0, 0);
+        r[e][0] = v[0]; r[e][1] = v[1]; r[e][2 % BITS] = v[2]; r[e][3 % BITS] = v[3];
+      }
+    }
+  };
+
+  // ---- softmax statistics and weights of THIS WAVE's rows (no workgroup barrier: a wave is its own split until the
+  //      epilogue merges the waves with exp(m_wave - m_wg)).  Same arithmetic as the kernels above.
+  float mloc[GS], sloc[GS], cz[GS], cw[GS];
+#pragma unroll
+  for (int h = 0; h < GS; ++h) mloc[h] = sloc[h] = cz[h] = cw[h] = 0.f;
+  if ((p.exp_flags & 2) || nw == 0) {                 // (spare waves of a group's last range touch no memory)
+#pragma unroll
+    for (int s = 0; s < NSET; ++s) load_unit(raw[s], s);
+  } else {
+    h16 sc[MAXR][GS], mk[MAXR];
+    unsigned mt[MAXR];
+    const h16* mb = p.meta + (int64_t)g * p.sm_g + (int64_t)(l0 + r0) * p.sm_l;
+    const h16* mkp = p.mask ? p.mask : p.scores + (int64_t)g * GS * p.ss_h;   // branch-free: a dummy row when there is no mask
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k) {
+      const int ic = min(lane + 64 * k, nwlast);
+#pragma unroll
+      for (int h = 0; h < GS; ++h) sc[k][h] = p.scores[(int64_t)(g * GS + h) * p.ss_h + l0 + r0 + ic];
+      mk[k] = mkp[l0 + r0 + ic];
+      mt[k] = *reinterpret_cast<const unsigned*>(mb + (int64_t)ic * p.sm_l);
+    }
+    // the first units are requested BEHIND the (small) score / meta loads: loads return in order, so the statistics do
+    // not wait for the V burst, and the burst is in flight while they are computed
+#pragma unroll
+    for (int s = 0; s < NSET; ++s) load_unit(raw[s], s);
+    float xl[MAXR][GS];
+#pragma unroll
+    for (int h = 0; h < GS; ++h) mloc[h] = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k) {
+      const bool ok = lane + 64 * k < nw;
+#pragma unroll
+      for (int h = 0; h < GS; ++h) {
+        // fp16 tensor / python float -> fp32 divide, rounded to fp16 (torch semantics); then + mask in fp16
+        h16 x16 = (h16)((float)sc[k][h] / p.inv_scale);
+        if (p.mask) x16 = (h16)((float)x16 + (float)mk[k]);
+        xl[k][h] = ok ? (float)x16 : -INFINITY;
+        mloc[h] = fmaxf(mloc[h], xl[k][h]);
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < GS; ++h) mloc[h] = wave_max(mloc[h]);
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k) {
+      const int i = lane + 64 * k;
+      const h16x2 m2 = __builtin_bit_cast(h16x2, mt[k]);
+      const int slot = (i & ~31) + ((i & 3) << 3) + ((i & 31) >> 2);          // row 32b + 4e + q -> k-slot order 32b + 8q + e
+#pragma unroll
+      for (int h = 0; h < GS; ++h) {
+        h16 wq = (h16)0.f;
+        if (i < nw) {
+          const float e = (mloc[h] == -INFINITY) ? 0.f : __expf(xl[k][h] - mloc[h]);
+          sloc[h] += e;
+          wq = (h16)(e * (float)m2[0]);
+          cw[h] += (float)wq;
+          cz[h] = fmaf((float)wq, (float)m2[1], cz[h]);
+        }
+        wl[h * WS + slot] = wq;
+      }
+    }
+  }
+
+  tstamp[1] = wall_clock64();
+  // ---- phase B.  P is the A operand (m = 4 * row set + head), the decoded codes the B operand (n = V lane):
+  //      D lane (n, q) holds rows m = 4q .. 4q+3 = the 4 heads of row set q -> meaningful where q == sA(n)
+  f32x4 acc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int sP = m >> 2, hP = m & 3;
+  const bool actP = sP < S && hP < GS;
+  const unsigned wl_lane = wl_wave + (unsigned)(((actP ? hP : 0) * WS + (actP ? sP : 0) * 32 + q * 8) * sizeof(h16));
+  typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+  const unsigned M1024 = vgpr_const(0x64006400u), M128 = vgpr_const(0x58005800u), M16 = vgpr_const(0x4C004C00u),
+                 M8 = vgpr_const(0x48004800u), M64 = vgpr_const(0x54005400u);
+  const unsigned K07 = sgpr_const(0x00070007u), K38 = sgpr_const(0x00380038u), K1C0 = sgpr_const(0x01C001C0u),
+                 K380 = sgpr_const(0x03800380u), K0F = sgpr_const(0x000F000Fu), KF0 = sgpr_const(0x00F000F0u);
+  auto consume = [&](const unsigned (&r)[8][BITS], int u) {
+    const u32x4 pw = *(const lds_u32x4*)(uintptr_t)(wl_lane + (unsigned)(u * RU * sizeof(h16)));
+    const h16x8 pop = __builtin_bit_cast(h16x8, pw);
+    if (BITS == 3) {
+      // code column 8b + k of the chunk sits at bit 3k of the 3 bytes 3b .. 3b+2 of the row: bring those bytes to the
+      // front of a dword per row, then W1 = bytes (0,1) and W2 = bytes (1,2) of rows (2p, 2p+1) side by side
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        unsigned o[4][8];
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+          unsigned x0, x1;
+          if (b == 0) { x0 = r[2 * pr][0]; x1 = r[2 * pr + 1][0]; }
+          else if (b == 1) {
+            x0 = __builtin_amdgcn_alignbit(r[2 * pr][1], r[2 * pr][0], 24);
+            x1 = __builtin_amdgcn_alignbit(r[2 * pr + 1][1], r[2 * pr + 1][0], 24);
+          } else if (b == 2) {
+            x0 = __builtin_amdgcn_alignbit(r[2 * pr][2], r[2 * pr][1], 16);
+            x1 = __builtin_amdgcn_alignbit(r[2 * pr + 1][2], r[2 * pr + 1][1], 16);
+          } else { x0 = r[2 * pr][2]; x1 = r[2 * pr + 1][2]; }                 // bytes 9..11 = bytes 1..3 of dword 2
+          const unsigned w1 = __builtin_amdgcn_perm(x1, x0, b == 3 ? 0x06050201u : 0x05040100u);
+          const unsigned w2 = __builtin_amdgcn_perm(x1, x0, b == 3 ? 0x07060302u : 0x06050201u);
+          const unsigned w1s = w1 >> 9, w2s = w2 >> 10;
+          o[pr][0] = and_or(w1, K07, M1024);
+          o[pr][1] = and_or(w1, K38, M128);
+          o[pr][2] = and_or(w1, K1C0, M16);
+          o[pr][3] = and_or(w1s, K07, M1024);
+          o[pr][4] = and_or(w1s, K38, M128);
+          o[pr][5] = and_or(w2, K380, M8);
+          o[pr][6] = and_or(w2s, K07, M1024);
+          o[pr][7] = and_or(w2s, K38, M128);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const h16x8 vop = __builtin_bit_cast(h16x8, u32x4{o[0][k], o[1][k], o[2][k], o[3][k]});
+          acc[8 * b + k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pop, vop, acc[8 * b + k], 0, 0, 0);
+        }
+      }
+    } else {
+      // code column 4b + k sits at bit 4k of bytes 2b, 2b+1 of the row
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        unsigned o[4][4];
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+          const unsigned w = __builtin_amdgcn_perm(r[2 * pr + 1][(b >> 1) % BITS], r[2 * pr][(b >> 1) % BITS],
+                                                   (b & 1) ? 0x07060302u : 0x05040100u);
+          const unsigned ws = w >> 8;
+          o[pr][0] = and_or(w, K0F, M1024);
+          o[pr][1] = and_or(w, KF0, M64);
+          o[pr][2] = and_or(ws, K0F, M1024);
+          o[pr][3] = and_or(ws, KF0, M64);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const h16x8 vop = __builtin_bit_cast(h16x8, u32x4{o[0][k], o[1][k], o[2][k], o[3][k]});
+          acc[4 * b + k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pop, vop, acc[4 * b + k], 0, 0, 0);
+        }
+      }
+    }
+  };
+  // NSET named register sets, each refilled right after it was consumed (NSET - 1 units stay in flight); the weight
+  // rows were written by this wave itself: LDS operations of one wave complete in order, no barrier
+  for (int u = 0; u < ((p.exp_flags & 1) ? 0 : nunit); u += NSET) {
+#pragma unroll
+    for (int s = 0; s < NSET; ++s) {
+      if (u + s < nunit) consume(raw[s], u + s);
+      load_unit(raw[s], u + s + NSET);
+    }
+  }
+  tstamp[2] = wall_clock64();
+  if (p.exp_flags & 4) {
+    float t = 0.f;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) t += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    if (tid < GS * p.Rv) part[tid] = t;
+    return;
+  }
+
+  // ---- merge of the waves: every wave parks its accumulators and statistics in its own LDS patch, ONE barrier (the only
+  //      one of the kernel: waves reach it at their own pace, and with one workgroup per CU a waiting wave costs nothing),
+  //      then all waves share the columns of the sum.  (A barrier-free "last arrival merges" variant was measured: a lone
+  //      wave issues ~1 instruction per 8 cycles and needed 6-8 us for what 8 waves do in well under 1.)
+#pragma unroll
+  for (int h = 0; h < GS; ++h) {
+    sloc[h] = wave_sum_dpp(sloc[h]);
+    cz[h] = wave_sum_dpp(cz[h]);
+    cw[h] = wave_sum_dpp(cw[h]);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int h = 0; h < GS; ++h)
+      *reinterpret_cast<f32x4*>(stat + (wv * GS + h) * 4) = nw > 0 ? f32x4{mloc[h], sloc[h], cz[h], cw[h]}
+                                                                     : f32x4{-INFINITY, 0.f, 0.f, 0.f};
+  }
+  // red [row set * ncw + chunk][33 (32 code columns + 1 pad: chunks on different banks)][4 heads]
+  if (actA && q == sA) {
+    f32x4* dst = reinterpret_cast<f32x4*>(red) + (size_t)(sA * ncw + cA) * 33;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) dst[j] = acc[j];
+  }
+  tstamp[3] = wall_clock64();
+  __syncthreads();
+  {
+    // factors exp(m_wave - m_range) and the scalar terms.  Straight-line code (selects, no branches): the LDS reads are
+    // independent and are waited for once.  Waves without rows parked (-inf, 0, 0, 0): factor 0, and what is read from
+    // their (zeroed) accumulators is 0 as well.
+    f32x4 st[NW][GS];
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+#pragma unroll
+      for (int h = 0; h < GS; ++h)
+        st[w][h] = *reinterpret_cast<const f32x4*>(stat + ((min(w, nws - 1) * nsl + sl) * GS + h) * 4);
+    float mr[GS], fz[GS], fw[GS], fs[GS], f[NW][GS];
+#pragma unroll
+    for (int h = 0; h < GS; ++h) {
+      mr[h] = -INFINITY;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) mr[h] = fmaxf(mr[h], w < nws ? st[w][h][0] : -INFINITY);
+      fz[h] = fw[h] = fs[h] = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const bool live = w < nws && st[w][h][0] != -INFINITY;
+        f[w][h] = live ? __expf(st[w][h][0] - mr[h]) : 0.f;
+        fs[h] = fmaf(f[w][h], st[w][h][1], fs[h]);
+        fz[h] = fmaf(f[w][h], st[w][h][2], fz[h]);
+        fw[h] = fmaf(f[w][h], st[w][h][3], fw[h]);
+      }
+    }
+    const int ncol = min(ncw, nch - sl * ncw) * 32;                  // columns of this slice, shared by its nws waves
+    for (int c = wph * 64 + lane; c < ncol; c += 64 * nws) {
+      const int c2 = c >> 5, jq = c & 31;
+      const float off = QrDecode<BITS>::off(jq);
+      f32x4 a[NW];
+#pragma unroll
+      for (int w = 0; w < NW; ++w) a[w] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int s = 0; s < S; ++s) {                     // (uniform trip count; the NW reads of one pass are independent)
+        f32x4 t[NW];
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+          t[w] = reinterpret_cast<const f32x4*>(red_all + (size_t)(min(w, nws - 1) * nsl + sl) * (16 * 33 * 4))[(size_t)(s * ncw + c2) * 33 + jq];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) a[w] += t[w];
+      }
+#pragma unroll
+      for (int h = 0; h < GS; ++h) {
+        float o = -fz[h] - off * fw[h];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) o = fmaf(f[w][h], w < nws ? a[w][h] : 0.f, o);
+        part[(size_t)h * p.Rv + sl * ncw * 32 + c] = o;
+      }
+    }
+    if (tid == 0) {
+#pragma unroll
+      for (int h = 0; h < GS; ++h) {
+        ml[2 * h] = mr[h];
+        ml[2 * h + 1] = fs[h];
+      }
+    }
+  }
+  if ((p.exp_flags & 8) && lane == 0) {           // timeline dump behind the workspace proper (tools/time_pvq.py allocates it)
+    tstamp[4] = wall_clock64();
+    long long* dbg = reinterpret_cast<long long*>(p.ml + ((size_t)p.G * GS * p.nsplit + (size_t)p.G * GS) * 2) + ((size_t)blockIdx.x * NW + wv) * 5;
+#pragma unroll
+    for (int t = 0; t < 5; ++t) dbg[t] = tstamp[t];
+  }
+}
+
 struct CombineParams {
   const float* part;
   const float* ml;
@@ -685,7 +1055,7 @@ struct CombineParams {
 
 // grid (H, ceil(Rv/64)), 512 threads: the 8 waves share the splits of one head for 64 context columns
 // (8 independent loads in flight per lane: the merge is latency-, not bandwidth-bound), LDS sum at the end.
-constexpr int CB_WAVES = 8;
+constexpr int CB_WAVES = 16;
 __global__ __launch_bounds__(64 * CB_WAVES) void pv_combine_kernel(CombineParams p) {
   __shared__ float red[CB_WAVES][64];
   __shared__ float redt[CB_WAVES];
@@ -759,6 +1129,16 @@ int pv_wgs_per_cu() {
 
 // split target: ~PALU_PV_WGS_PER_CU (default 4) workgroups per CU in flight, whole multiples of the CU count
 // (every CU gets the same number of workgroups: no straggler round)
+int pv_qr_wgs() {
+  static int wgs = 0;
+  if (wgs == 0) {
+    const char* e = getenv("PALU_PVQ_WGS");
+    wgs = e ? atoi(e) : 1;
+    if (wgs < 1) wgs = 1;
+  }
+  return wgs;
+}
+
 long long pv_split_target(int G) {
   long long t = ((long long)pv_wgs_per_cu() * palu_num_cus() + G - 1) / G;
   return t < 1 ? 1 : t;
@@ -778,12 +1158,25 @@ int pv_rows_per_split(int G, int L) {
 // 8 and clamped), so a workspace sized from nsplit(Lcap) can be too small for a shorter fill level: with
 // rps = clamp(round8(ceil(L/T)), 128, 2048) the count is <= min(T, ceil(L/128)) while rps < 2048 and ceil(L/2048) after.
 // The fused decode kernel (decode_fused.hip) splits into min(CUs / G, ceil(L/64)) ranges: covered by min(T, ceil(L/64)).
-int pv_nsplit_bound(int G, int Lcap) {
+int pv_nsplit_bound(int G, int Lcap, int Rv) {
   const long long T = pv_split_target(G);
   long long a = ((long long)Lcap + 63) / 64;
   if (a > T) a = T;
   const long long b = ((long long)Lcap + 2047) / 2048;
-  return (int)(a > b ? a : b);
+  long long r = a > b ? a : b;
+  // the register-direct quantised kernel (pv_partial_qr_kernel): ranges of nws = 8 / (column slices) wave ranges, k rounds
+  // of Pr = CUs / G ranges for the smallest k that keeps a wave range <= 320 rows (whole units, >= 32 rows); k > 1 only
+  // when k - 1 did not fit, which keeps a wave range above (320 - 128) / 2 = 96 rows
+  int nsl = 1;
+  while (nsl * 16 < Rv / 32) nsl *= 2;
+  const long long nws = nsl >= 8 ? 1 : 8 / nsl;
+  const long long Pr = ((long long)pv_qr_wgs() * palu_num_cus() + G - 1) / G;
+  long long c = ((long long)Lcap + 32 * nws - 1) / (32 * nws);
+  if (c > Pr) {
+    c = ((long long)Lcap + 96 * nws - 1) / (96 * nws) + 1;
+    if (c < Pr) c = Pr;
+  }
+  return (int)(r > c ? r : c);
 }
 
 }  // namespace
@@ -811,7 +1204,7 @@ extern "C" size_t palu_pv_workspace_bytes(int H, int G, int L, int Rv) {
   if (L <= 0 || G <= 0) return 0;
   // part [H][ns][Rv] + ml [H][ns][2] + stats [H][2], fp32, for the largest split count any L' <= L can produce
   // (this kernel's and the fused decode kernel's, which never exceeds CUs / G <= the split target)
-  const int ns = pv_nsplit_bound(G, L);
+  const int ns = pv_nsplit_bound(G, L, Rv);
   return ((size_t)H * ns * (Rv + 2) + (size_t)H * 2) * sizeof(float);
 }
 
@@ -903,6 +1296,86 @@ extern "C" int palu_softmax_pv_q(const void* scores, int64_t ss_h, const void* m
   const bool qm = qm_enabled && gs == 4 && ncs > 0 &&
                   (bits == 3 || (qm_enabled == 2 && ((uintptr_t)codes & 15) == 0 && sc_g % 16 == 0 && sc_l % 16 == 0));
   int rps = pv_rows_per_split(G, L);
+  // register-direct kernel (pv_partial_qr_kernel): any gs in {1,2,4}, Rv a multiple of 32 up to 4096, offsets below 2^31
+  static int qr_enabled = -1;
+  if (qr_enabled < 0) {
+    const char* e = getenv("PALU_PVQ_DIRECT");
+    qr_enabled = e ? atoi(e) : 1;
+  }
+  const long long code_bytes = (long long)(L - 1) * sc_l + (long long)Rv * bits / 8;
+  bool qr = qr_enabled && code_bytes + 4096ll * sc_l < 0x7FFFFFFFll && (bits == 3 || sc_l % 4 == 0);
+  int nsl = 1, ncw = 0, S = 1, rps_qr = rps, ns_qr = 0;
+  if (qr) {
+    const int nch = Rv / 32;
+    while (nsl * 16 < nch) nsl *= 2;                      // 1, 2, 4, 8 column slices of <= 16 chunks
+    ncw = (nch + nsl - 1) / nsl;
+    S = 16 / ncw;
+    if (S > 4) S = 4;
+    const int wgs = pv_qr_wgs();
+    // every wave is its own split (whole units of 32 S rows, at most 320 rows): k * (8 waves * CUs / G) wave ranges for the
+    // smallest k that fits -- one round of 8-wave workgroups (256 VGPRs per wave: one workgroup per CU) whenever possible
+    const int RU = 32 * S, nws = 8 / nsl;
+    const long long P = ((long long)wgs * palu_num_cus() * nws + G - 1) / G;
+    const int rpw_max = 320 / RU * RU;
+    long long rpw = rpw_max;
+    for (int k = 1; k <= 1024; ++k) {
+      long long r = (L + k * P - 1) / (k * P);
+      r = (r + RU - 1) / RU * RU;
+      if (r <= rpw_max) { rpw = r; break; }
+    }
+    rps_qr = (int)rpw * nws;
+    ns_qr = (L + rps_qr - 1) / rps_qr;
+    if (ns_qr > pv_nsplit_bound(G, L, Rv)) qr = false;       // (cannot happen for a workspace sized by palu_pv_workspace_bytes)
+  }
+  if (qr) {
+    rps = rps_qr;
+    const int nws_q = 8 / nsl;
+    const int ns = ns_qr;                                  // ranges (one workgroup each) = splits seen by pv_combine
+    const int nwg = ns;
+    (void)nws_q;
+    float* ws = (float*)workspace;
+    PvQParams p;
+    p.scores = (const h16*)scores; p.ss_h = ss_h; p.mask = (const h16*)mask;
+    p.codes = (const unsigned char*)codes; p.sc_g = sc_g; p.sc_l = sc_l;
+    p.meta = (const h16*)meta; p.sm_g = sm_g; p.sm_l = sm_l;
+    p.part = ws;
+    p.ml = ws + (size_t)H * ns * Rv;
+    float* stats = p.ml + (size_t)H * ns * 2;
+    p.G = G; p.gs = gs; p.L = L; p.Rv = Rv; p.nsplit = ns; p.rps = rps;
+    p.inv_scale = sqrt_d;
+    {
+      static int ex = -1;
+      if (ex < 0) {
+        const char* e = getenv("PALU_PVQ_EXP");      // timing experiments (1: no unit loop, 2: one row per range); results are wrong when set
+        ex = e ? atoi(e) : 0;
+      }
+      p.exp_flags = ex;
+    }
+    p.qr_nsl = nsl; p.qr_ncw = ncw; p.qr_s = S;
+    const size_t ldsr = (size_t)8 * 4 * (320 + 8) * sizeof(h16) + (size_t)8 * 16 * 33 * 4 * sizeof(float) +
+                        (size_t)8 * gs * 4 * sizeof(float);
+    dim3 gridr(G * nwg), blockr(512);
+#define PALU_PVQR(GSV)                                                                                 \
+  if (bits == 4) hipLaunchKernelGGL((pv_partial_qr_kernel<GSV, 4>), gridr, blockr, ldsr, s, p);        \
+  else hipLaunchKernelGGL((pv_partial_qr_kernel<GSV, 3>), gridr, blockr, ldsr, s, p)
+    switch (gs) {
+      case 1: PALU_PVQR(1); break;
+      case 2: PALU_PVQR(2); break;
+      default: PALU_PVQR(4); break;
+    }
+#undef PALU_PVQR
+    PALU_LAUNCH_CHECK();
+    int rcq = palu_pv_combine_launch(ws, ctx, H, G, Rv, ns, s);
+    if (rcq) return rcq;
+    if (probs) {
+      int bx = (L + 255) / 256;
+      if (bx > 64) bx = 64;
+      hipLaunchKernelGGL(probs_kernel, dim3(bx, H), dim3(256), 0, s, (const h16*)scores, ss_h, (const h16*)mask,
+                         (const float*)stats, (h16*)probs, sp_h, L, sqrt_d);
+      PALU_LAUNCH_CHECK();
+    }
+    return PALU_OK;
+  }
   if (qm) {
     // whole tiles; as many workgroups as are resident at once (PALU_PVQ_WGS per CU, default 2), never more splits than the VALU kernel would use (the workspace bound holds)
     static int wgs = 0;
