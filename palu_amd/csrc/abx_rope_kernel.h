@@ -642,10 +642,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
   //      KIND 0 also carries the LDS-DMA pieces of tile stt into ring slot sslot (or the quantised staging),
   //      KIND 1 the reduce/store of tile stt (partials in red[sslot]); LAST = block 3: the fragment prefetch
   //      crosses into block 0 of the next tile (ring distance nd bytes); KIND 3 = drain (epilogue only).
-  auto region = [&](auto kind_c, auto last_c, f32x16 (&acN)[NMM], int blk, int erslot, int eblk,
+  auto region = [&](auto kind_c, auto last_c, auto exact_c, f32x16 (&acN)[NMM], int blk, int erslot, int eblk,
                     const f32x16 (&acP)[NMM], int stt, int sslot, unsigned nd) {
     constexpr int KIND = decltype(kind_c)::value;
     constexpr bool LAST = decltype(last_c)::value;
+    constexpr bool EXACT = decltype(exact_c)::value;
     constexpr int GAPS = NKS * NMM;
     // chunks per pair j: [ang, lo, cc, ss] | per M-block: 2 FMAs x 2 heads | [advance cos, sin by 32 positions].
     // (Packed fp32 -- v_pk_fma_f32 over head pairs -- was measured and is an anti-lever beside MFMAs on gfx950:
@@ -667,9 +668,15 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
         // cos/sin at the oracle's fp32-rounded angle fl(l*f): exact angle = ang + lo.  First order in lo drops
         // lo^2/2 < 3.1e-5 for positions < 2^18 (|lo| <= half an ulp of the angle); the host selects ORDER2 beyond that
         // (palu_abx_rope_f16: pos0 + L > 262144), e.g. the harness's max_position_embeddings = 300000
+        // Waves 4..7 own pairs 32..63 (inv_freq <= 0.01): below 2^18 positions their angles stay under 2622 rad, the
+        // residual under 1.2e-4 and its effect on a score far below the fp16 rounding of that score -- they use the
+        // exact-angle state as it is (EXACT = false: 4 of the 16 instructions per pair less on one wave of every SIMD).
         const float ang = lf * fr[j];
         const float lo = fmaf(lf, fr[j], -ang);
-        if (ORDER2) {
+        if (!EXACT) {
+          cc = cs[j];
+          ss = sn[j];
+        } else if (ORDER2) {
           const float hh = 0.5f * lo * lo;
           cc = fmaf(-hh, cs[j], fmaf(lo, sn[j], cs[j]));
           ss = fmaf(-hh, sn[j], fmaf(-lo, cs[j], sn[j]));
@@ -797,6 +804,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
   using Last = std::true_type;
   // ring slots: tile tt sits in slot tt % 3 (LDS ring and red[] alike); kept as three rotating scalars
   int s_cur = 0, s_nxt = 1, s_prv = 2;     // tt % 3, (tt + 1) % 3, (tt + 2) % 3 == (tt - 1) % 3
+  auto main_loop = [&](auto exact_c) {
   for (int tt = 0; tt < ntile; ++tt) {
     stamp();  // 5+2*tt: arrive at barrier
     if (tt > 0) {
@@ -809,17 +817,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
     // tt+2 into the ring, cross-wave reduction + store of tile tt-2
     if (TIMING && (p.exp_flags & 1) && young) continue;   // experiment: one computing wave per SIMD
     const unsigned nd = (unsigned)((s_nxt - s_cur) * Geo::TILE_BYTES);
-    region(K0{}, NotLast{}, accA, 0, s_prv, 3, accB, min(tt + 2, ntile - 1), s_prv, 0u);   // tt == 0: epilogue result discarded
-    region(K1{}, NotLast{}, accB, 1, s_cur, 0, accA, tt - 2, s_nxt, 0u);
+    region(K0{}, NotLast{}, exact_c, accA, 0, s_prv, 3, accB, min(tt + 2, ntile - 1), s_prv, 0u);   // tt == 0: epilogue result discarded
+    region(K1{}, NotLast{}, exact_c, accB, 1, s_cur, 0, accA, tt - 2, s_nxt, 0u);
     if (p.prio_mode == 2 && young) __builtin_amdgcn_s_setprio(0);  // ... the old half catches up in the second
-    region(K2{}, NotLast{}, accA, 2, s_cur, 1, accB, 0, 0, 0u);
-    region(K2{}, Last{}, accB, 3, s_cur, 2, accA, 0, 0, nd);       // prefetches block 0 of the next tile
+    region(K2{}, NotLast{}, exact_c, accA, 2, s_cur, 1, accB, 0, 0, 0u);
+    region(K2{}, Last{}, exact_c, accB, 3, s_cur, 2, accA, 0, 0, nd);       // prefetches block 0 of the next tile
     const int t3 = s_prv;
     s_prv = s_cur;
     s_cur = s_nxt;
     s_nxt = t3;
   }
-  region(K3{}, NotLast{}, accA, 0, s_prv, 3, accB, 0, 0, 0u);      // epilogue of the very last block
+  region(K3{}, NotLast{}, exact_c, accA, 0, s_prv, 3, accB, 0, 0, 0u);      // epilogue of the very last block
+  };
+  // ORDER2 launches (positions beyond 2^18) keep the correction on every wave
+  if (ORDER2 || w < 4 || (p.exp_flags & 4)) main_loop(std::true_type{}); else main_loop(std::false_type{});
   stamp();
   dma_wait();
   __syncthreads();

@@ -9,7 +9,9 @@
 //   pv_combine : merges the splits, normalises, rounds once to fp16
 //   probs      : optional attention weights (output_attentions=True), fp16 like :238
 // x = fp16(fp16(score)/sqrt(D)) [+ mask], the rounding points of the reference's fp16 tensors.
+#include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "palu_common.h"
 #include "pv_mfma.h"
@@ -239,6 +241,7 @@ struct PvQParams {
   float inv_scale;
   int exp_flags;   // PALU_PVQ_EXP (timing experiments of the matrix-core kernel; results are wrong when set)
   int qr_nsl, qr_ncw, qr_s;   // register-direct kernel: column slices, chunks per slice, row sets per unit
+  float rcp_scale;            // 1 / inv_scale when the 3-instruction quotient is exact for every fp16 score (else 0)
 };
 
 // one thread owns a 16-code column chunk (8 bytes at 4 bit, 6 bytes at 3 bit) and walks the rows in PAIRS:
@@ -714,6 +717,19 @@ struct QrDecode {
 // SGPR values and the magics as opaque VGPR values: the plain C expression then selects v_and_or_b32 v, v, s, v.
 // (Writing the instruction as inline asm is NOT an option: the hazard recogniser does not see an asm as a VALU write and
 //  leaves out the wait states an MFMA reading the result needs -- measured: sporadic NaNs in one code column.)
+static __device__ __forceinline__ float wave_max_dpp(float v) {
+#define PALU_DPP_MAX(CTRL, ROWMASK)                                                                                    \
+  v = fmaxf(v, __uint_as_float((unsigned)__builtin_amdgcn_update_dpp((int)__float_as_uint(v), (int)__float_as_uint(v), \
+                                                                       CTRL, ROWMASK, 0xF, false)))
+  PALU_DPP_MAX(0xB1, 0xF);    // quad_perm [1,0,3,2]
+  PALU_DPP_MAX(0x4E, 0xF);    // quad_perm [2,3,0,1]
+  PALU_DPP_MAX(0x141, 0xF);   // row_half_mirror
+  PALU_DPP_MAX(0x140, 0xF);   // row_mirror
+  PALU_DPP_MAX(0x142, 0xA);   // row_bcast:15 -> rows 1 and 3
+  PALU_DPP_MAX(0x143, 0xC);   // row_bcast:31 -> rows 2 and 3
+#undef PALU_DPP_MAX
+  return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
+}
 static __device__ __forceinline__ float wave_sum_dpp(float v) {
 #define PALU_DPP_ADD(CTRL, ROWMASK)                                                                                    \
   v += __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, ROWMASK, 0xF, true))
@@ -742,7 +758,7 @@ static __device__ __forceinline__ unsigned sgpr_const(unsigned c) {
 
 template <int GS, int BITS>
 __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
-  constexpr int NW = 8, NSET = 2, NJ = 32, MAXR = 5;     // MAXR * 64 = 320 rows per wave at most
+  constexpr int NW = 8, NSET = 2, NJ = 32, MAXR = 9;     // MAXR * 64 = 576 rows per wave at most
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const unsigned smem_lds = (unsigned)reinterpret_cast<uintptr_t>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -759,7 +775,7 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
   const int nsl = p.qr_nsl, ncw = p.qr_ncw, S = p.qr_s;          // slices, chunks per slice, row sets (host plan)
   const int RU = 32 * S;
   const int sl = wv % nsl, wph = wv / nsl, nws = NW / nsl;       // this wave: slice, row phase; waves per slice
-  const int rpw = p.rps / nws;                                   // rows per wave: a multiple of RU, <= 320
+  const int rpw = p.rps / nws;                                   // rows per wave: a multiple of RU, <= 576
   const int r0 = wph * rpw;
   const int nw = max(0, min(n - r0, rpw));                       // valid rows of this wave
   const int nwlast = max(nw - 1, 0);
@@ -769,7 +785,7 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
   float* part = p.part + (size_t)(g * p.nsplit + split) * GS * p.Rv;
   // LDS: per-wave weight rows [4][WS] fp16 | per-wave red [S * ncw][33][4 heads] fp32 (the accumulators on their way
   // out) | stat [NW][GS][4] fp32 (max, sum, zero-point term, weight sum)
-  const int WS = 320 + 8;
+  const int WS = 576 + 8;
   const unsigned wl_wave = smem_lds + (unsigned)(wv * 4 * WS * sizeof(h16));
   h16* wl = reinterpret_cast<h16*>(smem_raw) + (size_t)wv * 4 * WS;
   float* red_all = reinterpret_cast<float*>(smem_raw + (size_t)NW * 4 * WS * sizeof(h16));
@@ -814,13 +830,16 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
     unsigned mt[MAXR];
     const h16* mb = p.meta + (int64_t)g * p.sm_g + (int64_t)(l0 + r0) * p.sm_l;
     const h16* mkp = p.mask ? p.mask : p.scores + (int64_t)g * GS * p.ss_h;   // branch-free: a dummy row when there is no mask
+    const int kmax = (rpw + 63) >> 6;                       // row batches of this launch (uniform): the rest is skipped
 #pragma unroll
     for (int k = 0; k < MAXR; ++k) {
-      const int ic = min(lane + 64 * k, nwlast);
+      if (k < kmax) {
+        const int ic = min(lane + 64 * k, nwlast);
 #pragma unroll
-      for (int h = 0; h < GS; ++h) sc[k][h] = p.scores[(int64_t)(g * GS + h) * p.ss_h + l0 + r0 + ic];
-      mk[k] = mkp[l0 + r0 + ic];
-      mt[k] = *reinterpret_cast<const unsigned*>(mb + (int64_t)ic * p.sm_l);
+        for (int h = 0; h < GS; ++h) sc[k][h] = p.scores[(int64_t)(g * GS + h) * p.ss_h + l0 + r0 + ic];
+        mk[k] = mkp[l0 + r0 + ic];
+        mt[k] = *reinterpret_cast<const unsigned*>(mb + (int64_t)ic * p.sm_l);
+      }
     }
     // the first units are requested BEHIND the (small) score / meta loads: loads return in order, so the statistics do
     // not wait for the V burst, and the burst is in flight while they are computed
@@ -831,20 +850,32 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
     for (int h = 0; h < GS; ++h) mloc[h] = -INFINITY;
 #pragma unroll
     for (int k = 0; k < MAXR; ++k) {
+      if (k >= kmax) continue;
       const bool ok = lane + 64 * k < nw;
 #pragma unroll
       for (int h = 0; h < GS; ++h) {
-        // fp16 tensor / python float -> fp32 divide, rounded to fp16 (torch semantics); then + mask in fp16
-        h16 x16 = (h16)((float)sc[k][h] / p.inv_scale);
+        // fp16 tensor / python float -> fp32 divide, rounded to fp16 (torch semantics); then + mask in fp16.  The IEEE
+        // quotient costs ~12 instructions; q0 = x r, q1 = fma(fma(-q0, d, x), r, q0) gives the same bits for EVERY fp16 x
+        // when the host has checked that for this divisor (pv_exact_rcp: all 63488 finite inputs; true for sqrt(128))
+        const float xs = (float)sc[k][h];
+        float qv;
+        if (p.rcp_scale != 0.f) {
+          const float q0 = xs * p.rcp_scale;
+          qv = fmaf(fmaf(-q0, p.inv_scale, xs), p.rcp_scale, q0);
+        } else {
+          qv = xs / p.inv_scale;
+        }
+        h16 x16 = (h16)qv;
         if (p.mask) x16 = (h16)((float)x16 + (float)mk[k]);
         xl[k][h] = ok ? (float)x16 : -INFINITY;
         mloc[h] = fmaxf(mloc[h], xl[k][h]);
       }
     }
 #pragma unroll
-    for (int h = 0; h < GS; ++h) mloc[h] = wave_max(mloc[h]);
+    for (int h = 0; h < GS; ++h) mloc[h] = wave_max_dpp(mloc[h]);
 #pragma unroll
     for (int k = 0; k < MAXR; ++k) {
+      if (k >= kmax) continue;
       const int i = lane + 64 * k;
       const h16x2 m2 = __builtin_bit_cast(h16x2, mt[k]);
       const int slot = (i & ~31) + ((i & 3) << 3) + ((i & 31) >> 2);          // row 32b + 4e + q -> k-slot order 32b + 8q + e
@@ -1129,6 +1160,29 @@ int pv_wgs_per_cu() {
 
 // split target: ~PALU_PV_WGS_PER_CU (default 4) workgroups per CU in flight, whole multiples of the CU count
 // (every CU gets the same number of workgroups: no straggler round)
+// 1 / d if  q0 = x * r,  q1 = fma(fma(-q0, d, x), r, q0)  equals the IEEE quotient x / d for every finite fp16 x, else 0
+// (checked once per divisor on the host, all 63488 inputs)
+float pv_exact_rcp(float d) {
+  static float last_d = 0.f, last_r = 0.f;
+  if (d == last_d) return last_r;
+  const float r = 1.0f / d;
+  bool ok = d > 0.f;
+  for (unsigned bits = 0; ok && bits < 65536u; ++bits) {
+    const unsigned short hb = (unsigned short)bits;
+    _Float16 xh;
+    memcpy(&xh, &hb, 2);
+    const float x = (float)xh;
+    if (!(x - x == 0.f)) continue;                       // inf / nan
+    const float q0 = x * r;
+    const float q1 = fmaf(fmaf(-q0, d, x), r, q0);
+    const float ref = x / d;
+    if (memcmp(&q1, &ref, 4) != 0 && !(q1 == 0.f && ref == 0.f)) ok = false;
+  }
+  last_d = d;
+  last_r = ok ? r : 0.f;
+  return last_r;
+}
+
 int pv_qr_wgs() {
   static int wgs = 0;
   if (wgs == 0) {
@@ -1165,8 +1219,8 @@ int pv_nsplit_bound(int G, int Lcap, int Rv) {
   const long long b = ((long long)Lcap + 2047) / 2048;
   long long r = a > b ? a : b;
   // the register-direct quantised kernel (pv_partial_qr_kernel): ranges of nws = 8 / (column slices) wave ranges, k rounds
-  // of Pr = CUs / G ranges for the smallest k that keeps a wave range <= 320 rows (whole units, >= 32 rows); k > 1 only
-  // when k - 1 did not fit, which keeps a wave range above (320 - 128) / 2 = 96 rows
+  // of Pr = CUs / G ranges for the smallest k that keeps a wave range <= 576 rows (whole units, >= 32 rows); k > 1 only
+  // when k - 1 did not fit, which keeps a wave range above (576 - 128) / 2 = 224 rows (96 is used: a safe under-estimate)
   int nsl = 1;
   while (nsl * 16 < Rv / 32) nsl *= 2;
   const long long nws = nsl >= 8 ? 1 : 8 / nsl;
@@ -1312,11 +1366,11 @@ extern "C" int palu_softmax_pv_q(const void* scores, int64_t ss_h, const void* m
     S = 16 / ncw;
     if (S > 4) S = 4;
     const int wgs = pv_qr_wgs();
-    // every wave is its own split (whole units of 32 S rows, at most 320 rows): k * (8 waves * CUs / G) wave ranges for the
+    // every wave is its own split (whole units of 32 S rows, at most 576 rows): k * (8 waves * CUs / G) wave ranges for the
     // smallest k that fits -- one round of 8-wave workgroups (256 VGPRs per wave: one workgroup per CU) whenever possible
     const int RU = 32 * S, nws = 8 / nsl;
     const long long P = ((long long)wgs * palu_num_cus() * nws + G - 1) / G;
-    const int rpw_max = 320 / RU * RU;
+    const int rpw_max = 576 / RU * RU;
     long long rpw = rpw_max;
     for (int k = 1; k <= 1024; ++k) {
       long long r = (L + k * P - 1) / (k * P);
@@ -1352,7 +1406,8 @@ extern "C" int palu_softmax_pv_q(const void* scores, int64_t ss_h, const void* m
       p.exp_flags = ex;
     }
     p.qr_nsl = nsl; p.qr_ncw = ncw; p.qr_s = S;
-    const size_t ldsr = (size_t)8 * 4 * (320 + 8) * sizeof(h16) + (size_t)8 * 16 * 33 * 4 * sizeof(float) +
+    p.rcp_scale = pv_exact_rcp(sqrt_d);
+    const size_t ldsr = (size_t)8 * 4 * (576 + 8) * sizeof(h16) + (size_t)8 * 16 * 33 * 4 * sizeof(float) +
                         (size_t)8 * gs * 4 * sizeof(float);
     dim3 gridr(G * nwg), blockr(512);
 #define PALU_PVQR(GSV)                                                                                 \
