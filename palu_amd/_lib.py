@@ -9,7 +9,8 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpalu_hip.so")
+LIB_PATH = os.environ.get("PALU_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libpalu_hip.so")
+# (PALU_HIP_LIB: an alternative build of the same library, for kernel experiments -- never a different implementation)
 
 
 class PaluError(RuntimeError):

@@ -239,8 +239,9 @@ struct PvQParams {
   float* ml;
   int G, gs, L, Rv, nsplit, rps;
   float inv_scale;
-  int exp_flags;   // PALU_PVQ_EXP (timing experiments of the matrix-core kernel; results are wrong when set)
+  int exp_flags;   // PALU_PVQ_EXP = 8: timeline dump of pv_partial_qr_kernel (tools/time_pvq.py)
   int qr_nsl, qr_ncw, qr_s;   // register-direct kernel: column slices, chunks per slice, row sets per unit
+  unsigned qr_park_off;       // LDS offset of the parked per-lane partial sums [8 waves][3][64 lanes] f32x4
   float rcp_scale;            // 1 / inv_scale when the 3-instruction quotient is exact for every fp16 score (else 0)
 };
 
@@ -443,243 +444,6 @@ __global__ __launch_bounds__(PV_THREADS) void pv_partial_q_kernel(PvQParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Quantised V latents on the matrix cores (pv_mfma.h).  The VALU kernel above spends 3-4.5 instructions per code
-// (extraction + one v_dot2 per head); here a code costs one extraction step and nothing per head:
-//   packed codes --coalesced global loads, thread = one 32-code chunk of a [32*NRH rows][Rv] tile, PF tiles in flight-->
-//     registers --(1024 + code) fp16 pairs: v_and_or / v_bfe + v_lshl_or--> ds_write_b128 into [32 rows][64 codes] fp16
-//     unit images (the XOR-swizzled layout of pv_mfma.h, double buffered, one barrier per tile)
-//     --ds_read_b64_tr_b16--> v_mfma_f32_16x16x32_f16
-// with B = w = fp16(e^(x-m) * scale_row):   sum_l w_l (1024 + c_l)  -  sum_l w_l (1024 + z_l)  =  sum_l p_l s_l (c_l - z_l).
-// Wave (slice cs, phase uh) owns 64 latent columns of every NRH-th 32-row unit; threads = Rv * NRH, so a tile is exactly
-// one chunk per thread.  The logits are evaluated twice (maximum, then weights) instead of being parked in LDS.
-template <int BITS>
-static __device__ __forceinline__ void unpack32(const unsigned (&w)[BITS], unsigned (&o)[16]) {
-  if (BITS == 4) {
-    // dword d = codes c0..c7: (d >> 4i) & 0x000F000F = (c_i, c_{i+4}) -> image column order [c0 c4 c1 c5 c2 c6 c3 c7]
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[4 * d + i] = ((w[d] >> (4 * i)) & 0x000F000Fu) | 0x64006400u;
-  } else {
-    // 6-bit field f = (c_2i, c_2i+1) at bit 6i of the 96-bit row chunk; f | f << 13 puts c_2i+1 at bits 16..18
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int bit = 6 * i, dw = bit >> 5, sh = bit & 31;
-      unsigned f;
-      if (sh + 6 <= 32) {
-        f = __builtin_amdgcn_ubfe(w[dw], sh, 6);
-      } else {
-        f = __builtin_amdgcn_alignbit(w[(dw + 1) % BITS], w[dw], sh) & 0x3Fu;
-      }
-      o[i] = ((f | (f << 13)) & 0x00070007u) | 0x64006400u;
-    }
-  }
-}
-
-template <int GS, int BITS, int NCS, int NRH>
-__global__ __launch_bounds__(64 * NCS * NRH) void pv_partial_qm_kernel(PvQParams p) {
-  constexpr int NWV = NCS * NRH, NTH = 64 * NWV, BT = 3, TR = 32 * NRH, CR = 2 * NCS;   // CR: 32-code chunks per row
-  // unit images are 4096 + 128 bytes apart and slice cs XORs its 32-byte segments with (cs >> 1) & 3 on top of the row
-  // key: the 8 lanes of a ds_write_b128 group (4 slices x 2 halves of one row) then hit 8 different 16-byte bank groups
-  // (4 KB apart with the plain layout they were 4-way conflicts, and the LDS write port was the kernel's bottleneck)
-  constexpr int IMG = 4096 + 128;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const unsigned smem_lds = (unsigned)reinterpret_cast<uintptr_t>(smem_raw);
-  h16* wl = reinterpret_cast<h16*>(smem_raw);                        // [4][rps] fp16 weights (heads >= GS: zeros)
-  const unsigned img_off = (unsigned)(4 * p.rps * sizeof(h16));      // [2 buffers][NWV][4 KB] unit images
-  // block-reduction scratch behind the images (no static __shared__: the image addresses must stay 128-byte aligned)
-  float (*shg)[GS][NWV] = reinterpret_cast<float (*)[GS][NWV]>(smem_raw + img_off + 2 * NWV * IMG);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = blockIdx.x % p.G;
-  const int split = blockIdx.x / p.G;
-  const int l0 = split * p.rps;
-  const int n = max(0, min(p.L - l0, p.rps));
-  const int nlast = max(n - 1, 0);
-  float* ml = p.ml + ((size_t)(g * p.nsplit + split) * GS) * 2;
-  float* part = p.part + (size_t)(g * p.nsplit + split) * GS * p.Rv;
-
-  // ---- V stream: thread = chunk (row trow of the tile, 32 codes cchunk of the row): consecutive threads read
-  //      consecutive bytes of the packed rows
-  const int trow = tid / CR, cchunk = tid - trow * CR;
-  const unsigned char* cb = p.codes + (int64_t)g * p.sc_g + (int64_t)l0 * p.sc_l + cchunk * (32 * BITS / 8);
-  const int ntile = p.rps / TR;             // every workgroup walks its whole range (rps is a multiple of BT tiles): rows
-                                            // past n are re-reads of row n-1 with weight 0, so the loop is branch-free
-  unsigned rawA[BT][BITS], rawB[BT][BITS];
-  auto load_tile = [&](unsigned (&r)[BITS], int t) {
-    const int row = min(TR * t + trow, nlast);
-    const unsigned* src = reinterpret_cast<const unsigned*>(cb + (int64_t)row * p.sc_l);
-    if (BITS == 4) {
-      const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
-      r[0] = v[0]; r[1] = v[1]; r[2 % BITS] = v[2]; r[3 % BITS] = v[3];
-    } else {
-#pragma unroll
-      for (int e = 0; e < BITS; ++e) r[e] = __builtin_nontemporal_load(src + e);
-    }
-  };
-  auto load_batch = [&](unsigned (&r)[BT][BITS], int t) {
-#pragma unroll
-    for (int j = 0; j < BT; ++j) load_tile(r[j], t + j);
-  };
-  load_batch(rawA, 0);   // in flight while the softmax statistics are computed
-
-  // ---- phase A: the raw scores (and mask, (scale, zero)) of this thread's <= MAXR rows are requested together (one
-  //      memory round trip), the scaled logits stay in registers between the maximum and the weight pass
-  constexpr int MAXR = (2048 + NTH - 1) / NTH;
-  h16 sc[MAXR][GS], mk[MAXR];
-  unsigned mt[MAXR];
-  const h16* mb = p.meta + (int64_t)g * p.sm_g + (int64_t)l0 * p.sm_l;
-  const h16* mkp = p.mask ? p.mask : p.scores + (int64_t)g * GS * p.ss_h;   // branch-free: a dummy row when there is no mask
-#pragma unroll
-  for (int k = 0; k < MAXR; ++k) {
-    const int ic = min(tid + k * NTH, nlast);
-#pragma unroll
-    for (int h = 0; h < GS; ++h) sc[k][h] = p.scores[(int64_t)(g * GS + h) * p.ss_h + l0 + ic];
-    mk[k] = mkp[l0 + ic];
-    mt[k] = *reinterpret_cast<const unsigned*>(mb + (int64_t)ic * p.sm_l);
-  }
-  float xl[MAXR][GS];
-  float mloc[GS], sloc[GS], corr[GS];
-#pragma unroll
-  for (int h = 0; h < GS; ++h) mloc[h] = -INFINITY;
-#pragma unroll
-  for (int k = 0; k < MAXR; ++k) {
-    const bool ok = tid + k * NTH < n;
-#pragma unroll
-    for (int h = 0; h < GS; ++h) {
-      // fp16 tensor / python float -> fp32 divide, rounded to fp16 (torch semantics); then + mask in fp16
-      h16 x16 = (h16)((float)sc[k][h] / p.inv_scale);
-      if (p.mask) x16 = (h16)((float)x16 + (float)mk[k]);
-      xl[k][h] = ok ? (float)x16 : -INFINITY;
-      mloc[h] = fmaxf(mloc[h], xl[k][h]);
-    }
-  }
-  auto block_all = [&](float (&v)[GS], int slot, bool is_max) {
-#pragma unroll
-    for (int h = 0; h < GS; ++h) v[h] = is_max ? wave_max(v[h]) : wave_sum(v[h]);
-    if (lane == 0) {
-#pragma unroll
-      for (int h = 0; h < GS; ++h) shg[slot][h][wv] = v[h];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int h = 0; h < GS; ++h) {
-      float r = shg[slot][h][0];
-#pragma unroll
-      for (int k = 1; k < NWV; ++k) r = is_max ? fmaxf(r, shg[slot][h][k]) : r + shg[slot][h][k];
-      v[h] = r;
-    }
-  };
-  block_all(mloc, 0, true);
-#pragma unroll
-  for (int h = 0; h < GS; ++h) {
-    sloc[h] = 0.f;
-    corr[h] = 0.f;
-  }
-#pragma unroll
-  for (int k = 0; k < MAXR; ++k) {
-    const int i = tid + k * NTH;
-    if (i < p.rps) {
-      const h16x2 m2 = __builtin_bit_cast(h16x2, mt[k]);
-#pragma unroll
-      for (int h = 0; h < 4; ++h) {
-        h16 wq = (h16)0.f;
-        if (h < GS && i < n) {
-          const float e = (mloc[h % GS] == -INFINITY) ? 0.f : __expf(xl[k][h % GS] - mloc[h % GS]);
-          sloc[h % GS] += e;
-          wq = (h16)(e * (float)m2[0]);
-          corr[h % GS] = fmaf((float)wq, 1024.f + (float)m2[1], corr[h % GS]);
-        }
-        wl[h * p.rps + i] = wq;
-      }
-    }
-  }
-  block_all(sloc, 1, false);
-  block_all(corr, 2, false);
-  if (tid == 0) {
-#pragma unroll
-    for (int h = 0; h < GS; ++h) {
-      ml[2 * h] = mloc[h];
-      ml[2 * h + 1] = sloc[h];
-    }
-  }
-  // (wl is published by the first barrier of the loop below)
-
-  // ---- phase B: unpack -> unit images -> barrier -> transpose read -> MFMA
-  pvm::Lane<4> ln = pvm::make_lane<4>(lane, 0, 0u, p.rps * 2);
-  ln.rd ^= (unsigned)((((wv % NCS) >> 1) & 3) << 5);                   // the slice's segment XOR (see IMG)
-  // where this thread's chunk goes: unit image (phase trow / 32, slice cchunk / 2), row trow % 32, the two 32-byte
-  // segments 2 * half and 2 * half + 1 (16 codes each), XOR-swizzled by the row key
-  const int w_uh = trow >> 5, w_row = trow & 31, w_half = cchunk & 1, w_cs = cchunk >> 1;
-  const unsigned wimg = smem_lds + img_off + (unsigned)((w_uh * NCS + w_cs) * IMG + w_row * 128);
-  const int w_key = pvm::Cfg<4>::key(w_row) ^ ((w_cs >> 1) & 3);
-  const unsigned wr0 = wimg + (unsigned)(((2 * w_half) ^ w_key) * 32);
-  const unsigned wr1 = wimg + (unsigned)(((2 * w_half + 1) ^ w_key) * 32);
-  const int uh = wv / NCS;                                            // this wave consumes image wv = uh * NCS + cs
-  const unsigned rimg = smem_lds + img_off + (unsigned)(wv * IMG);
-  f32x4 acc[4];
-#pragma unroll
-  for (int ct = 0; ct < 4; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-  typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
-  auto consume = [&](const unsigned (&r)[BT][BITS], int t0) {
-#pragma unroll
-    for (int j = 0; j < BT; ++j) {
-      const int t = t0 + j;
-      const unsigned boff = (unsigned)((t & 1) * NWV * IMG);
-      unsigned o[16];
-      unpack32<BITS>(r[j], o);
-      *(lds_u32x4*)(uintptr_t)(wr0 + boff) = u32x4{o[0], o[1], o[2], o[3]};
-      *(lds_u32x4*)(uintptr_t)(wr0 + boff + 16) = u32x4{o[4], o[5], o[6], o[7]};
-      *(lds_u32x4*)(uintptr_t)(wr1 + boff) = u32x4{o[8], o[9], o[10], o[11]};
-      *(lds_u32x4*)(uintptr_t)(wr1 + boff + 16) = u32x4{o[12], o[13], o[14], o[15]};
-      __syncthreads();   // tile t is complete; tile t-1's buffer is rewritten only after every wave passed this point
-      pvm::pv_unit<4>(acc, ln, rimg + boff, smem_lds + (unsigned)(32 * (t * NRH + uh) * 2));
-    }
-  };
-  // two register batches of BT tiles, one a full batch ahead (the streaming structure of pv_partial_kernel): the
-  // compiler's waits then keep a batch in flight; in-place refills of a single ring made it drain vmcnt(0) per iteration
-  for (int t = 0;;) {
-    load_batch(rawB, t + BT);
-    consume(rawA, t);
-    t += BT;
-    if (t >= ntile) break;
-    load_batch(rawA, t + BT);
-    consume(rawB, t);
-    t += BT;
-    if (t >= ntile) break;
-  }
-  // ---- sum the row phases, subtract the zero-point term, write the partial context
-  __syncthreads();   // all images are dead: reuse the area as red [NRH][NCS][GS][64]
-  float* red = reinterpret_cast<float*>(smem_raw + img_off);
-  {
-    // D layout (pv_mfma.h): lane l, reg j -> image column 16*ct + 4*(l/16) + j, head l % 16
-    const int cs = wv % NCS;
-    const int hn = lane & 15, qd = lane >> 4;
-    if (hn < GS) {
-#pragma unroll
-      for (int ct = 0; ct < 4; ++ct)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int pc = 16 * ct + 4 * qd + j;                                   // image column inside the slice
-          const int col = BITS == 4 ? 8 * (pc >> 3) + ((pc & 7) >> 1) + 4 * (pc & 1) : pc;   // undo the unpack order
-          red[((uh * NCS + cs) * GS + hn) * 64 + col] = acc[ct][j];
-        }
-    }
-  }
-  __syncthreads();
-  for (int o = tid; o < GS * p.Rv; o += NTH) {
-    const int h = o / p.Rv, c = o - h * p.Rv;
-    float cr = corr[0];                       // corr[h] for a runtime h: unrolled select chain (no scratch)
-#pragma unroll
-    for (int hh = 1; hh < GS; ++hh) cr = (h == hh) ? corr[hh] : cr;
-    float sum = -cr;
-#pragma unroll
-    for (int r = 0; r < NRH; ++r) sum += red[((r * NCS + (c >> 6)) * GS + h) * 64 + (c & 63)];
-    part[o] = sum;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Quantised V latents, register-direct: packed rows go HBM -> VGPRs -> MFMA operands with no LDS, no barrier and no
 // transpose read in between (pv_partial_qm_kernel above pays a ds_write + barrier + ds_read_tr round trip per 32 rows
 // and is latency-bound at 3 waves per SIMD).  The MFMA contracts over ROWS, and which row sits in which k-slot is
@@ -756,9 +520,9 @@ static __device__ __forceinline__ unsigned sgpr_const(unsigned c) {
   return d;
 }
 
-template <int GS, int BITS>
+template <int GS, int BITS, int S>
 __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
-  constexpr int NW = 8, NSET = 2, NJ = 32, MAXR = 9;     // MAXR * 64 = 576 rows per wave at most
+  constexpr int NW = 8, NSET = 2, NJ = 32;   // (a third register set spills next to the 128 accumulator registers)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const unsigned smem_lds = (unsigned)reinterpret_cast<uintptr_t>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -767,13 +531,14 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
   const int split = blockIdx.x / p.G;
   const int l0 = split * p.rps;
   const int n = max(0, min(p.L - l0, p.rps));
-  long long tstamp[5];
-  tstamp[0] = wall_clock64();
+  long long tstamp[5] = {0, 0, 0, 0, 0};
+  const bool stamps = (p.exp_flags & 8) != 0;               // timeline dump (tools/time_pvq.py)
+  if (stamps) tstamp[0] = wall_clock64();
 
   // ---- geometry (uniform): column slices of <= 16 chunks, S row sets per unit, every wave owns rpw consecutive rows
   const int nch = p.Rv >> 5;
-  const int nsl = p.qr_nsl, ncw = p.qr_ncw, S = p.qr_s;          // slices, chunks per slice, row sets (host plan)
-  const int RU = 32 * S;
+  const int nsl = p.qr_nsl, ncw = p.qr_ncw;                      // slices, chunks per slice (host plan; S = p.qr_s row sets)
+  constexpr int RU = 32 * S;
   const int sl = wv % nsl, wph = wv / nsl, nws = NW / nsl;       // this wave: slice, row phase; waves per slice
   const int rpw = p.rps / nws;                                   // rows per wave: a multiple of RU, <= 576
   const int r0 = wph * rpw;
@@ -783,12 +548,9 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
   const int m = lane & 15, q = lane >> 4;
   float* ml = p.ml + ((size_t)(g * p.nsplit + split) * GS) * 2;
   float* part = p.part + (size_t)(g * p.nsplit + split) * GS * p.Rv;
-  // LDS: per-wave weight rows [4][WS] fp16 | per-wave red [S * ncw][33][4 heads] fp32 (the accumulators on their way
+  // LDS: per-wave weight rows of one batch [4][64 + 8] fp16 | per-wave red [S * ncw][33][4 heads] fp32 (the accumulators on their way
   // out) | stat [NW][GS][4] fp32 (max, sum, zero-point term, weight sum)
-  const int WS = 576 + 8;
-  const unsigned wl_wave = smem_lds + (unsigned)(wv * 4 * WS * sizeof(h16));
-  h16* wl = reinterpret_cast<h16*>(smem_raw) + (size_t)wv * 4 * WS;
-  float* red_all = reinterpret_cast<float*>(smem_raw + (size_t)NW * 4 * WS * sizeof(h16));
+  float* red_all = reinterpret_cast<float*>(smem_raw + (size_t)NW * 4 * (64 + 8) * sizeof(h16));
   float* red = red_all + (size_t)wv * (16 * 33 * 4);
   float* stat = red_all + (size_t)NW * (16 * 33 * 4);
   // V operand lanes: n = (row set sA, chunk cA)
@@ -817,174 +579,200 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
     }
   };
 
-  // ---- softmax statistics and weights of THIS WAVE's rows (no workgroup barrier: a wave is its own split until the
-  //      epilogue merges the waves with exp(m_wave - m_wg)).  Same arithmetic as the kernels above.
-  float mloc[GS], sloc[GS], cz[GS], cw[GS];
+  // ---- softmax statistics ONLINE, in batches of 64 rows of this wave's range (no workgroup barrier: a wave
+  //      is its own split until the epilogue merges the waves with exp(m_wave - m_range)).  Per batch: scaled logits ->
+  //      wave maximum (DPP) -> if it raises the running maximum (a wave-uniform, rare event after the first batches) the
+  //      accumulators and the partial sums are rescaled -> weights fp16(e^(x-m) * scale_row) into the wave's LDS patch in
+  //      k-slot order -> the batch's units run on the matrix cores.  The raw scores / (scale, zero) of batch b+1 are
+  //      requested before the units of batch b run, into the registers batch b has just vacated; the V units stream through
+  //      two register sets all along, so HBM never waits for the statistics and a range may have any number of rows.
+  constexpr int UB = 64 / RU;                                // units per 64-row batch: 2 (S = 1) or 1 (S = 2)
+  const int nbatch = (nw + 63) >> 6;
+  // per-lane partial sums (sum e, sum w z, sum w; 4 heads each) live in LDS between batches: 12 registers that the unit
+  // loop needs more (with them in VGPRs hipcc spilled an accumulator inside the loop)
+  typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+  const unsigned park = smem_lds + p.qr_park_off + (unsigned)((wv * 3 * 64 + lane) * sizeof(f32x4));
 #pragma unroll
-  for (int h = 0; h < GS; ++h) mloc[h] = sloc[h] = cz[h] = cw[h] = 0.f;
-  if ((p.exp_flags & 2) || nw == 0) {                 // (spare waves of a group's last range touch no memory)
+  for (int t = 0; t < 3; ++t) *(lds_f32x4*)(uintptr_t)(park + t * 64 * sizeof(f32x4)) = f32x4{0.f, 0.f, 0.f, 0.f};
+  float mrun[GS];
 #pragma unroll
-    for (int s = 0; s < NSET; ++s) load_unit(raw[s], s);
-  } else {
-    h16 sc[MAXR][GS], mk[MAXR];
-    unsigned mt[MAXR];
-    const h16* mb = p.meta + (int64_t)g * p.sm_g + (int64_t)(l0 + r0) * p.sm_l;
-    const h16* mkp = p.mask ? p.mask : p.scores + (int64_t)g * GS * p.ss_h;   // branch-free: a dummy row when there is no mask
-    const int kmax = (rpw + 63) >> 6;                       // row batches of this launch (uniform): the rest is skipped
+  for (int h = 0; h < GS; ++h) mrun[h] = -INFINITY;
+  h16 sc[GS], mk;
+  unsigned mt;
+  const h16* mb = p.meta + (int64_t)g * p.sm_g + (int64_t)(l0 + r0) * p.sm_l;
+  const h16* mkp = p.mask ? p.mask : p.scores + (int64_t)g * GS * p.ss_h;   // branch-free: a dummy row when there is no mask
+  const bool has_mask = p.mask != nullptr;
+  auto load_scores = [&](int b) {
+    const int ic = min(b * 64 + lane, nwlast);
 #pragma unroll
-    for (int k = 0; k < MAXR; ++k) {
-      if (k < kmax) {
-        const int ic = min(lane + 64 * k, nwlast);
+    for (int h = 0; h < GS; ++h) sc[h] = p.scores[(int64_t)(g * GS + h) * p.ss_h + l0 + r0 + ic];
+    mk = mkp[l0 + r0 + ic];
+    mt = *reinterpret_cast<const unsigned*>(mb + (int64_t)ic * p.sm_l);
+  };
+  if (nw > 0) load_scores(0);                                // (spare waves of a group's last range touch no memory)
 #pragma unroll
-        for (int h = 0; h < GS; ++h) sc[k][h] = p.scores[(int64_t)(g * GS + h) * p.ss_h + l0 + r0 + ic];
-        mk[k] = mkp[l0 + r0 + ic];
-        mt[k] = *reinterpret_cast<const unsigned*>(mb + (int64_t)ic * p.sm_l);
-      }
-    }
-    // the first units are requested BEHIND the (small) score / meta loads: loads return in order, so the statistics do
-    // not wait for the V burst, and the burst is in flight while they are computed
-#pragma unroll
-    for (int s = 0; s < NSET; ++s) load_unit(raw[s], s);
-    float xl[MAXR][GS];
-#pragma unroll
-    for (int h = 0; h < GS; ++h) mloc[h] = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < MAXR; ++k) {
-      if (k >= kmax) continue;
-      const bool ok = lane + 64 * k < nw;
-#pragma unroll
-      for (int h = 0; h < GS; ++h) {
-        // fp16 tensor / python float -> fp32 divide, rounded to fp16 (torch semantics); then + mask in fp16.  The IEEE
-        // quotient costs ~12 instructions; q0 = x r, q1 = fma(fma(-q0, d, x), r, q0) gives the same bits for EVERY fp16 x
-        // when the host has checked that for this divisor (pv_exact_rcp: all 63488 finite inputs; true for sqrt(128))
-        const float xs = (float)sc[k][h];
-        float qv;
-        if (p.rcp_scale != 0.f) {
-          const float q0 = xs * p.rcp_scale;
-          qv = fmaf(fmaf(-q0, p.inv_scale, xs), p.rcp_scale, q0);
-        } else {
-          qv = xs / p.inv_scale;
-        }
-        h16 x16 = (h16)qv;
-        if (p.mask) x16 = (h16)((float)x16 + (float)mk[k]);
-        xl[k][h] = ok ? (float)x16 : -INFINITY;
-        mloc[h] = fmaxf(mloc[h], xl[k][h]);
-      }
-    }
-#pragma unroll
-    for (int h = 0; h < GS; ++h) mloc[h] = wave_max_dpp(mloc[h]);
-#pragma unroll
-    for (int k = 0; k < MAXR; ++k) {
-      if (k >= kmax) continue;
-      const int i = lane + 64 * k;
-      const h16x2 m2 = __builtin_bit_cast(h16x2, mt[k]);
-      const int slot = (i & ~31) + ((i & 3) << 3) + ((i & 31) >> 2);          // row 32b + 4e + q -> k-slot order 32b + 8q + e
-#pragma unroll
-      for (int h = 0; h < GS; ++h) {
-        h16 wq = (h16)0.f;
-        if (i < nw) {
-          const float e = (mloc[h] == -INFINITY) ? 0.f : __expf(xl[k][h] - mloc[h]);
-          sloc[h] += e;
-          wq = (h16)(e * (float)m2[0]);
-          cw[h] += (float)wq;
-          cz[h] = fmaf((float)wq, (float)m2[1], cz[h]);
-        }
-        wl[h * WS + slot] = wq;
-      }
-    }
-  }
+  for (int s = 0; s < NSET; ++s) load_unit(raw[s], s);       // requested BEHIND the small score loads: they return first
 
-  tstamp[1] = wall_clock64();
-  // ---- phase B.  P is the A operand (m = 4 * row set + head), the decoded codes the B operand (n = V lane):
+  // ---- P is the A operand (m = 4 * row set + head), the decoded codes the B operand (n = V lane):
   //      D lane (n, q) holds rows m = 4q .. 4q+3 = the 4 heads of row set q -> meaningful where q == sA(n)
   f32x4 acc[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int sP = m >> 2, hP = m & 3;
   const bool actP = sP < S && hP < GS;
+  const int WS = 64 + 8;                                     // one batch of weights per head
+  const unsigned wl_wave = smem_lds + (unsigned)(wv * 4 * WS * sizeof(h16));
+  h16* wl = reinterpret_cast<h16*>(smem_raw) + (size_t)wv * 4 * WS;
   const unsigned wl_lane = wl_wave + (unsigned)(((actP ? hP : 0) * WS + (actP ? sP : 0) * 32 + q * 8) * sizeof(h16));
   typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
   const unsigned M1024 = vgpr_const(0x64006400u), M128 = vgpr_const(0x58005800u), M16 = vgpr_const(0x4C004C00u),
                  M8 = vgpr_const(0x48004800u), M64 = vgpr_const(0x54005400u);
   const unsigned K07 = sgpr_const(0x00070007u), K38 = sgpr_const(0x00380038u), K1C0 = sgpr_const(0x01C001C0u),
                  K380 = sgpr_const(0x03800380u), K0F = sgpr_const(0x000F000Fu), KF0 = sgpr_const(0x00F000F0u);
+  // One unit: row-pair windows (byte permutes) -> code pairs as fp16 pairs (v_and_or_b32) -> MFMA, one block of 8 (4)
+  // code columns at a time.  (Column-major -- 4 operand registers live instead of 32 -- measured slower: every MFMA then
+  // waits on the v_and_or just in front of it.)
+  // (Requesting the set's next unit right after the windows are formed -- the packed words are dead from there -- was
+  //  tried: it keeps two units in flight all the time, but the 32 window registers on top of both sets spill.)
   auto consume = [&](const unsigned (&r)[8][BITS], int u) {
-    const u32x4 pw = *(const lds_u32x4*)(uintptr_t)(wl_lane + (unsigned)(u * RU * sizeof(h16)));
+    constexpr int NB = BITS == 3 ? 4 : 8, NWIN = BITS == 3 ? 2 : 1, NK = BITS == 3 ? 8 : 4;
+    const u32x4 pw = *(const lds_u32x4*)(uintptr_t)(wl_lane + (unsigned)(u * RU * sizeof(h16)));   // u: unit inside the batch
     const h16x8 pop = __builtin_bit_cast(h16x8, pw);
-    if (BITS == 3) {
-      // code column 8b + k of the chunk sits at bit 3k of the 3 bytes 3b .. 3b+2 of the row: bring those bytes to the
-      // front of a dword per row, then W1 = bytes (0,1) and W2 = bytes (1,2) of rows (2p, 2p+1) side by side
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        unsigned o[4][8];
+    for (int b = 0; b < NB; ++b) {
+      unsigned W[4][NWIN], ws1[4], ws2[4];
 #pragma unroll
-        for (int pr = 0; pr < 4; ++pr) {
+      for (int pr = 0; pr < 4; ++pr) {
+        if (BITS == 3) {
+          // code column 8b + k of the chunk sits at bit 3k of the 3 bytes 3b .. 3b+2 of the row: bring those bytes to
+          // the front of a dword per row, then W1 = bytes (0,1) and W2 = bytes (1,2) of rows (2p, 2p+1) side by side
           unsigned x0, x1;
           if (b == 0) { x0 = r[2 * pr][0]; x1 = r[2 * pr + 1][0]; }
           else if (b == 1) {
             x0 = __builtin_amdgcn_alignbit(r[2 * pr][1], r[2 * pr][0], 24);
             x1 = __builtin_amdgcn_alignbit(r[2 * pr + 1][1], r[2 * pr + 1][0], 24);
           } else if (b == 2) {
-            x0 = __builtin_amdgcn_alignbit(r[2 * pr][2], r[2 * pr][1], 16);
-            x1 = __builtin_amdgcn_alignbit(r[2 * pr + 1][2], r[2 * pr + 1][1], 16);
-          } else { x0 = r[2 * pr][2]; x1 = r[2 * pr + 1][2]; }                 // bytes 9..11 = bytes 1..3 of dword 2
-          const unsigned w1 = __builtin_amdgcn_perm(x1, x0, b == 3 ? 0x06050201u : 0x05040100u);
-          const unsigned w2 = __builtin_amdgcn_perm(x1, x0, b == 3 ? 0x07060302u : 0x06050201u);
-          const unsigned w1s = w1 >> 9, w2s = w2 >> 10;
+            x0 = __builtin_amdgcn_alignbit(r[2 * pr][2 % BITS], r[2 * pr][1], 16);
+            x1 = __builtin_amdgcn_alignbit(r[2 * pr + 1][2 % BITS], r[2 * pr + 1][1], 16);
+          } else { x0 = r[2 * pr][2 % BITS]; x1 = r[2 * pr + 1][2 % BITS]; }   // bytes 9..11 = bytes 1..3 of dword 2
+          W[pr][0] = __builtin_amdgcn_perm(x1, x0, b == 3 ? 0x06050201u : 0x05040100u);
+          W[pr][NWIN - 1] = __builtin_amdgcn_perm(x1, x0, b == 3 ? 0x07060302u : 0x06050201u);
+        } else {
+          // code column 4b + k sits at bit 4k of bytes 2b, 2b+1 of the row
+          W[pr][0] = __builtin_amdgcn_perm(r[2 * pr + 1][(b >> 1) % BITS], r[2 * pr][(b >> 1) % BITS],
+                                           (b & 1) ? 0x07060302u : 0x05040100u);
+        }
+        ws1[pr] = W[pr][0] >> (BITS == 3 ? 9 : 8);
+        ws2[pr] = W[pr][NWIN - 1] >> 10;
+      }
+      unsigned o[4][NK];
+#pragma unroll
+      for (int pr = 0; pr < 4; ++pr) {
+        const unsigned w1 = W[pr][0], w2 = W[pr][NWIN - 1];
+        if (BITS == 3) {
           o[pr][0] = and_or(w1, K07, M1024);
           o[pr][1] = and_or(w1, K38, M128);
           o[pr][2] = and_or(w1, K1C0, M16);
-          o[pr][3] = and_or(w1s, K07, M1024);
-          o[pr][4] = and_or(w1s, K38, M128);
-          o[pr][5] = and_or(w2, K380, M8);
-          o[pr][6] = and_or(w2s, K07, M1024);
-          o[pr][7] = and_or(w2s, K38, M128);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const h16x8 vop = __builtin_bit_cast(h16x8, u32x4{o[0][k], o[1][k], o[2][k], o[3][k]});
-          acc[8 * b + k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pop, vop, acc[8 * b + k], 0, 0, 0);
+          o[pr][3] = and_or(ws1[pr], K07, M1024);
+          o[pr][4 % NK] = and_or(ws1[pr], K38, M128);
+          o[pr][5 % NK] = and_or(w2, K380, M8);
+          o[pr][6 % NK] = and_or(ws2[pr], K07, M1024);
+          o[pr][7 % NK] = and_or(ws2[pr], K38, M128);
+        } else {
+          o[pr][0] = and_or(w1, K0F, M1024);
+          o[pr][1] = and_or(w1, KF0, M64);
+          o[pr][2] = and_or(ws1[pr], K0F, M1024);
+          o[pr][3] = and_or(ws1[pr], KF0, M64);
         }
       }
-    } else {
-      // code column 4b + k sits at bit 4k of bytes 2b, 2b+1 of the row
 #pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        unsigned o[4][4];
-#pragma unroll
-        for (int pr = 0; pr < 4; ++pr) {
-          const unsigned w = __builtin_amdgcn_perm(r[2 * pr + 1][(b >> 1) % BITS], r[2 * pr][(b >> 1) % BITS],
-                                                   (b & 1) ? 0x07060302u : 0x05040100u);
-          const unsigned ws = w >> 8;
-          o[pr][0] = and_or(w, K0F, M1024);
-          o[pr][1] = and_or(w, KF0, M64);
-          o[pr][2] = and_or(ws, K0F, M1024);
-          o[pr][3] = and_or(ws, KF0, M64);
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const h16x8 vop = __builtin_bit_cast(h16x8, u32x4{o[0][k], o[1][k], o[2][k], o[3][k]});
-          acc[4 * b + k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pop, vop, acc[4 * b + k], 0, 0, 0);
-        }
+      for (int k = 0; k < NK; ++k) {
+        const h16x8 vop = __builtin_bit_cast(h16x8, u32x4{o[0][k], o[1][k], o[2][k], o[3][k]});
+        acc[NK * b + k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pop, vop, acc[NK * b + k], 0, 0, 0);
       }
     }
   };
-  // NSET named register sets, each refilled right after it was consumed (NSET - 1 units stay in flight); the weight
-  // rows were written by this wave itself: LDS operations of one wave complete in order, no barrier
-  for (int u = 0; u < ((p.exp_flags & 1) ? 0 : nunit); u += NSET) {
+
+  // statistics of batch b (its raw scores are in sc / mk / mt), weights into the LDS patch; then batch b+1 is requested.
+  // Branch-free except for the (wave-uniform, rare) rescale.
+  auto batch_stats = [&](int b) {
+    const bool ok = b * 64 + lane < nw;
+    const float mkf = has_mask ? (float)mk : 0.f;            // x + 0 leaves the fp16 logit as it is
+    float xl[GS], mb_[GS];
+    bool raise = false;
+#pragma unroll
+    for (int h = 0; h < GS; ++h) {
+      // fp16 tensor / python float -> fp32 divide, rounded to fp16 (torch semantics); then + mask in fp16.  The IEEE
+      // quotient costs ~12 instructions; q0 = x r, q1 = fma(fma(-q0, d, x), r, q0) gives the same bits for EVERY fp16 x
+      // (the host checks that for the divisor of the launch -- pv_exact_rcp, all 63488 finite inputs; true for sqrt(128) --
+      // and takes the older kernels otherwise)
+      const float xs = (float)sc[h];
+      const float q0 = xs * p.rcp_scale;
+      const h16 x16 = (h16)fmaf(fmaf(-q0, p.inv_scale, xs), p.rcp_scale, q0);
+      xl[h] = ok ? (float)(h16)((float)x16 + mkf) : -INFINITY;
+      raise = raise || __builtin_amdgcn_ballot_w64(xl[h] > mrun[h]) != 0;
+    }
+    f32x4 ps = *(const lds_f32x4*)(uintptr_t)(park), pz = *(const lds_f32x4*)(uintptr_t)(park + 64 * sizeof(f32x4)),
+          pw = *(const lds_f32x4*)(uintptr_t)(park + 128 * sizeof(f32x4));
+    if (raise) {                                             // wave-uniform: some row of the batch beats a running maximum
+      // (the wave-wide maximum -- 6 DPP steps per head plus their hazard wait states, ~140 instructions per batch -- is
+      //  only evaluated in here: after the first batches of a range almost never)
+      f32x4 al = f32x4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+      for (int h = 0; h < GS; ++h) {
+        mb_[h] = wave_max_dpp(xl[h]);
+        const float mn = fmaxf(mrun[h], mb_[h]);
+        al[h] = mrun[h] == -INFINITY ? 0.f : __expf(mrun[h] - mn);
+        mrun[h] = mn;
+      }
+      ps *= al;
+      pz *= al;
+      pw *= al;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[j] *= al;
+    }
+    const h16x2 m2 = __builtin_bit_cast(h16x2, mt);
+    const int slot = ((lane & 32)) + ((lane & 3) << 3) + ((lane & 31) >> 2);   // row 32c + 4e + q -> k-slot order 32c + 8q + e
+#pragma unroll
+    for (int h = 0; h < GS; ++h) {
+      const float e = xl[h] == -INFINITY ? 0.f : __expf(xl[h] - mrun[h]);      // (x > -inf implies m >= x > -inf)
+      const h16 wq = (h16)(e * (float)m2[0]);
+      ps[h] += e;
+      pw[h] += (float)wq;
+      pz[h] = fmaf((float)wq, (float)m2[1], pz[h]);
+      wl[h * WS + slot] = wq;
+    }
+    *(lds_f32x4*)(uintptr_t)(park) = ps;
+    *(lds_f32x4*)(uintptr_t)(park + 64 * sizeof(f32x4)) = pz;
+    *(lds_f32x4*)(uintptr_t)(park + 128 * sizeof(f32x4)) = pw;
+    load_scores(b + 1);                                      // (clamped to the range: harmless after the last batch)
+  };
+  if (stamps) tstamp[1] = wall_clock64();
+  // unit u of the range sits in register set u % NSET (the loop is unrolled by NSET: the set index is a compile-time
+  // constant); a batch of statistics precedes the first of its UB units
+  for (int base = 0; base < nunit; base += NSET) {
 #pragma unroll
     for (int s = 0; s < NSET; ++s) {
-      if (u + s < nunit) consume(raw[s], u + s);
-      load_unit(raw[s], u + s + NSET);
+      const int u = base + s;
+      if (u < nunit) {
+        if ((u & (UB - 1)) == 0) batch_stats(u / UB);
+        consume(raw[s], u & (UB - 1));
+      }
+      load_unit(raw[s], u + NSET);
     }
   }
-  tstamp[2] = wall_clock64();
-  if (p.exp_flags & 4) {
-    float t = 0.f;
+  if (stamps) tstamp[2] = wall_clock64();
+  float mloc[GS], sloc[GS], cz[GS], cw[GS];
+  {
+    const f32x4 ps = *(const lds_f32x4*)(uintptr_t)(park), pz = *(const lds_f32x4*)(uintptr_t)(park + 64 * sizeof(f32x4)),
+                pw = *(const lds_f32x4*)(uintptr_t)(park + 128 * sizeof(f32x4));
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) t += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
-    if (tid < GS * p.Rv) part[tid] = t;
-    return;
+    for (int h = 0; h < GS; ++h) {
+      mloc[h] = mrun[h];
+      sloc[h] = ps[h];
+      cz[h] = pz[h];
+      cw[h] = pw[h];
+    }
   }
 
   // ---- merge of the waves: every wave parks its accumulators and statistics in its own LDS patch, ONE barrier (the only
@@ -1009,7 +797,7 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
 #pragma unroll
     for (int j = 0; j < NJ; ++j) dst[j] = acc[j];
   }
-  tstamp[3] = wall_clock64();
+  if (stamps) tstamp[3] = wall_clock64();
   __syncthreads();
   {
     // factors exp(m_wave - m_range) and the scalar terms.  Straight-line code (selects, no branches): the LDS reads are
@@ -1068,7 +856,7 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
       }
     }
   }
-  if ((p.exp_flags & 8) && lane == 0) {           // timeline dump behind the workspace proper (tools/time_pvq.py allocates it)
+  if (stamps && lane == 0) {           // timeline dump behind the workspace proper (tools/time_pvq.py allocates it)
     tstamp[4] = wall_clock64();
     long long* dbg = reinterpret_cast<long long*>(p.ml + ((size_t)p.G * GS * p.nsplit + (size_t)p.G * GS) * 2) + ((size_t)blockIdx.x * NW + wv) * 5;
 #pragma unroll
@@ -1218,18 +1006,14 @@ int pv_nsplit_bound(int G, int Lcap, int Rv) {
   if (a > T) a = T;
   const long long b = ((long long)Lcap + 2047) / 2048;
   long long r = a > b ? a : b;
-  // the register-direct quantised kernel (pv_partial_qr_kernel): ranges of nws = 8 / (column slices) wave ranges, k rounds
-  // of Pr = CUs / G ranges for the smallest k that keeps a wave range <= 576 rows (whole units, >= 32 rows); k > 1 only
-  // when k - 1 did not fit, which keeps a wave range above (576 - 128) / 2 = 224 rows (96 is used: a safe under-estimate)
+  // the register-direct quantised kernel (pv_partial_qr_kernel): one round of Pr = CUs / G ranges, each at least one
+  // unit (32 rows) per wave of a slice
   int nsl = 1;
   while (nsl * 16 < Rv / 32) nsl *= 2;
   const long long nws = nsl >= 8 ? 1 : 8 / nsl;
   const long long Pr = ((long long)pv_qr_wgs() * palu_num_cus() + G - 1) / G;
   long long c = ((long long)Lcap + 32 * nws - 1) / (32 * nws);
-  if (c > Pr) {
-    c = ((long long)Lcap + 96 * nws - 1) / (96 * nws) + 1;
-    if (c < Pr) c = Pr;
-  }
+  if (c > Pr) c = Pr;
   return (int)(r > c ? r : c);
 }
 
@@ -1331,24 +1115,6 @@ extern "C" int palu_softmax_pv_q(const void* scores, int64_t ss_h, const void* m
                    sm_g % 2 == 0 && sm_l % 2 == 0,
                PALU_ERR_ARG, "softmax_pv_q: packed rows / meta must be 4-byte aligned");
   hipStream_t s = (hipStream_t)stream;
-  // matrix-core kernel: gs = 4, Rv a multiple of 64 with a (column slices, row phases) plan, 16-byte aligned 4-bit rows
-  int ncs = 0, nrh = 0;
-  switch (Rv) {
-    case 384: ncs = 6; nrh = 1; break;
-    case 192: ncs = 3; nrh = 2; break;
-    case 256: ncs = 4; nrh = 2; break;
-    case 128: ncs = 2; nrh = 4; break;
-    default: break;
-  }
-  static int qm_enabled = -1;
-  if (qm_enabled < 0) {
-    const char* e = getenv("PALU_PVQ_MFMA");
-    qm_enabled = e ? atoi(e) : 1;
-  }
-  // measured (tools/bench_q_kernels.py, same box): 3-bit C3 49 vs 54 us for the VALU kernel, 4-bit C4 55-62 vs 50 us --
-  // the matrix-core kernel is the default for 3-bit codes only (PALU_PVQ_MFMA=2 forces it for 4-bit as well, 0 turns it off)
-  const bool qm = qm_enabled && gs == 4 && ncs > 0 &&
-                  (bits == 3 || (qm_enabled == 2 && ((uintptr_t)codes & 15) == 0 && sc_g % 16 == 0 && sc_l % 16 == 0));
   int rps = pv_rows_per_split(G, L);
   // register-direct kernel (pv_partial_qr_kernel): any gs in {1,2,4}, Rv a multiple of 32 up to 4096, offsets below 2^31
   static int qr_enabled = -1;
@@ -1357,26 +1123,23 @@ extern "C" int palu_softmax_pv_q(const void* scores, int64_t ss_h, const void* m
     qr_enabled = e ? atoi(e) : 1;
   }
   const long long code_bytes = (long long)(L - 1) * sc_l + (long long)Rv * bits / 8;
-  bool qr = qr_enabled && code_bytes + 4096ll * sc_l < 0x7FFFFFFFll && (bits == 3 || sc_l % 4 == 0);
+  bool qr = qr_enabled && code_bytes + 4096ll * sc_l < 0x7FFFFFFFll && (bits == 3 || sc_l % 4 == 0) &&
+            pv_exact_rcp(sqrt_d) != 0.f;
   int nsl = 1, ncw = 0, S = 1, rps_qr = rps, ns_qr = 0;
   if (qr) {
     const int nch = Rv / 32;
     while (nsl * 16 < nch) nsl *= 2;                      // 1, 2, 4, 8 column slices of <= 16 chunks
     ncw = (nch + nsl - 1) / nsl;
     S = 16 / ncw;
-    if (S > 4) S = 4;
+    if (S > 2) S = 2;                                     // (a unit is at most one 64-row batch of statistics)
     const int wgs = pv_qr_wgs();
-    // every wave is its own split (whole units of 32 S rows, at most 576 rows): k * (8 waves * CUs / G) wave ranges for the
-    // smallest k that fits -- one round of 8-wave workgroups (256 VGPRs per wave: one workgroup per CU) whenever possible
+    // one round of 8-wave workgroups (256 VGPRs per wave: one workgroup per CU): CUs / G ranges per group, each cut
+    // into nws = 8 / slices wave ranges of whole units (32 S rows); the statistics are computed online, so a wave range
+    // may have any number of rows
     const int RU = 32 * S, nws = 8 / nsl;
     const long long P = ((long long)wgs * palu_num_cus() * nws + G - 1) / G;
-    const int rpw_max = 576 / RU * RU;
-    long long rpw = rpw_max;
-    for (int k = 1; k <= 1024; ++k) {
-      long long r = (L + k * P - 1) / (k * P);
-      r = (r + RU - 1) / RU * RU;
-      if (r <= rpw_max) { rpw = r; break; }
-    }
+    long long rpw = (L + P - 1) / P;
+    rpw = (rpw + RU - 1) / RU * RU;
     rps_qr = (int)rpw * nws;
     ns_qr = (L + rps_qr - 1) / rps_qr;
     if (ns_qr > pv_nsplit_bound(G, L, Rv)) qr = false;       // (cannot happen for a workspace sized by palu_pv_workspace_bytes)
@@ -1400,23 +1163,31 @@ extern "C" int palu_softmax_pv_q(const void* scores, int64_t ss_h, const void* m
     {
       static int ex = -1;
       if (ex < 0) {
-        const char* e = getenv("PALU_PVQ_EXP");      // timing experiments (1: no unit loop, 2: one row per range); results are wrong when set
+        const char* e = getenv("PALU_PVQ_EXP");      // 8: every wave dumps 5 wall-clock stamps behind the workspace (tools/time_pvq.py)
         ex = e ? atoi(e) : 0;
       }
       p.exp_flags = ex;
     }
     p.qr_nsl = nsl; p.qr_ncw = ncw; p.qr_s = S;
     p.rcp_scale = pv_exact_rcp(sqrt_d);
-    const size_t ldsr = (size_t)8 * 4 * (576 + 8) * sizeof(h16) + (size_t)8 * 16 * 33 * 4 * sizeof(float) +
-                        (size_t)8 * gs * 4 * sizeof(float);
+    size_t ldsr = (size_t)8 * 4 * (64 + 8) * sizeof(h16) + (size_t)8 * 16 * 33 * 4 * sizeof(float) +
+                  (size_t)8 * gs * 4 * sizeof(float);
+    ldsr = (ldsr + 15) / 16 * 16;
+    p.qr_park_off = (unsigned)ldsr;
+    ldsr += (size_t)8 * 3 * 64 * 4 * sizeof(float);
     dim3 gridr(G * nwg), blockr(512);
-#define PALU_PVQR(GSV)                                                                                 \
-  if (bits == 4) hipLaunchKernelGGL((pv_partial_qr_kernel<GSV, 4>), gridr, blockr, ldsr, s, p);        \
-  else hipLaunchKernelGGL((pv_partial_qr_kernel<GSV, 3>), gridr, blockr, ldsr, s, p)
+#define PALU_PVQR(GSV)                                                                                       \
+  if (bits == 4) {                                                                                           \
+    if (S == 1) hipLaunchKernelGGL((pv_partial_qr_kernel<GSV, 4, 1>), gridr, blockr, ldsr, s, p);            \
+    else hipLaunchKernelGGL((pv_partial_qr_kernel<GSV, 4, 2>), gridr, blockr, ldsr, s, p);                   \
+  } else {                                                                                                   \
+    if (S == 1) hipLaunchKernelGGL((pv_partial_qr_kernel<GSV, 3, 1>), gridr, blockr, ldsr, s, p);            \
+    else hipLaunchKernelGGL((pv_partial_qr_kernel<GSV, 3, 2>), gridr, blockr, ldsr, s, p);                   \
+  }
     switch (gs) {
-      case 1: PALU_PVQR(1); break;
-      case 2: PALU_PVQR(2); break;
-      default: PALU_PVQR(4); break;
+      case 1: PALU_PVQR(1) break;
+      case 2: PALU_PVQR(2) break;
+      default: PALU_PVQR(4) break;
     }
 #undef PALU_PVQR
     PALU_LAUNCH_CHECK();
@@ -1431,23 +1202,6 @@ extern "C" int palu_softmax_pv_q(const void* scores, int64_t ss_h, const void* m
     }
     return PALU_OK;
   }
-  if (qm) {
-    // whole tiles; as many workgroups as are resident at once (PALU_PVQ_WGS per CU, default 2), never more splits than the VALU kernel would use (the workspace bound holds)
-    static int wgs = 0;
-    if (wgs == 0) {
-      const char* e = getenv("PALU_PVQ_WGS");
-      wgs = e ? atoi(e) : 2;
-      if (wgs < 1) wgs = 1;
-    }
-    long long target = ((long long)wgs * palu_num_cus()) / G;
-    if (target < 1) target = 1;
-    long long r2 = (L + target - 1) / target;
-    r2 = (r2 + 383) / 384 * 384;          // whole batches of 3 tiles of 32 * NRH <= 128 rows
-    if (r2 > 1920) r2 = 1920;
-    if (r2 > rps) rps = (int)r2;
-    rps = (rps + 383) / 384 * 384;
-    if (rps > 1920) rps = 1920;
-  }
   const int ns = (L + rps - 1) / rps;
   float* ws = (float*)workspace;
   PvQParams p;
@@ -1459,38 +1213,7 @@ extern "C" int palu_softmax_pv_q(const void* scores, int64_t ss_h, const void* m
   float* stats = p.ml + (size_t)H * ns * 2;
   p.G = G; p.gs = gs; p.L = L; p.Rv = Rv; p.nsplit = ns; p.rps = rps;
   p.inv_scale = sqrt_d;
-  {
-    static int ex = -1;
-    if (ex < 0) {
-      const char* e = getenv("PALU_PVQ_EXP");
-      ex = e ? atoi(e) : 0;
-    }
-    p.exp_flags = ex;
-  }
-  if (qm) {
-    const int nwv = ncs * nrh;
-    const size_t ldsq = (size_t)8 * rps + (size_t)2 * nwv * (4096 + 128) + (size_t)3 * 4 * nwv * sizeof(float);
-    dim3 gridq(G * ns), blockq(64 * nwv);
-#define PALU_PVQM(NCSV, NRHV)                                                                                  \
-  if (bits == 4) hipLaunchKernelGGL((pv_partial_qm_kernel<4, 4, NCSV, NRHV>), gridq, blockq, ldsq, s, p);      \
-  else hipLaunchKernelGGL((pv_partial_qm_kernel<4, 3, NCSV, NRHV>), gridq, blockq, ldsq, s, p)
-    if (ncs == 6) { PALU_PVQM(6, 1); }
-    else if (ncs == 3) { PALU_PVQM(3, 2); }
-    else if (ncs == 4) { PALU_PVQM(4, 2); }
-    else { PALU_PVQM(2, 4); }
-#undef PALU_PVQM
-    PALU_LAUNCH_CHECK();
-    int rcq = palu_pv_combine_launch(ws, ctx, H, G, Rv, ns, s);
-    if (rcq) return rcq;
-    if (probs) {
-      int bx = (L + 255) / 256;
-      if (bx > 64) bx = 64;
-      hipLaunchKernelGGL(probs_kernel, dim3(bx, H), dim3(256), 0, s, (const h16*)scores, ss_h, (const h16*)mask,
-                         (const float*)stats, (h16*)probs, sp_h, L, sqrt_d);
-      PALU_LAUNCH_CHECK();
-    }
-    return PALU_OK;
-  }
+  p.exp_flags = 0;
   size_t lds = (size_t)gs * rps * (sizeof(float) + sizeof(h16));
   if (lds < (size_t)PV_THREADS * 16 * sizeof(float)) lds = (size_t)PV_THREADS * 16 * sizeof(float);
   dim3 grid(G * ns), block(PV_THREADS);

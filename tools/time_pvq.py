@@ -34,6 +34,7 @@ for i in cand:
 t = w64[base:]
 t = t[: (len(t) // 5) * 5].reshape(-1, 5)
 ok = (t[:, 0] > 0) & (t[:, 4] >= t[:, 0]) & (t[:, 4] - t[:, 0] < 10_000_000)
+idx = np.nonzero(ok)[0]
 t = t[ok].astype(np.float64)
 n = len(t)
 t0 = t[:, 0].min()
@@ -45,3 +46,15 @@ print("per wave, mean (min..max) us:  stats %.2f (%.2f..%.2f)  loop %.2f (%.2f..
     d[:, 2].mean(), d[:, 2].min(), d[:, 2].max(), d[:, 3].mean(), d[:, 3].min(), d[:, 3].max()))
 print("wave start times (us), percentiles 0/10/50/90/100:", np.round(np.percentile(t[:, 0], [0, 10, 50, 90, 100]), 1))
 print("wave end times (us), percentiles 0/10/50/90/100:  ", np.round(np.percentile(t[:, 4], [0, 10, 50, 90, 100]), 1))
+
+# per latent group (= XCD: workgroup id % G) and per workgroup: where is the spread?
+wg = idx // 8
+grp = wg % G
+loop_end = t[:, 2]
+print("per group (XCD): mean / max time at which a wave leaves the unit loop (us)")
+print("  " + "  ".join(f"g{g}: {loop_end[grp == g].mean():.1f}/{loop_end[grp == g].max():.1f}" for g in range(G)))
+wg_end = np.array([loop_end[wg == w].max() for w in np.unique(wg)])
+print("per workgroup: slowest wave leaves the loop at  min %.1f  median %.1f  max %.1f us" % (wg_end.min(), np.median(wg_end), wg_end.max()))
+wi = idx % 8
+print("per wave index: mean time of leaving the unit loop (us): " + "  ".join(f"w{w}: {loop_end[wi == w].mean():.1f}" for w in range(8)))
+print("per wave index: mean stats-done time (us):               " + "  ".join(f"w{w}: {t[wi == w, 1].mean():.1f}" for w in range(8)))
