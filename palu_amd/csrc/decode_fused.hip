@@ -103,7 +103,8 @@ extern "C" int palu_decode_attn_nsplit(int G, int L) {
 }
 
 extern "C" size_t palu_decode_attn_stats_offset(int H, int G, int L, int Rv) {
-  return (size_t)H * palu_decode_attn_nsplit(G, L) * (Rv + 2) * sizeof(float);
+  (void)H; (void)G; (void)L; (void)Rv;
+  return 0;     // (max, sum) pairs lead the workspace (pv_ws_stats_floats, palu_common.h)
 }
 
 extern "C" int palu_decode_attn_f16(const void* q, int64_t sq_h, int64_t sq_d, const void* bfrag, const void* k,
@@ -137,8 +138,8 @@ extern "C" int palu_decode_attn_f16(const void* q, int64_t sq_h, int64_t sq_d, c
   p.dbg = nullptr;
   float* ws = (float*)workspace;
   const int ns = p.nch;
-  p.part = ws;
-  p.ml = ws + (size_t)H * ns * Rv;
+  p.part = ws + pv_ws_stats_floats(H);
+  p.ml = p.part + (size_t)H * ns * Rv;
   hipStream_t s = (hipStream_t)stream;
   const int nwg = ns * G;
   int nts = 0, ntl = 0;
@@ -179,8 +180,8 @@ extern "C" int palu_decode_attn_f16_timed(const void* q, int64_t sq_h, int64_t s
   p.exp_flags = fused_exp_flags();
   p.dbg = dbg;
   float* ws = (float*)workspace;
-  p.part = ws;
-  p.ml = ws + (size_t)H * p.nch * Rv;
+  p.part = ws + pv_ws_stats_floats(H);
+  p.ml = p.part + (size_t)H * p.nch * Rv;
   if (nwg_out) *nwg_out = p.nch * G;
   return launch_fused<8, 2, 4, true>(p, p.nch * G, (hipStream_t)stream);
 }

@@ -472,6 +472,7 @@ struct QrDecode {
       const int k = j & 7;
       return (k == 0 || k == 3 || k == 6) ? 1024.f : (k == 1 || k == 4 || k == 7) ? 128.f : (k == 2) ? 16.f : 8.f;
     }
+    if (BITS == 16) return 0.f;
     return (j & 1) ? 64.f : 1024.f;
   }
 };
@@ -522,7 +523,14 @@ static __device__ __forceinline__ unsigned sgpr_const(unsigned c) {
 
 template <int GS, int BITS, int S>
 __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
-  constexpr int NW = 8, NSET = 2, NJ = 32;   // (a third register set spills next to the 128 accumulator registers)
+  // BITS = 3 / 4: packed codes, 32 per chunk.  BITS = 16: plain fp16 latents, 8 per chunk (16 bytes) -- the same kernel
+  // without a decode step: 8 accumulators instead of 32 leave room for four register sets of units in flight.
+  constexpr bool FP16 = BITS == 16;
+  constexpr int CW = FP16 ? 8 : 32;          // columns per chunk = MFMAs per unit = accumulators
+  constexpr int CHB = FP16 ? 16 : 4 * BITS;  // bytes per chunk
+  constexpr int RDW = BITS == 3 ? 3 : 4;     // dwords per chunk
+  constexpr int NW = 8, NSET = FP16 ? 4 : 2, NJ = CW;   // (packed: a third set spills next to 128 accumulator registers)
+  constexpr int NJP = NJ + 1;                // red: code columns + 1 pad (chunks on different banks)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const unsigned smem_lds = (unsigned)reinterpret_cast<uintptr_t>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -536,7 +544,7 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
   if (stamps) tstamp[0] = wall_clock64();
 
   // ---- geometry (uniform): column slices of <= 16 chunks, S row sets per unit, every wave owns rpw consecutive rows
-  const int nch = p.Rv >> 5;
+  const int nch = p.Rv / CW;
   const int nsl = p.qr_nsl, ncw = p.qr_ncw;                      // slices, chunks per slice (host plan; S = p.qr_s row sets)
   constexpr int RU = 32 * S;
   const int sl = wv % nsl, wph = wv / nsl, nws = NW / nsl;       // this wave: slice, row phase; waves per slice
@@ -551,8 +559,8 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
   // LDS: per-wave weight rows of one batch [4][64 + 8] fp16 | per-wave red [S * ncw][33][4 heads] fp32 (the accumulators on their way
   // out) | stat [NW][GS][4] fp32 (max, sum, zero-point term, weight sum)
   float* red_all = reinterpret_cast<float*>(smem_raw + (size_t)NW * 4 * (64 + 8) * sizeof(h16));
-  float* red = red_all + (size_t)wv * (16 * 33 * 4);
-  float* stat = red_all + (size_t)NW * (16 * 33 * 4);
+  float* red = red_all + (size_t)wv * (16 * NJP * 4);
+  float* stat = red_all + (size_t)NW * (16 * NJP * 4);
   // V operand lanes: n = (row set sA, chunk cA)
   const int sA = m / ncw, cA = m - sA * ncw, chunk = sl * ncw + cA;
   const bool actA = sA < S && chunk < nch;
@@ -561,10 +569,10 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
       reinterpret_cast<void*>(cbase), 0, (int)((int64_t)(p.L - 1) * p.sc_l + (int64_t)p.Rv * BITS / 8), 0x00020000);
   // per-lane byte offset of (row l0 + r0 + 32 sA + q, chunk); inactive lanes sit past the descriptor (zeros, no traffic)
   const unsigned sc_l = (unsigned)p.sc_l;
-  const unsigned voff0 = actA ? (unsigned)(l0 + r0 + 32 * sA + q) * sc_l + (unsigned)(chunk * 4 * BITS) : 0x80000000u;
+  const unsigned voff0 = actA ? (unsigned)(l0 + r0 + 32 * sA + q) * sc_l + (unsigned)(chunk * CHB) : 0x80000000u;
 
-  unsigned raw[NSET][8][BITS];
-  auto load_unit = [&](unsigned (&r)[8][BITS], int u) {
+  unsigned raw[NSET][8][RDW];
+  auto load_unit = [&](unsigned (&r)[8][RDW], int u) {
     // (units past this wave's range belong to the next split: sent past the descriptor, they cost no traffic)
     const unsigned vo = u < nunit ? voff0 + (unsigned)(u * RU) * sc_l : 0x80000000u;
 #pragma unroll
@@ -574,7 +582,7 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
         r[e][0] = v[0]; r[e][1] = v[1]; r[e][2] = v[2];
       } else {
         const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + (unsigned)(4 * e) * sc_l, 0, 0);
-        r[e][0] = v[0]; r[e][1] = v[1]; r[e][2 % BITS] = v[2]; r[e][3 % BITS] = v[3];
+        r[e][0] = v[0]; r[e][1] = v[1]; r[e][2] = v[2]; r[e][3 % RDW] = v[3];
       }
     }
   };
@@ -598,8 +606,8 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
 #pragma unroll
   for (int h = 0; h < GS; ++h) mrun[h] = -INFINITY;
   h16 sc[GS], mk;
-  unsigned mt;
-  const h16* mb = p.meta + (int64_t)g * p.sm_g + (int64_t)(l0 + r0) * p.sm_l;
+  unsigned mt = 0x00003C00u;                                 // (scale 1, zero 0): fp16 latents have no meta
+  const h16* mb = FP16 ? nullptr : p.meta + (int64_t)g * p.sm_g + (int64_t)(l0 + r0) * p.sm_l;
   const h16* mkp = p.mask ? p.mask : p.scores + (int64_t)g * GS * p.ss_h;   // branch-free: a dummy row when there is no mask
   const bool has_mask = p.mask != nullptr;
   auto load_scores = [&](int b) {
@@ -607,7 +615,7 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
 #pragma unroll
     for (int h = 0; h < GS; ++h) sc[h] = p.scores[(int64_t)(g * GS + h) * p.ss_h + l0 + r0 + ic];
     mk = mkp[l0 + r0 + ic];
-    mt = *reinterpret_cast<const unsigned*>(mb + (int64_t)ic * p.sm_l);
+    if (!FP16) mt = *reinterpret_cast<const unsigned*>(mb + (int64_t)ic * p.sm_l);
   };
   if (nw > 0) load_scores(0);                                // (spare waves of a group's last range touch no memory)
 #pragma unroll
@@ -625,19 +633,40 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
   h16* wl = reinterpret_cast<h16*>(smem_raw) + (size_t)wv * 4 * WS;
   const unsigned wl_lane = wl_wave + (unsigned)(((actP ? hP : 0) * WS + (actP ? sP : 0) * 32 + q * 8) * sizeof(h16));
   typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
-  const unsigned M1024 = vgpr_const(0x64006400u), M128 = vgpr_const(0x58005800u), M16 = vgpr_const(0x4C004C00u),
-                 M8 = vgpr_const(0x48004800u), M64 = vgpr_const(0x54005400u);
-  const unsigned K07 = sgpr_const(0x00070007u), K38 = sgpr_const(0x00380038u), K1C0 = sgpr_const(0x01C001C0u),
-                 K380 = sgpr_const(0x03800380u), K0F = sgpr_const(0x000F000Fu), KF0 = sgpr_const(0x00F000F0u);
+  unsigned M1024 = 0, M128 = 0, M16 = 0, M8 = 0, M64 = 0, K07 = 0, K38 = 0, K1C0 = 0, K380 = 0, K0F = 0, KF0 = 0;
+  if (BITS == 3) {
+    M1024 = vgpr_const(0x64006400u); M128 = vgpr_const(0x58005800u); M16 = vgpr_const(0x4C004C00u); M8 = vgpr_const(0x48004800u);
+    K07 = sgpr_const(0x00070007u); K38 = sgpr_const(0x00380038u); K1C0 = sgpr_const(0x01C001C0u); K380 = sgpr_const(0x03800380u);
+  } else if (BITS == 4) {
+    M1024 = vgpr_const(0x64006400u); M64 = vgpr_const(0x54005400u);
+    K0F = sgpr_const(0x000F000Fu); KF0 = sgpr_const(0x00F000F0u);
+  }
   // One unit: row-pair windows (byte permutes) -> code pairs as fp16 pairs (v_and_or_b32) -> MFMA, one block of 8 (4)
   // code columns at a time.  (Column-major -- 4 operand registers live instead of 32 -- measured slower: every MFMA then
   // waits on the v_and_or just in front of it.)
   // (Requesting the set's next unit right after the windows are formed -- the packed words are dead from there -- was
   //  tried: it keeps two units in flight all the time, but the 32 window registers on top of both sets spill.)
-  auto consume = [&](const unsigned (&r)[8][BITS], int u) {
+  auto consume = [&](const unsigned (&r)[8][RDW], int u) {
     constexpr int NB = BITS == 3 ? 4 : 8, NWIN = BITS == 3 ? 2 : 1, NK = BITS == 3 ? 8 : 4;
     const u32x4 pw = *(const lds_u32x4*)(uintptr_t)(wl_lane + (unsigned)(u * RU * sizeof(h16)));   // u: unit inside the batch
     const h16x8 pop = __builtin_bit_cast(h16x8, pw);
+    if (FP16) {
+      // dword d of a row holds columns 2d, 2d+1: one byte permute per (row pair, column) is the whole "decode"
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        unsigned lo[4], hi[4];
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+          lo[pr] = __builtin_amdgcn_perm(r[2 * pr + 1][d % RDW], r[2 * pr][d % RDW], 0x05040100u);
+          hi[pr] = __builtin_amdgcn_perm(r[2 * pr + 1][d % RDW], r[2 * pr][d % RDW], 0x07060302u);
+        }
+        acc[(2 * d) % NJ] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+            pop, __builtin_bit_cast(h16x8, u32x4{lo[0], lo[1], lo[2], lo[3]}), acc[(2 * d) % NJ], 0, 0, 0);
+        acc[(2 * d + 1) % NJ] = __builtin_amdgcn_mfma_f32_16x16x32_f16(
+            pop, __builtin_bit_cast(h16x8, u32x4{hi[0], hi[1], hi[2], hi[3]}), acc[(2 * d + 1) % NJ], 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       unsigned W[4][NWIN], ws1[4], ws2[4];
@@ -652,14 +681,14 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
             x0 = __builtin_amdgcn_alignbit(r[2 * pr][1], r[2 * pr][0], 24);
             x1 = __builtin_amdgcn_alignbit(r[2 * pr + 1][1], r[2 * pr + 1][0], 24);
           } else if (b == 2) {
-            x0 = __builtin_amdgcn_alignbit(r[2 * pr][2 % BITS], r[2 * pr][1], 16);
-            x1 = __builtin_amdgcn_alignbit(r[2 * pr + 1][2 % BITS], r[2 * pr + 1][1], 16);
-          } else { x0 = r[2 * pr][2 % BITS]; x1 = r[2 * pr + 1][2 % BITS]; }   // bytes 9..11 = bytes 1..3 of dword 2
+            x0 = __builtin_amdgcn_alignbit(r[2 * pr][2], r[2 * pr][1], 16);
+            x1 = __builtin_amdgcn_alignbit(r[2 * pr + 1][2], r[2 * pr + 1][1], 16);
+          } else { x0 = r[2 * pr][2]; x1 = r[2 * pr + 1][2]; }   // bytes 9..11 = bytes 1..3 of dword 2
           W[pr][0] = __builtin_amdgcn_perm(x1, x0, b == 3 ? 0x06050201u : 0x05040100u);
           W[pr][NWIN - 1] = __builtin_amdgcn_perm(x1, x0, b == 3 ? 0x07060302u : 0x06050201u);
         } else {
           // code column 4b + k sits at bit 4k of bytes 2b, 2b+1 of the row
-          W[pr][0] = __builtin_amdgcn_perm(r[2 * pr + 1][(b >> 1) % BITS], r[2 * pr][(b >> 1) % BITS],
+          W[pr][0] = __builtin_amdgcn_perm(r[2 * pr + 1][(b >> 1) % RDW], r[2 * pr][(b >> 1) % RDW],
                                            (b & 1) ? 0x07060302u : 0x05040100u);
         }
         ws1[pr] = W[pr][0] >> (BITS == 3 ? 9 : 8);
@@ -688,7 +717,7 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
 #pragma unroll
       for (int k = 0; k < NK; ++k) {
         const h16x8 vop = __builtin_bit_cast(h16x8, u32x4{o[0][k], o[1][k], o[2][k], o[3][k]});
-        acc[NK * b + k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pop, vop, acc[NK * b + k], 0, 0, 0);
+        acc[(NK * b + k) % NJ] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pop, vop, acc[(NK * b + k) % NJ], 0, 0, 0);
       }
     }
   };
@@ -793,7 +822,7 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
   }
   // red [row set * ncw + chunk][33 (32 code columns + 1 pad: chunks on different banks)][4 heads]
   if (actA && q == sA) {
-    f32x4* dst = reinterpret_cast<f32x4*>(red) + (size_t)(sA * ncw + cA) * 33;
+    f32x4* dst = reinterpret_cast<f32x4*>(red) + (size_t)(sA * ncw + cA) * NJP;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) dst[j] = acc[j];
   }
@@ -825,9 +854,9 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
         fw[h] = fmaf(f[w][h], st[w][h][3], fw[h]);
       }
     }
-    const int ncol = min(ncw, nch - sl * ncw) * 32;                  // columns of this slice, shared by its nws waves
+    const int ncol = min(ncw, nch - sl * ncw) * CW;                  // columns of this slice, shared by its nws waves
     for (int c = wph * 64 + lane; c < ncol; c += 64 * nws) {
-      const int c2 = c >> 5, jq = c & 31;
+      const int c2 = c / CW, jq = c % CW;
       const float off = QrDecode<BITS>::off(jq);
       f32x4 a[NW];
 #pragma unroll
@@ -836,7 +865,7 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
         f32x4 t[NW];
 #pragma unroll
         for (int w = 0; w < NW; ++w)
-          t[w] = reinterpret_cast<const f32x4*>(red_all + (size_t)(min(w, nws - 1) * nsl + sl) * (16 * 33 * 4))[(size_t)(s * ncw + c2) * 33 + jq];
+          t[w] = reinterpret_cast<const f32x4*>(red_all + (size_t)(min(w, nws - 1) * nsl + sl) * (16 * NJP * 4))[(size_t)(s * ncw + c2) * NJP + jq];
 #pragma unroll
         for (int w = 0; w < NW; ++w) a[w] += t[w];
       }
@@ -845,7 +874,7 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
         float o = -fz[h] - off * fw[h];
 #pragma unroll
         for (int w = 0; w < NW; ++w) o = fmaf(f[w][h], w < nws ? a[w][h] : 0.f, o);
-        part[(size_t)h * p.Rv + sl * ncw * 32 + c] = o;
+        part[(size_t)h * p.Rv + sl * ncw * CW + c] = o;
       }
     }
     if (tid == 0) {
@@ -858,7 +887,7 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
   }
   if (stamps && lane == 0) {           // timeline dump behind the workspace proper (tools/time_pvq.py allocates it)
     tstamp[4] = wall_clock64();
-    long long* dbg = reinterpret_cast<long long*>(p.ml + ((size_t)p.G * GS * p.nsplit + (size_t)p.G * GS) * 2) + ((size_t)blockIdx.x * NW + wv) * 5;
+    long long* dbg = reinterpret_cast<long long*>(p.ml + (size_t)p.G * GS * p.nsplit * 2) + ((size_t)blockIdx.x * NW + wv) * 5;
 #pragma unroll
     for (int t = 0; t < 5; ++t) dbg[t] = tstamp[t];
   }
@@ -1019,13 +1048,13 @@ int pv_nsplit_bound(int G, int Lcap, int Rv) {
 
 }  // namespace
 
-// split merge shared with the fused decode kernel (decode_fused.hip): ws = part [H][ns][Rv] | ml [H][ns][2] | stats [H][2]
+// split merge shared with the fused decode kernel (decode_fused.hip): ws = stats [H][2] (padded) | part [H][ns][Rv] | ml [H][ns][2]
 int palu_pv_combine_launch(float* ws, void* ctx, int H, int G, int Rv, int ns, hipStream_t s) {
   CombineParams c;
-  c.part = ws;
-  c.ml = ws + (size_t)H * ns * Rv;
+  c.part = ws + pv_ws_stats_floats(H);
+  c.ml = c.part + (size_t)H * ns * Rv;
   c.ctx = (h16*)ctx;
-  c.stats = ws + (size_t)H * ns * (Rv + 2);
+  c.stats = ws;
   c.G = G; c.gs = H / G; c.Rv = Rv; c.nsplit = ns;
   hipLaunchKernelGGL(pv_combine_kernel, dim3(H, (Rv + 63) / 64), dim3(64 * CB_WAVES), 0, s, c);
   PALU_LAUNCH_CHECK();
@@ -1043,12 +1072,114 @@ extern "C" size_t palu_pv_workspace_bytes(int H, int G, int L, int Rv) {
   // part [H][ns][Rv] + ml [H][ns][2] + stats [H][2], fp32, for the largest split count any L' <= L can produce
   // (this kernel's and the fused decode kernel's, which never exceeds CUs / G <= the split target)
   const int ns = pv_nsplit_bound(G, L, Rv);
-  return ((size_t)H * ns * (Rv + 2) + (size_t)H * 2) * sizeof(float);
+  return ((size_t)H * ns * (Rv + 2) + pv_ws_stats_floats(H)) * sizeof(float);
 }
 
 extern "C" size_t palu_pv_stats_offset(int H, int G, int L, int Rv) {
-  int ns = palu_pv_nsplit(G, L);
-  return (size_t)H * ns * (Rv + 2) * sizeof(float);
+  (void)H; (void)G; (void)L; (void)Rv;
+  return 0;     // the global (max, sum) pairs lead the workspace, whichever kernel and split count ran
+}
+
+
+// The register-direct matrix-core kernel for packed (bits = 3, 4) or plain fp16 (bits = 16) latent rows: gs in {1,2,4},
+// whole 32-code (8-column) chunks, dword (16-byte) aligned rows, a group's rows within 2 GiB, and a divisor whose fast
+// quotient is exact.  Returns PV_QR_NOT_TAKEN when the shape is left to the older kernels.
+constexpr int PV_QR_NOT_TAKEN = 1;
+static int pv_qr_launch(const void* scores, int64_t ss_h, const void* mask, const void* rows, int64_t sc_g, int64_t sc_l,
+                        const void* meta, int64_t sm_g, int64_t sm_l, void* ctx, void* probs, int64_t sp_h,
+                        void* workspace, int H, int G, int L, int Rv, int bits, float sqrt_d, hipStream_t s) {
+  static int qr_enabled = -1, qr16_enabled = -1;
+  if (qr_enabled < 0) {
+    const char* e = getenv("PALU_PVQ_DIRECT");
+    qr_enabled = e ? atoi(e) : 1;
+    // plain fp16 rows through the same kernel: correct (the fp16 parity tests pass with it) and 2 % faster back to back
+    // (76.1 vs 78.7 us at C2), but 2.5 us slower behind the score kernel inside the step (bench.py, same box:
+    // 182.6 vs 177.4 us per step) -- both kernels stream at the ~6.3 TB/s this part sustains, the VALU kernel's four
+    // small workgroups per CU ramp up and drain better.  Opt-in: PALU_PV_DIRECT=1.
+    const char* e16 = getenv("PALU_PV_DIRECT");
+    qr16_enabled = e16 ? atoi(e16) : 0;
+  }
+  const int gs = H / G;
+  const int cw = bits == 16 ? 8 : 32;
+  const long long row_bytes = (long long)Rv * bits / 8;
+  const long long span = (long long)(L - 1) * sc_l + row_bytes;
+  bool ok = (bits == 16 ? qr16_enabled : qr_enabled) && (gs == 1 || gs == 2 || gs == 4) && Rv % cw == 0 && Rv / cw <= 128 &&
+            span + 4096ll * sc_l < 0x7FFFFFFFll && ((uintptr_t)rows & 3) == 0 && sc_g % 4 == 0 && sc_l % 4 == 0 &&
+            (bits == 3 || (((uintptr_t)rows & 15) == 0 && sc_g % 16 == 0 && sc_l % 16 == 0)) && pv_exact_rcp(sqrt_d) != 0.f;
+  if (!ok) return PV_QR_NOT_TAKEN;
+  const int nch = Rv / cw;
+  int nsl = 1;
+  while (nsl * 16 < nch) nsl *= 2;                      // 1, 2, 4, 8 column slices of <= 16 chunks
+  const int ncw = (nch + nsl - 1) / nsl;
+  int S = 16 / ncw;
+  if (S > 2) S = 2;                                     // (a unit is at most one 64-row batch of statistics)
+  const int wgs = pv_qr_wgs();
+  // one round of 8-wave workgroups (256 VGPRs per wave: one workgroup per CU): CUs / G ranges per group, each cut
+  // into nws = 8 / slices wave ranges of whole units (32 S rows); the statistics are computed online, so a wave range
+  // may have any number of rows
+  const int RU = 32 * S, nws = 8 / nsl;
+  const long long P = ((long long)wgs * palu_num_cus() * nws + G - 1) / G;
+  long long rpw = (L + P - 1) / P;
+  rpw = (rpw + RU - 1) / RU * RU;
+  const int rps = (int)rpw * nws;
+  const int ns = (L + rps - 1) / rps;                   // ranges (one workgroup each) = splits seen by pv_combine
+  if (ns > pv_nsplit_bound(G, L, Rv)) return PV_QR_NOT_TAKEN;   // (cannot happen for a workspace sized by palu_pv_workspace_bytes)
+  float* ws = (float*)workspace;
+  PvQParams p;
+  p.scores = (const h16*)scores; p.ss_h = ss_h; p.mask = (const h16*)mask;
+  p.codes = (const unsigned char*)rows; p.sc_g = sc_g; p.sc_l = sc_l;
+  p.meta = (const h16*)meta; p.sm_g = sm_g; p.sm_l = sm_l;
+  p.part = ws + pv_ws_stats_floats(H);
+  p.ml = p.part + (size_t)H * ns * Rv;
+  float* stats = ws;
+  p.G = G; p.gs = gs; p.L = L; p.Rv = Rv; p.nsplit = ns; p.rps = rps;
+  p.inv_scale = sqrt_d;
+  {
+    static int ex = -1;
+    if (ex < 0) {
+      const char* e = getenv("PALU_PVQ_EXP");      // 8: every wave dumps 5 wall-clock stamps behind the workspace (tools/time_pvq.py)
+      ex = e ? atoi(e) : 0;
+    }
+    p.exp_flags = ex;
+  }
+  p.qr_nsl = nsl; p.qr_ncw = ncw; p.qr_s = S;
+  p.rcp_scale = pv_exact_rcp(sqrt_d);
+  const int njp = cw + 1;
+  size_t ldsr = (size_t)8 * 4 * (64 + 8) * sizeof(h16) + (size_t)8 * 16 * njp * 4 * sizeof(float) +
+                (size_t)8 * gs * 4 * sizeof(float);
+  ldsr = (ldsr + 15) / 16 * 16;
+  p.qr_park_off = (unsigned)ldsr;
+  ldsr += (size_t)8 * 3 * 64 * 4 * sizeof(float);
+  dim3 gridr(G * ns), blockr(512);
+#define PALU_PVQR2(GSV, BV)                                                                            \
+  {                                                                                                    \
+    if (S == 1) hipLaunchKernelGGL((pv_partial_qr_kernel<GSV, BV, 1>), gridr, blockr, ldsr, s, p);     \
+    else hipLaunchKernelGGL((pv_partial_qr_kernel<GSV, BV, 2>), gridr, blockr, ldsr, s, p);            \
+  }
+#define PALU_PVQR(GSV)                        \
+  {                                           \
+    if (bits == 16) PALU_PVQR2(GSV, 16)       \
+    else if (bits == 4) PALU_PVQR2(GSV, 4)    \
+    else PALU_PVQR2(GSV, 3)                   \
+  }
+  switch (gs) {
+    case 1: PALU_PVQR(1) break;
+    case 2: PALU_PVQR(2) break;
+    default: PALU_PVQR(4) break;
+  }
+#undef PALU_PVQR
+#undef PALU_PVQR2
+  PALU_LAUNCH_CHECK();
+  int rcq = palu_pv_combine_launch(ws, ctx, H, G, Rv, ns, s);
+  if (rcq) return rcq;
+  if (probs) {
+    int bx = (L + 255) / 256;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(probs_kernel, dim3(bx, H), dim3(256), 0, s, (const h16*)scores, ss_h, (const h16*)mask,
+                       (const float*)stats, (h16*)probs, sp_h, L, sqrt_d);
+    PALU_LAUNCH_CHECK();
+  }
+  return PALU_OK;
 }
 
 extern "C" int palu_softmax_pv_f16(const void* scores, int64_t ss_h, const void* mask, const void* v, int64_t sv_g,
@@ -1063,15 +1194,21 @@ extern "C" int palu_softmax_pv_f16(const void* scores, int64_t ss_h, const void*
   PALU_REQUIRE(((uintptr_t)v & 15) == 0 && sv_g % 8 == 0 && sv_l % 8 == 0 && sv_l >= Rv, PALU_ERR_ARG,
                "softmax_pv: v rows must be 16-byte aligned");
   hipStream_t s = (hipStream_t)stream;
+  // matrix-core streaming kernel first (pv_partial_qr_kernel with plain fp16 rows); the VALU kernel below takes gs = 8 etc.
+  {
+    const int rcq = pv_qr_launch(scores, ss_h, mask, v, sv_g * 2, sv_l * 2, nullptr, 0, 0, ctx, probs, sp_h, workspace, H, G, L,
+                                 Rv, 16, sqrt_d, s);
+    if (rcq != PV_QR_NOT_TAKEN) return rcq;
+  }
   const int rps = pv_rows_per_split(G, L);
   const int ns = (L + rps - 1) / rps;
   float* ws = (float*)workspace;
   PvParams p;
   p.scores = (const h16*)scores; p.ss_h = ss_h; p.mask = (const h16*)mask;
   p.v = (const h16*)v; p.sv_g = sv_g; p.sv_l = sv_l;
-  p.part = ws;
-  p.ml = ws + (size_t)H * ns * Rv;
-  float* stats = p.ml + (size_t)H * ns * 2;
+  p.part = ws + pv_ws_stats_floats(H);
+  p.ml = p.part + (size_t)H * ns * Rv;
+  float* stats = ws;
   p.G = G; p.gs = gs; p.L = L; p.Rv = Rv; p.nsplit = ns; p.rps = rps;
   p.inv_scale = sqrt_d;
   size_t lds = (size_t)gs * rps * sizeof(float);
@@ -1116,91 +1253,11 @@ extern "C" int palu_softmax_pv_q(const void* scores, int64_t ss_h, const void* m
                PALU_ERR_ARG, "softmax_pv_q: packed rows / meta must be 4-byte aligned");
   hipStream_t s = (hipStream_t)stream;
   int rps = pv_rows_per_split(G, L);
-  // register-direct kernel (pv_partial_qr_kernel): any gs in {1,2,4}, Rv a multiple of 32 up to 4096, offsets below 2^31
-  static int qr_enabled = -1;
-  if (qr_enabled < 0) {
-    const char* e = getenv("PALU_PVQ_DIRECT");
-    qr_enabled = e ? atoi(e) : 1;
-  }
-  const long long code_bytes = (long long)(L - 1) * sc_l + (long long)Rv * bits / 8;
-  bool qr = qr_enabled && code_bytes + 4096ll * sc_l < 0x7FFFFFFFll && (bits == 3 || sc_l % 4 == 0) &&
-            pv_exact_rcp(sqrt_d) != 0.f;
-  int nsl = 1, ncw = 0, S = 1, rps_qr = rps, ns_qr = 0;
-  if (qr) {
-    const int nch = Rv / 32;
-    while (nsl * 16 < nch) nsl *= 2;                      // 1, 2, 4, 8 column slices of <= 16 chunks
-    ncw = (nch + nsl - 1) / nsl;
-    S = 16 / ncw;
-    if (S > 2) S = 2;                                     // (a unit is at most one 64-row batch of statistics)
-    const int wgs = pv_qr_wgs();
-    // one round of 8-wave workgroups (256 VGPRs per wave: one workgroup per CU): CUs / G ranges per group, each cut
-    // into nws = 8 / slices wave ranges of whole units (32 S rows); the statistics are computed online, so a wave range
-    // may have any number of rows
-    const int RU = 32 * S, nws = 8 / nsl;
-    const long long P = ((long long)wgs * palu_num_cus() * nws + G - 1) / G;
-    long long rpw = (L + P - 1) / P;
-    rpw = (rpw + RU - 1) / RU * RU;
-    rps_qr = (int)rpw * nws;
-    ns_qr = (L + rps_qr - 1) / rps_qr;
-    if (ns_qr > pv_nsplit_bound(G, L, Rv)) qr = false;       // (cannot happen for a workspace sized by palu_pv_workspace_bytes)
-  }
-  if (qr) {
-    rps = rps_qr;
-    const int nws_q = 8 / nsl;
-    const int ns = ns_qr;                                  // ranges (one workgroup each) = splits seen by pv_combine
-    const int nwg = ns;
-    (void)nws_q;
-    float* ws = (float*)workspace;
-    PvQParams p;
-    p.scores = (const h16*)scores; p.ss_h = ss_h; p.mask = (const h16*)mask;
-    p.codes = (const unsigned char*)codes; p.sc_g = sc_g; p.sc_l = sc_l;
-    p.meta = (const h16*)meta; p.sm_g = sm_g; p.sm_l = sm_l;
-    p.part = ws;
-    p.ml = ws + (size_t)H * ns * Rv;
-    float* stats = p.ml + (size_t)H * ns * 2;
-    p.G = G; p.gs = gs; p.L = L; p.Rv = Rv; p.nsplit = ns; p.rps = rps;
-    p.inv_scale = sqrt_d;
-    {
-      static int ex = -1;
-      if (ex < 0) {
-        const char* e = getenv("PALU_PVQ_EXP");      // 8: every wave dumps 5 wall-clock stamps behind the workspace (tools/time_pvq.py)
-        ex = e ? atoi(e) : 0;
-      }
-      p.exp_flags = ex;
-    }
-    p.qr_nsl = nsl; p.qr_ncw = ncw; p.qr_s = S;
-    p.rcp_scale = pv_exact_rcp(sqrt_d);
-    size_t ldsr = (size_t)8 * 4 * (64 + 8) * sizeof(h16) + (size_t)8 * 16 * 33 * 4 * sizeof(float) +
-                  (size_t)8 * gs * 4 * sizeof(float);
-    ldsr = (ldsr + 15) / 16 * 16;
-    p.qr_park_off = (unsigned)ldsr;
-    ldsr += (size_t)8 * 3 * 64 * 4 * sizeof(float);
-    dim3 gridr(G * nwg), blockr(512);
-#define PALU_PVQR(GSV)                                                                                       \
-  if (bits == 4) {                                                                                           \
-    if (S == 1) hipLaunchKernelGGL((pv_partial_qr_kernel<GSV, 4, 1>), gridr, blockr, ldsr, s, p);            \
-    else hipLaunchKernelGGL((pv_partial_qr_kernel<GSV, 4, 2>), gridr, blockr, ldsr, s, p);                   \
-  } else {                                                                                                   \
-    if (S == 1) hipLaunchKernelGGL((pv_partial_qr_kernel<GSV, 3, 1>), gridr, blockr, ldsr, s, p);            \
-    else hipLaunchKernelGGL((pv_partial_qr_kernel<GSV, 3, 2>), gridr, blockr, ldsr, s, p);                   \
-  }
-    switch (gs) {
-      case 1: PALU_PVQR(1) break;
-      case 2: PALU_PVQR(2) break;
-      default: PALU_PVQR(4) break;
-    }
-#undef PALU_PVQR
-    PALU_LAUNCH_CHECK();
-    int rcq = palu_pv_combine_launch(ws, ctx, H, G, Rv, ns, s);
-    if (rcq) return rcq;
-    if (probs) {
-      int bx = (L + 255) / 256;
-      if (bx > 64) bx = 64;
-      hipLaunchKernelGGL(probs_kernel, dim3(bx, H), dim3(256), 0, s, (const h16*)scores, ss_h, (const h16*)mask,
-                         (const float*)stats, (h16*)probs, sp_h, L, sqrt_d);
-      PALU_LAUNCH_CHECK();
-    }
-    return PALU_OK;
+  // register-direct matrix-core kernel first (pv_partial_qr_kernel); the VALU kernel below takes what it does not
+  {
+    const int rcq = pv_qr_launch(scores, ss_h, mask, codes, sc_g, sc_l, meta, sm_g, sm_l, ctx, probs, sp_h, workspace, H, G, L,
+                                 Rv, bits, sqrt_d, s);
+    if (rcq != PV_QR_NOT_TAKEN) return rcq;
   }
   const int ns = (L + rps - 1) / rps;
   float* ws = (float*)workspace;
@@ -1208,9 +1265,9 @@ extern "C" int palu_softmax_pv_q(const void* scores, int64_t ss_h, const void* m
   p.scores = (const h16*)scores; p.ss_h = ss_h; p.mask = (const h16*)mask;
   p.codes = (const unsigned char*)codes; p.sc_g = sc_g; p.sc_l = sc_l;
   p.meta = (const h16*)meta; p.sm_g = sm_g; p.sm_l = sm_l;
-  p.part = ws;
-  p.ml = ws + (size_t)H * ns * Rv;
-  float* stats = p.ml + (size_t)H * ns * 2;
+  p.part = ws + pv_ws_stats_floats(H);
+  p.ml = p.part + (size_t)H * ns * Rv;
+  float* stats = ws;
   p.G = G; p.gs = gs; p.L = L; p.Rv = Rv; p.nsplit = ns; p.rps = rps;
   p.inv_scale = sqrt_d;
   p.exp_flags = 0;

@@ -53,3 +53,8 @@ static __device__ __forceinline__ float wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// split workspace of the P.V kernels (decode_pv.hip, decode_fused.hip):  stats [H][2] (padded) | part [H][ns][Rv] | ml [H][ns][2]
+// -- the (max, sum) pairs the probs kernel and the callers read sit at offset 0 whatever split count a kernel chose
+static inline size_t pv_ws_stats_floats(int H) { return ((size_t)2 * H + 63) / 64 * 64; }
+
