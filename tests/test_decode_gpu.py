@@ -438,3 +438,18 @@ def test_whole_llama_model_decodes_through_latent_caches():
         o = small(ids, past_key_values=qc, use_cache=True)
         o2 = small(tok, past_key_values=qc, use_cache=True)
     assert qc.get_seq_length() == 38 and torch.isfinite(o2.logits).all() and o.logits.shape == (1, 37, 128)
+
+
+def test_softmax_pv_fp16_rows_through_the_register_direct_kernel():
+    """PALU_PV_DIRECT=1 routes plain fp16 latent rows through pv_partial_qr_kernel<..., 16, ...> (opt-in: DESIGN 4.4).
+    The switch is read once per process, so the parametrised cases of test_softmax_pv are re-run in a child process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, PALU_PV_DIRECT="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_decode_gpu.py"), "-q", "-x", "-m", "gpu",
+                        "-k", "test_softmax_pv and not register_direct and not full_size and not config5"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout
