@@ -196,3 +196,43 @@ def test_quantised_kernels_full_size(bits, R, Rv, L):
                                           H, G, L, Rv, bits, math.sqrt(128.0), _lib.current_stream()), "pv_q")
     ref_ctx, _ = softmax_pv(scores, vdeq)
     torch.testing.assert_close(ctx, ref_ctx, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("bits,Rv,gs,H,L,masked", [
+    (3, 64, 2, 4, 1, False), (4, 128, 4, 8, 33, False), (3, 512, 4, 4, 700, True), (4, 1024, 1, 2, 300, False),
+    (3, 2048, 4, 4, 200, True), (4, 96, 2, 8, 5000, True), (3, 384, 4, 32, 4097, True), (4, 4096, 1, 1, 65, False)])
+def test_softmax_pv_q_shapes_and_masks(bits, Rv, gs, H, L, masked):
+    """The register-direct kernel's geometry cases: one / two row sets per unit, 1-8 column slices (R_v up to 4096), ranges
+    shorter than a unit, an additive mask that blanks whole 64-row batches (a wave's running maximum stays -inf for a
+    while) -- against the fp16 HIP kernel on the dequantised latents and the fp64 softmax."""
+    from palu_amd import _lib
+    from palu_amd.kernel import quant as q
+    rng = np.random.default_rng(bits * 1000 + Rv + L)
+    G = H // gs
+    scores = torch.from_numpy((rng.standard_normal((H, L)) * 15).astype(np.float16)).to(DEV)
+    v = torch.from_numpy((rng.standard_normal((G, L, Rv)) * rng.uniform(0.2, 3, (G, L, 1))).astype(np.float16)).to(DEV)
+    codes, meta, deq = q.quantize_pack(v, bits, want_dequant=True)
+    mask = None
+    if masked:
+        m = np.zeros(L, dtype=np.float16)
+        m[: min(L // 2, 200)] = np.float16(-65504.0)                # whole leading batches masked out
+        m[rng.random(L) < 0.2] = np.float16(-65504.0)
+        m[L - 1] = 0
+        mask = torch.from_numpy(m).to(DEV)
+    ws = torch.empty(_lib.lib.palu_pv_workspace_bytes(H, G, L, Rv), dtype=torch.uint8, device=DEV)
+    ctx = torch.empty(H, Rv, dtype=torch.float16, device=DEV)
+    _lib.check(_lib.lib.palu_softmax_pv_q(scores.data_ptr(), scores.stride(0), 0 if mask is None else mask.data_ptr(),
+                                          codes.data_ptr(), codes.stride(0), codes.stride(1), meta.data_ptr(), meta.stride(0),
+                                          meta.stride(1), ctx.data_ptr(), 0, 0, ws.data_ptr(), H, G, L, Rv, bits,
+                                          math.sqrt(128.0), _lib.current_stream()), "pv_q")
+    x = scores.cpu().float() / math.sqrt(128.0)
+    x = x.half()
+    if mask is not None:
+        x = (x.float() + mask.cpu().float().reshape(1, L)).half()
+    p64 = torch.softmax(x.double(), dim=-1)
+    c64 = torch.matmul(p64.reshape(G, gs, L), deq.cpu().double()).reshape(H, Rv)
+    assert torch.isfinite(ctx).all()
+    assert (ctx.cpu().double() - c64).abs().max().item() <= 1.5e-3 * max(1.0, c64.abs().max().item())
+    if gs in (1, 2, 4, 8) and Rv <= 2048:
+        ref_ctx = softmax_pv(scores, deq, mask)[0]
+        torch.testing.assert_close(ctx, ref_ctx, rtol=2e-3, atol=2e-3)
