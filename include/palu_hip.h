@@ -163,6 +163,17 @@ int palu_decode_step_f16(const void* hidden,
                          const void* mask, const float* inv_freq, void* out, void* probs, int64_t sp_h,
                          void* workspace, int Lcap, int H, int G, int D, int hidden_size, int Rk, int Rv,
                          int cache_len, int pos, palu_stream_t stream);
+
+/* The same step for checkpoints whose heads share B inside a latent group (true GQA; the reference's
+ * svd_mistral modules, palu/model/svd_mistral/modeling_palu_mistral.py:37-59): bfrag = fragments of the [G, R, D]
+ * shared factor, palu_abx_prepare_b(b_g, H := G, G); scores by palu_abx_rope_shared_f16.  Same arguments otherwise. */
+int palu_decode_step_sharedb_f16(const void* hidden,
+                         const void* wq, int64_t ldq, const void* vtk, int64_t ldk, const void* vtv, int64_t ldv,
+                         const void* bfrag, const void* wo, int64_t ldo,
+                         void* k_cache, int64_t sk_g, int64_t sk_l, void* v_cache, int64_t sv_g, int64_t sv_l,
+                         const void* mask, const float* inv_freq, void* out, void* probs, int64_t sp_h,
+                         void* workspace, int Lcap, int H, int G, int D, int hidden_size, int Rk, int Rv,
+                         int cache_len, int pos, palu_stream_t stream);
 /* The same step WITHOUT the final o_proj: what one rank of the head-group sharding runs on the heads it owns
  * (H, G = local counts); ctx [H, Rv] fp16 is the slice it contributes to the all-gather.
  * Workspace as palu_decode_step_f16. */

@@ -78,6 +78,8 @@ SIGNATURES = {
                                      i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "palu_decode_step_f16": (i32, [vp, vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64, i64, vp, i64, i64,
                                    vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "palu_decode_step_sharedb_f16": (i32, [vp, vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64, i64, vp, i64, i64,
+                                           vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
 }
 
 for _name, (_res, _args) in SIGNATURES.items():

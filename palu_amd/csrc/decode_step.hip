@@ -30,12 +30,12 @@ extern "C" size_t palu_decode_workspace_bytes(int H, int G, int D, int Lcap, int
   return step_layout(H, G, D, Lcap, Rv).total;
 }
 
-extern "C" int palu_decode_step_f16(const void* hidden, const void* wq, int64_t ldq, const void* vtk, int64_t ldk,
-                                    const void* vtv, int64_t ldv, const void* bfrag, const void* wo, int64_t ldo,
-                                    void* k_cache, int64_t sk_g, int64_t sk_l, void* v_cache, int64_t sv_g,
-                                    int64_t sv_l, const void* mask, const float* inv_freq, void* out, void* probs,
-                                    int64_t sp_h, void* workspace, int Lcap, int H, int G, int D, int hidden_size,
-                                    int Rk, int Rv, int cache_len, int pos, palu_stream_t stream) {
+static int decode_step_impl(bool shared_b, const void* hidden, const void* wq, int64_t ldq, const void* vtk, int64_t ldk,
+                            const void* vtv, int64_t ldv, const void* bfrag, const void* wo, int64_t ldo,
+                            void* k_cache, int64_t sk_g, int64_t sk_l, void* v_cache, int64_t sv_g,
+                            int64_t sv_l, const void* mask, const float* inv_freq, void* out, void* probs,
+                            int64_t sp_h, void* workspace, int Lcap, int H, int G, int D, int hidden_size,
+                            int Rk, int Rv, int cache_len, int pos, palu_stream_t stream) {
   PALU_REQUIRE(workspace && Lcap > cache_len && cache_len >= 0, PALU_ERR_ARG,
                "decode_step: cache_len %d must be < workspace capacity %d", cache_len, Lcap);
   const StepWs w = step_layout(H, G, D, Lcap, Rv);
@@ -49,17 +49,42 @@ extern "C" int palu_decode_step_f16(const void* hidden, const void* wq, int64_t 
   int rc = palu_decode_qkv_f16(wq, ldq, vtk, ldk, vtv, ldv, hidden, q, k_cache, sk_g, sk_l, v_cache, sv_g, sv_l,
                                inv_freq, H, D, hidden_size, G, Rk, Rv, pos, cache_len, stream);
   if (rc) return rc;
-  if (!mask && !probs && palu_decode_attn_preferred(H, G, L, Rk, Rv, D)) {
+  if (!shared_b && !mask && !probs && palu_decode_attn_preferred(H, G, L, Rk, Rv, D)) {
     rc = palu_decode_attn_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, v_cache, sv_g, sv_l, ctx, pvws, H, G, L, Rk, Rv, D,
                               inv_freq, 0, sqrtf((float)D), stream);
   } else {
-    rc = palu_abx_rope_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, scores, ss_h, H, G, L, Rk, D, inv_freq, 0, stream);
+    rc = shared_b ? palu_abx_rope_shared_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, scores, ss_h, H, G, L, Rk, D, inv_freq, 0, stream)
+                  : palu_abx_rope_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, scores, ss_h, H, G, L, Rk, D, inv_freq, 0, stream);
     if (rc) return rc;
     rc = palu_softmax_pv_f16(scores, ss_h, mask, v_cache, sv_g, sv_l, ctx, probs, sp_h, pvws, H, G, L, Rv,
                              sqrtf((float)D), stream);
   }
   if (rc) return rc;
   return palu_gemv_f16(wo, ldo, ctx, out, hidden_size, H * Rv, stream);
+}
+
+extern "C" int palu_decode_step_f16(const void* hidden, const void* wq, int64_t ldq, const void* vtk, int64_t ldk,
+                                    const void* vtv, int64_t ldv, const void* bfrag, const void* wo, int64_t ldo,
+                                    void* k_cache, int64_t sk_g, int64_t sk_l, void* v_cache, int64_t sv_g,
+                                    int64_t sv_l, const void* mask, const float* inv_freq, void* out, void* probs,
+                                    int64_t sp_h, void* workspace, int Lcap, int H, int G, int D, int hidden_size,
+                                    int Rk, int Rv, int cache_len, int pos, palu_stream_t stream) {
+  return decode_step_impl(false, hidden, wq, ldq, vtk, ldk, vtv, ldv, bfrag, wo, ldo, k_cache, sk_g, sk_l, v_cache, sv_g, sv_l,
+                          mask, inv_freq, out, probs, sp_h, workspace, Lcap, H, G, D, hidden_size, Rk, Rv, cache_len, pos, stream);
+}
+
+// The same step for weights whose heads share B inside a latent group (true GQA): `bfrag` are the
+// fragments of the [G, R, D] shared factor (palu_abx_prepare_b(b_g, H := G, G)) and the scores come from
+// palu_abx_rope_shared_f16 (keys reconstructed once per group).
+extern "C" int palu_decode_step_sharedb_f16(const void* hidden, const void* wq, int64_t ldq, const void* vtk, int64_t ldk,
+                                            const void* vtv, int64_t ldv, const void* bfrag_shared, const void* wo,
+                                            int64_t ldo, void* k_cache, int64_t sk_g, int64_t sk_l, void* v_cache,
+                                            int64_t sv_g, int64_t sv_l, const void* mask, const float* inv_freq, void* out,
+                                            void* probs, int64_t sp_h, void* workspace, int Lcap, int H, int G, int D,
+                                            int hidden_size, int Rk, int Rv, int cache_len, int pos, palu_stream_t stream) {
+  return decode_step_impl(true, hidden, wq, ldq, vtk, ldk, vtv, ldv, bfrag_shared, wo, ldo, k_cache, sk_g, sk_l, v_cache, sv_g,
+                          sv_l, mask, inv_freq, out, probs, sp_h, workspace, Lcap, H, G, D, hidden_size, Rk, Rv, cache_len, pos,
+                          stream);
 }
 
 // The step without its last GEMV: everything that is local to a head-group shard; the caller

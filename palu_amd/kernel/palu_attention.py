@@ -28,7 +28,7 @@ from torch import nn
 
 from .. import _lib
 from .abx_rope import abx as recompute_k_gemv  # same alias as kernel/palu_attention.py:13
-from .abx_rope import invalidate_b, prepare_b, rope_inv_freq
+from .abx_rope import invalidate_b, prepare_b, rope_inv_freq, shared_b
 
 __all__ = ["HeadwiseLowRankModule", "LlamaPaluAttention", "LatentCache", "QuantLatentCache", "DynamicCache",
            "build_b", "fuse_wo"]
@@ -443,7 +443,9 @@ class LlamaPaluAttention(nn.Module):
         kbuf, vbuf = cache.buffers(li)
         cap = kbuf.shape[2]
         ws = self._workspace(dev, cap + 8)
-        frag = prepare_b(self.k_proj.B, G)
+        # heads that share B inside a group (true GQA) take the shared-B score kernel (keys reconstructed once per group)
+        bg = shared_b(self.k_proj.B, G)
+        frag = prepare_b(self.k_proj.B if bg is None else bg, G)
         inv = rope_inv_freq(dev, D, self.rope_theta)
         out = torch.empty((1, 1, self.hidden_size), dtype=hidden_states.dtype, device=dev)
         probs = torch.empty((1, H, 1, n + 1), dtype=hidden_states.dtype, device=dev) if output_attentions else None
@@ -459,10 +461,11 @@ class LlamaPaluAttention(nn.Module):
             # through the dispatcher (torch.ops.palu.decode_step, palu_amd/ops.py): torch.compile / export see one node
             from .. import ops as _ops  # noqa: F401  (registers the ops on first use)
             o = torch.ops.palu.decode_step(x, wq, vtk, vtv, frag, wo, kbuf[0], vbuf[0], inv, ws, self._ws_cap, H, n, int(pos),
-                                           attention_mask)
+                                           attention_mask, bg is not None)
             cache.advance(li, 1)
             return o.view(1, 1, self.hidden_size), None
-        _lib.check(_lib.lib.palu_decode_step_f16(
+        step_fn = _lib.lib.palu_decode_step_f16 if bg is None else _lib.lib.palu_decode_step_sharedb_f16
+        _lib.check(step_fn(
             x.data_ptr(), wq.data_ptr(), wq.stride(0), vtk.data_ptr(), vtk.stride(0), vtv.data_ptr(), vtv.stride(0),
             frag.data_ptr(), wo.data_ptr(), wo.stride(0),
             kbuf.data_ptr(), kbuf.stride(1), kbuf.stride(2), vbuf.data_ptr(), vbuf.stride(1), vbuf.stride(2),

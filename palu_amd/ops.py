@@ -164,10 +164,11 @@ def _(q, k, v_lat, past=0, causal=True, scale=1.0 / math.sqrt(128.0)):
 def decode_step(hidden: torch.Tensor, wq: torch.Tensor, vt_k: torch.Tensor, vt_v: torch.Tensor, bfrag: torch.Tensor,
                 wo: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, inv_freq: torch.Tensor,
                 workspace: torch.Tensor, ws_capacity: int, num_heads: int, cache_len: int, pos: int,
-                mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+                mask: Optional[torch.Tensor] = None, shared_b: bool = False) -> torch.Tensor:
     """One decode token on an fp16 latent cache (palu_decode_step_f16; kernel/palu_attention.py:207-257).
     hidden [hidden_size]; k_cache [G, cap, Rk] / v_cache [G, cap, Rv] hold cache_len rows and receive row cache_len;
-    bfrag from palu_abx_prepare_b; workspace of palu_decode_workspace_bytes(H, G, D, ws_capacity, Rv) bytes."""
+    bfrag from palu_abx_prepare_b; workspace of palu_decode_workspace_bytes(H, G, D, ws_capacity, Rv) bytes.
+    shared_b: bfrag holds the fragments of the [G, R, D] factor all heads of a group share (palu_decode_step_sharedb_f16)."""
     G, cap, Rk = k_cache.shape
     Rv = v_cache.shape[2]
     hidden_size = wq.shape[1]
@@ -175,8 +176,9 @@ def decode_step(hidden: torch.Tensor, wq: torch.Tensor, vt_k: torch.Tensor, vt_v
     x = hidden.reshape(-1).contiguous()
     out = torch.empty(hidden_size, dtype=torch.float16, device=hidden.device)
     m = None if mask is None else mask.reshape(-1).to(torch.float16).contiguous()
+    fn = _lib.lib.palu_decode_step_sharedb_f16 if shared_b else _lib.lib.palu_decode_step_f16
     with _lib.on_device(hidden):
-        _lib.check(_lib.lib.palu_decode_step_f16(
+        _lib.check(fn(
             x.data_ptr(), wq.data_ptr(), wq.stride(0), vt_k.data_ptr(), vt_k.stride(0), vt_v.data_ptr(), vt_v.stride(0),
             bfrag.data_ptr(), wo.data_ptr(), wo.stride(0),
             k_cache.data_ptr(), k_cache.stride(0), k_cache.stride(1), v_cache.data_ptr(), v_cache.stride(0), v_cache.stride(1),
@@ -188,7 +190,7 @@ def decode_step(hidden: torch.Tensor, wq: torch.Tensor, vt_k: torch.Tensor, vt_v
 
 @decode_step.register_fake
 def _(hidden, wq, vt_k, vt_v, bfrag, wo, k_cache, v_cache, inv_freq, workspace, ws_capacity, num_heads, cache_len, pos,
-      mask=None):
+      mask=None, shared_b=False):
     return hidden.new_empty((wq.shape[1],))
 
 

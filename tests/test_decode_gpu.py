@@ -453,3 +453,48 @@ def test_softmax_pv_fp16_rows_through_the_register_direct_kernel():
                        env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "passed" in r.stdout
+
+
+@pytest.mark.parametrize("with_probs", [False, True])
+def test_decode_step_with_shared_b_goes_through_the_shared_kernel(with_probs):
+    """True-GQA weights (every head of a group has the same U_k block): the module's one-call decode step
+    detects the tied B, hands the [G, R, D] fragments to palu_decode_step_sharedb_f16 (scores by the shared-B kernel) and
+    still equals the oracle's step on the expanded per-head weights."""
+    from palu_amd.kernel.abx_rope import shared_b
+    from palu_amd.kernel.palu_attention import LatentCache
+    hidden, H, D, gs, rank_k, rank_v, L = 4096, 32, 128, 4, 1024, 3072, 777
+    w, k_lat, v_lat, tok, _ = gi.step_inputs(77, hidden, H, D, gs, rank_k, rank_v, L, False)
+    # tie the heads of each group: U_k block of head 0 of the group for all its heads
+    u_tied = []
+    for u in w["u_k"]:                                              # u: [gs * D, R] per group
+        blk = u[:D].clone()
+        u_tied.append(blk.repeat(gs, 1))
+    w = dict(w, u_k=u_tied)
+    m = _module_from_palu_weights(hidden, H, D, gs, rank_k, rank_v, w)
+    assert shared_b(m.k_proj.B, H // gs) is not None
+    cache = LatentCache()
+    cache.update(k_lat.unsqueeze(0).to(DEV), v_lat.unsqueeze(0).to(DEV), 0)
+    seen = []
+    if not with_probs:
+        from torch.utils._python_dispatch import TorchDispatchMode
+
+        class Spy(TorchDispatchMode):
+            def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+                if "palu.decode_step" in str(func):
+                    seen.append(args[-1] if args else None)
+                return func(*args, **(kwargs or {}))
+        ctxm = Spy()
+    else:
+        import contextlib
+        ctxm = contextlib.nullcontext()
+    with torch.no_grad(), ctxm:
+        out, probs, _ = m(tok.reshape(1, 1, hidden).to(DEV), position_ids=torch.arange(L, L + 1), past_key_value=cache,
+                          output_attentions=with_probs)
+    if not with_probs:
+        assert seen == [True], seen                                  # the op was called with shared_b=True
+    wd = {"wq": w["wq"].half(), "vt_k": w["vt_k"].half(), "vt_v": w["vt_v"].half(),
+          "b": oracle.build_b_from_u(w["u_k"], gs, D).half(), "wo": w["wo"].half()}
+    ref_out, ref_p, _, _ = oracle.decode_step(tok, L, wd, k_lat, v_lat)
+    torch.testing.assert_close(out.cpu().reshape(-1), ref_out, rtol=1e-3, atol=1e-3)
+    if with_probs:
+        torch.testing.assert_close(probs.cpu().reshape(H, L + 1), ref_p, rtol=1e-3, atol=1e-3)
