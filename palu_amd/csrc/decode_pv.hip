@@ -242,6 +242,7 @@ struct PvQParams {
   int exp_flags;   // PALU_PVQ_EXP = 8: timeline dump of pv_partial_qr_kernel (tools/time_pvq.py)
   int qr_nsl, qr_ncw, qr_s;   // register-direct kernel: column slices, chunks per slice, row sets per unit
   unsigned qr_park_off;       // LDS offset of the parked per-lane partial sums [8 waves][3][64 lanes] f32x4
+  int qr_prio;                // 1: waves 4-7 run the unit loop at raised priority
   float rcp_scale;            // 1 / inv_scale when the 3-instruction quotient is exact for every fp16 score (else 0)
 };
 
@@ -779,7 +780,15 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
   if (stamps) tstamp[1] = wall_clock64();
   // unit u of the range sits in register set u % NSET (the loop is unrolled by NSET: the set index is a compile-time
   // constant); a batch of statistics precedes the first of its UB units
+  // the second-dispatched wave of every SIMD loses issue arbitration to the older one (measured: waves 0-3 left this loop
+  // at 11 us, waves 4-7 at 17.5 us).  Static priority for the younger half (PALU_PVQ_PRIO=1, default) is worth 3 %
+  // (28.6 vs 29.5 us at C3, same box); taking turns per iteration (=2) is worth nothing.
+  if (p.qr_prio == 1 && wv >= NW / 2) __builtin_amdgcn_s_setprio(1);
   for (int base = 0; base < nunit; base += NSET) {
+    if (p.qr_prio == 2) {                       // the two waves of a SIMD take turns
+      if (((base / NSET) + (wv >= NW / 2 ? 1 : 0)) & 1) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+    }
 #pragma unroll
     for (int s = 0; s < NSET; ++s) {
       const int u = base + s;
@@ -790,6 +799,7 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
       load_unit(raw[s], u + NSET);
     }
   }
+  if (p.qr_prio) __builtin_amdgcn_s_setprio(0);
   if (stamps) tstamp[2] = wall_clock64();
   float mloc[GS], sloc[GS], cz[GS], cw[GS];
   {
@@ -1144,6 +1154,14 @@ static int pv_qr_launch(const void* scores, int64_t ss_h, const void* mask, cons
   }
   p.qr_nsl = nsl; p.qr_ncw = ncw; p.qr_s = S;
   p.rcp_scale = pv_exact_rcp(sqrt_d);
+  {
+    static int prio = -1;
+    if (prio < 0) {
+      const char* e = getenv("PALU_PVQ_PRIO");
+      prio = e ? atoi(e) : 1;
+    }
+    p.qr_prio = prio;
+  }
   const int njp = cw + 1;
   size_t ldsr = (size_t)8 * 4 * (64 + 8) * sizeof(h16) + (size_t)8 * 16 * njp * 4 * sizeof(float) +
                 (size_t)8 * gs * 4 * sizeof(float);
