@@ -478,11 +478,7 @@ struct QrDecode {
   }
 };
 
-// (a & mask) | magic in ONE instruction: gfx9 VOP3 takes no literals and one scalar operand, and with literal operands
-// hipcc selects v_and_b32 + v_or_b32 (twice the VALU work).  The masks are therefore handed to the compiler as opaque
-// SGPR values and the magics as opaque VGPR values: the plain C expression then selects v_and_or_b32 v, v, s, v.
-// (Writing the instruction as inline asm is NOT an option: the hazard recogniser does not see an asm as a VALU write and
-//  leaves out the wait states an MFMA reading the result needs -- measured: sporadic NaNs in one code column.)
+// wave-wide maximum / sum by DPP (no LDS): quad permutes, row mirrors, row broadcasts; lane 63 ends up with the result
 static __device__ __forceinline__ float wave_max_dpp(float v) {
 #define PALU_DPP_MAX(CTRL, ROWMASK)                                                                                    \
   v = fmaxf(v, __uint_as_float((unsigned)__builtin_amdgcn_update_dpp((int)__float_as_uint(v), (int)__float_as_uint(v), \
@@ -508,6 +504,11 @@ static __device__ __forceinline__ float wave_sum_dpp(float v) {
 #undef PALU_DPP_ADD
   return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), 63));
 }
+// (a & mask) | magic in ONE instruction: gfx9 VOP3 takes no literals and one scalar operand, and with literal operands
+// hipcc selects v_and_b32 + v_or_b32 (twice the VALU work).  The masks are therefore handed to the compiler as opaque
+// SGPR values and the magics as opaque VGPR values: the plain C expression then selects v_and_or_b32 v, v, s, v.
+// (Writing the instruction as inline asm is NOT an option: the hazard recogniser does not see an asm as a VALU write and
+//  leaves out the wait states an MFMA reading the result needs -- measured: sporadic NaNs in one code column.)
 static __device__ __forceinline__ unsigned and_or(unsigned a, unsigned mask_sgpr, unsigned magic_vgpr) {
   return (a & mask_sgpr) | magic_vgpr;
 }
@@ -913,7 +914,7 @@ struct CombineParams {
 
 // grid (H, ceil(Rv/64)), 512 threads: the 8 waves share the splits of one head for 64 context columns
 // (8 independent loads in flight per lane: the merge is latency-, not bandwidth-bound), LDS sum at the end.
-constexpr int CB_WAVES = 16;
+constexpr int CB_WAVES = 8;
 __global__ __launch_bounds__(64 * CB_WAVES) void pv_combine_kernel(CombineParams p) {
   __shared__ float red[CB_WAVES][64];
   __shared__ float redt[CB_WAVES];
@@ -922,16 +923,14 @@ __global__ __launch_bounds__(64 * CB_WAVES) void pv_combine_kernel(CombineParams
   const int r = blockIdx.y * 64 + lane;
   const float* ml = p.ml + ((size_t)g * p.nsplit * p.gs + hh) * 2;
   const size_t ml_stride = (size_t)p.gs * 2;
-  // global max over the splits (every wave computes it: nsplit is small)
-  float M = -INFINITY;
-  for (int s = lane; s < p.nsplit; s += 64) M = fmaxf(M, ml[s * ml_stride]);
-  M = wave_max(M);
   const float* part = p.part + ((size_t)g * p.nsplit * p.gs + hh) * p.Rv + min(r, p.Rv - 1);
   const size_t pstride = (size_t)p.gs * p.Rv;
   float acc = 0.f, tot = 0.f;
-  constexpr int UN = 8;
-  for (int s0 = wv * UN; s0 < p.nsplit; s0 += CB_WAVES * UN) {
-    float m[UN], sm[UN], pv[UN];
+  constexpr int UN = 16;
+  // first batch of this wave's splits is requested BEFORE the global maximum is reduced: the partial rows do not depend
+  // on it, and the merge is one memory round trip instead of two (it is latency-bound: 4.7 us for ~1.5 MB)
+  float m[UN], sm[UN], pv[UN];
+  auto load_batch = [&](int s0) {
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const int s = min(s0 + u, p.nsplit - 1);
@@ -939,6 +938,14 @@ __global__ __launch_bounds__(64 * CB_WAVES) void pv_combine_kernel(CombineParams
       sm[u] = ml[s * ml_stride + 1];
       pv[u] = part[s * pstride];
     }
+  };
+  load_batch(wv * UN);
+  // global max over the splits (every wave computes it: nsplit is small)
+  float M = -INFINITY;
+  for (int s = lane; s < p.nsplit; s += 64) M = fmaxf(M, ml[s * ml_stride]);
+  M = wave_max(M);
+  for (int s0 = wv * UN; s0 < p.nsplit; s0 += CB_WAVES * UN) {
+    if (s0 != wv * UN) load_batch(s0);
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const float wgt = (s0 + u < p.nsplit && m[u] != -INFINITY) ? __expf(m[u] - M) : 0.f;
