@@ -535,7 +535,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
   }
   stamp();  // 2: rope init done
   // ---- query: either folded into the fragments (FOLD) or kept per (pair, head) for the epilogue
-  float q1[FOLD ? 1 : HPW][4], q2[FOLD ? 1 : HPW][4];
+  float q1[(FOLD || SHARED) ? 1 : HPW][4], q2[(FOLD || SHARED) ? 1 : HPW][4];
   if (FOLD) {
     // A-fragment lane = row m of the M-block: t = m&1, u = (m>>1)&1, pair = m>>2.
     //   row u=0 (B[:,i])    <- P = q_i B[:,i] + q_{i+64} B[:,i+64]
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
         bf[mb][ks] = __builtin_bit_cast(h16x8, res);
       }
     }
-  } else {
+  } else if (!SHARED) {
 #pragma unroll
     for (int s = 0; s < HPW; ++s) {
       int hloc = hb * HPW + s;
@@ -589,6 +589,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
         q1[s][j] = valid ? v1 : 0.f;
         q2[s][j] = valid ? v2 : 0.f;
       }
+    }
+  }
+  // SHARED: the q-dot runs on the matrix cores too.  After the rotation a lane (position n, half hi) holds the 8 rotated
+  // key components of ITS 4 pairs -- as fp16 exactly one B operand of v_mfma_f32_32x32x16_f16 (k-slot order is ours to
+  // choose: slot 2j = component i_j, slot 2j+1 = component i_j + 64, i_j = 8w + 2j + hi).  The A operand carries q:
+  // lane (m, hi) = head m of the block, the same 8 components; rows beyond the block's heads are zero.  One MFMA per
+  // 32-position block replaces 8 of the 20 VALU operations per (position, pair).
+  h16x8 qa;
+  if (SHARED) {
+    const int hloc = hb * HPW + n;                       // A row m = lane & 31
+    const bool valid = n < HPW && hloc < p.gs;
+    const int h = g * p.gs + (valid ? hloc : 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = 8 * w + 2 * j + hi;
+      qa[2 * j] = valid ? p.a[h * p.sa_h + i * p.sa_d] : (h16)0.f;
+      qa[2 * j + 1] = valid ? p.a[h * p.sa_h + (i + 64) * p.sa_d] : (h16)0.f;
     }
   }
 
@@ -662,6 +679,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
 #pragma unroll
     for (int s = 0; s < HPW; ++s) part[s] = 0.f;
     float cc = 0.f, ss = 0.f, kr1 = 0.f, kr2 = 0.f;
+    h16x8 krb;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) krb[e] = (h16)0.f;
     auto chunk = [&](int c) {
       const int j = c / CPP, t = c % CPP;
       if (t == 0) {
@@ -688,18 +708,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
       } else if (t <= NMB) {
         const int mb = t - 1;
         if (SHARED) {
-          // one reconstructed key per group: rotate the pair once (first chunk of the pair), two FMAs per head
+          // one reconstructed key per group: rotate the pair once and hand it to the score MFMA as an fp16 pair
           if (mb == 0) {
             const float k1 = acP[0][4 * j], k2 = acP[0][4 * j + 2];
             kr1 = fmaf(-ss, k2, cc * k1);
             kr2 = fmaf(ss, k1, cc * k2);
-            asm volatile("" : "+v"(kr1), "+v"(kr2));
-          }
-#pragma unroll
-          for (int h2 = 0; h2 < 2; ++h2) {
-            const int s = 2 * mb + h2;
-            part[s] = fmaf(q1[s][j], kr1, fmaf(q2[s][j], kr2, part[s]));
-            asm volatile("" : "+v"(part[s]));
+            krb[2 * j] = (h16)kr1;
+            krb[2 * j + 1] = (h16)kr2;
           }
         } else
 #pragma unroll
@@ -763,11 +778,26 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
     // lanes n and n+32 hold complementary pairs of the same position: one half-swap per head PAIR leaves head
     // 2mb in the low half and head 2mb+1 in the high half, so one add and one store cover two heads
     const unsigned rdst = red_lane + (unsigned)((erslot * RED_STRIDE + eblk * 32) * sizeof(float));
+    if (SHARED) {
+      // scores of the block's heads over this wave's 16 key components: D[m = head, n = position]; lanes hi = 0 hold
+      // rows 0..3 in registers 0..3 (both halves' components are already summed by the contraction)
+      f32x16 sd;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sd[e] = 0.f;
+      sd = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa, krb, sd, 0, 0, 0);
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb) {
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sd[2 * mb]), __float_as_uint(sd[2 * mb + 1]), false, false);
+        *(__attribute__((address_space(3))) float*)(uintptr_t)(rdst + (unsigned)(mb * 2 * TL * sizeof(float))) =
+            __uint_as_float(sw[0]);
+      }
+    } else {
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb) {
       auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(part[2 * mb]), __float_as_uint(part[2 * mb + 1]), false, false);
       *(__attribute__((address_space(3))) float*)(uintptr_t)(rdst + (unsigned)(mb * 2 * TL * sizeof(float))) =
           __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    }
     }
     if (KIND == 0 && QBITS != 0) {
       store_q(sslot);                         // registers hold tile min(stt, ntile-1)
