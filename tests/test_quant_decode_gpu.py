@@ -236,3 +236,19 @@ def test_softmax_pv_q_shapes_and_masks(bits, Rv, gs, H, L, masked):
     if gs in (1, 2, 4, 8) and Rv <= 2048:
         ref_ctx = softmax_pv(scores, deq, mask)[0]
         torch.testing.assert_close(ctx, ref_ctx, rtol=2e-3, atol=2e-3)
+
+
+def test_softmax_pv_q_valu_fallback_kernel():
+    """PALU_PVQ_DIRECT=0 selects the VALU kernel (pv_partial_q_kernel) that takes the shapes the register-direct kernel
+    leaves (unaligned rows, > 2 GiB of codes per group, a divisor without an exact fast quotient).  The switch is read
+    once per process: the quantised P.V cases are re-run in a child process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, PALU_PVQ_DIRECT="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_quant_decode_gpu.py"), "-q", "-x",
+                        "-m", "gpu", "-k", "test_softmax_pv_q and not fallback and not shapes_and_masks"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout
