@@ -95,6 +95,9 @@ int palu_abx_rope_shared_f16(const void* a, int64_t sa_h, int64_t sa_d, const vo
  * monotone in L), so a workspace sized for a cache capacity serves every fill level.
  */
 int palu_pv_nsplit(int G, int L);
+/* split count of the register-direct matrix-core kernel behind palu_softmax_pv_q (bits 3 / 4) and, opt-in, behind
+ * palu_softmax_pv_f16 (bits 16); covered by palu_pv_workspace_bytes for every L <= the capacity it was sized for */
+int palu_pv_direct_nsplit(int G, int L, int Rv, int bits);
 size_t palu_pv_workspace_bytes(int H, int G, int L, int Rv);
 /* Byte offset, inside the workspace, of the per-head softmax statistics the call leaves behind:
  * float stats[H][2] = (max_l x[h,l], sum_l exp(x[h,l] - max)).  With ctx they are what a split-L

@@ -44,6 +44,7 @@ SIGNATURES = {
     "palu_abx_rope_f16": (i32, [vp, i64, i64, vp, vp, i64, i64, vp, i64, i32, i32, i32, i32, i32, vp, i32, vp]),
     "palu_abx_rope_shared_f16": (i32, [vp, i64, i64, vp, vp, i64, i64, vp, i64, i32, i32, i32, i32, i32, vp, i32, vp]),
     "palu_pv_nsplit": (i32, [i32, i32]),
+    "palu_pv_direct_nsplit": (i32, [i32, i32, i32, i32]),
     "palu_pv_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "palu_pv_stats_offset": (sz, [i32, i32, i32, i32]),
     "palu_softmax_pv_f16": (i32, [vp, i64, vp, vp, i64, i64, vp, vp, i64, vp, i32, i32, i32, i32, f32, vp]),

@@ -1092,6 +1092,17 @@ extern "C" size_t palu_pv_workspace_bytes(int H, int G, int L, int Rv) {
   return ((size_t)H * ns * (Rv + 2) + pv_ws_stats_floats(H)) * sizeof(float);
 }
 
+static int pv_qr_plan(int G, int L, int Rv, int cw, int* nsl_o, int* ncw_o, int* S_o, int* rps_o);
+// split count of the register-direct kernel for (G, L, Rv, bits = 3 / 4 / 16): what palu_pv_workspace_bytes has to cover
+// (introspection for tests and tools; 0 for shapes that kernel does not take)
+extern "C" int palu_pv_direct_nsplit(int G, int L, int Rv, int bits) {
+  if (G <= 0 || L <= 0 || Rv <= 0 || !(bits == 3 || bits == 4 || bits == 16)) return 0;
+  const int cw = bits == 16 ? 8 : 32;
+  if (Rv % cw != 0 || Rv / cw > 128) return 0;
+  int nsl, ncw, S, rps;
+  return pv_qr_plan(G, L, Rv, cw, &nsl, &ncw, &S, &rps);
+}
+
 extern "C" size_t palu_pv_stats_offset(int H, int G, int L, int Rv) {
   (void)H; (void)G; (void)L; (void)Rv;
   return 0;     // the global (max, sum) pairs lead the workspace, whichever kernel and split count ran
@@ -1102,6 +1113,25 @@ extern "C" size_t palu_pv_stats_offset(int H, int G, int L, int Rv) {
 // whole 32-code (8-column) chunks, dword (16-byte) aligned rows, a group's rows within 2 GiB, and a divisor whose fast
 // quotient is exact.  Returns PV_QR_NOT_TAKEN when the shape is left to the older kernels.
 constexpr int PV_QR_NOT_TAKEN = 1;
+// geometry of a register-direct launch: column slices of <= 16 chunks (cw columns each), S row sets per unit, and one
+// round of 8-wave workgroups (256 VGPRs per wave: one workgroup per CU): CUs / G ranges per group, each cut into
+// nws = 8 / slices wave ranges of whole units (32 S rows); the statistics are computed online, so a wave range may have
+// any number of rows.  Returns the number of ranges.
+static int pv_qr_plan(int G, int L, int Rv, int cw, int* nsl_o, int* ncw_o, int* S_o, int* rps_o) {
+  const int nch = Rv / cw;
+  int nsl = 1;
+  while (nsl * 16 < nch) nsl *= 2;                      // 1, 2, 4, 8 column slices of <= 16 chunks
+  const int ncw = (nch + nsl - 1) / nsl;
+  int S = 16 / ncw;
+  if (S > 2) S = 2;                                     // (a unit is at most one 64-row batch of statistics)
+  const int RU = 32 * S, nws = 8 / nsl;
+  const long long P = ((long long)pv_qr_wgs() * palu_num_cus() * nws + G - 1) / G;
+  long long rpw = (L + P - 1) / P;
+  rpw = (rpw + RU - 1) / RU * RU;
+  const int rps = (int)rpw * nws;
+  *nsl_o = nsl; *ncw_o = ncw; *S_o = S; *rps_o = rps;
+  return (L + rps - 1) / rps;
+}
 static int pv_qr_launch(const void* scores, int64_t ss_h, const void* mask, const void* rows, int64_t sc_g, int64_t sc_l,
                         const void* meta, int64_t sm_g, int64_t sm_l, void* ctx, void* probs, int64_t sp_h,
                         void* workspace, int H, int G, int L, int Rv, int bits, float sqrt_d, hipStream_t s) {
@@ -1124,22 +1154,8 @@ static int pv_qr_launch(const void* scores, int64_t ss_h, const void* mask, cons
             span + 4096ll * sc_l < 0x7FFFFFFFll && ((uintptr_t)rows & 3) == 0 && sc_g % 4 == 0 && sc_l % 4 == 0 &&
             (bits == 3 || (((uintptr_t)rows & 15) == 0 && sc_g % 16 == 0 && sc_l % 16 == 0)) && pv_exact_rcp(sqrt_d) != 0.f;
   if (!ok) return PV_QR_NOT_TAKEN;
-  const int nch = Rv / cw;
-  int nsl = 1;
-  while (nsl * 16 < nch) nsl *= 2;                      // 1, 2, 4, 8 column slices of <= 16 chunks
-  const int ncw = (nch + nsl - 1) / nsl;
-  int S = 16 / ncw;
-  if (S > 2) S = 2;                                     // (a unit is at most one 64-row batch of statistics)
-  const int wgs = pv_qr_wgs();
-  // one round of 8-wave workgroups (256 VGPRs per wave: one workgroup per CU): CUs / G ranges per group, each cut
-  // into nws = 8 / slices wave ranges of whole units (32 S rows); the statistics are computed online, so a wave range
-  // may have any number of rows
-  const int RU = 32 * S, nws = 8 / nsl;
-  const long long P = ((long long)wgs * palu_num_cus() * nws + G - 1) / G;
-  long long rpw = (L + P - 1) / P;
-  rpw = (rpw + RU - 1) / RU * RU;
-  const int rps = (int)rpw * nws;
-  const int ns = (L + rps - 1) / rps;                   // ranges (one workgroup each) = splits seen by pv_combine
+  int nsl, ncw, S, rps;
+  const int ns = pv_qr_plan(G, L, Rv, cw, &nsl, &ncw, &S, &rps);   // ranges (one workgroup each) = splits seen by pv_combine
   if (ns > pv_nsplit_bound(G, L, Rv)) return PV_QR_NOT_TAKEN;   // (cannot happen for a workspace sized by palu_pv_workspace_bytes)
   float* ws = (float*)workspace;
   PvQParams p;

@@ -83,6 +83,18 @@ def test_pv_workspace_covers_every_fill_level():
                 assert lib.palu_pv_stats_offset(H, G, L, Rv) + H * 2 * 4 <= nbytes
                 assert lib.palu_decode_attn_stats_offset(H, G, L, Rv) + H * 2 * 4 <= nbytes
             assert worst >= 1
+    # the register-direct quantised / fp16 P.V kernel plans its own ranges (column slices for wide rows): same bound
+    for G, H in ((8, 32), (1, 4), (4, 16)):
+        for Rv in (64, 128, 192, 384, 512, 1024, 4096):
+            for bits in (3, 4, 16):
+                for cap in (64, 1000, 4096, 16512, 65600, 300032):
+                    nbytes = lib.palu_pv_workspace_bytes(H, G, cap, Rv)
+                    for L in sorted({1, 31, 33, 64, 65, cap // 3, cap // 2 + 1, cap - 1, cap}):
+                        if L < 1 or L > cap:
+                            continue
+                        ns = lib.palu_pv_direct_nsplit(G, L, Rv, bits)
+                        assert ns >= 1
+                        assert (64 + H * ns * (Rv + 2)) * 4 <= nbytes, (G, Rv, bits, cap, L, ns, nbytes)
     # the round-1 failure: capacity 16512 was sized for 122 splits while L <= 16384 uses up to 128
     assert lib.palu_pv_nsplit(8, 16384) == 128
     assert lib.palu_pv_workspace_bytes(32, 8, 16512, 384) >= (32 * 128 * (384 + 2) + 64) * 4
