@@ -1054,9 +1054,11 @@ int pv_nsplit_bound(int G, int Lcap, int Rv) {
   long long r = a > b ? a : b;
   // the register-direct quantised kernel (pv_partial_qr_kernel): one round of Pr = CUs / G ranges, each at least one
   // unit (32 rows) per wave of a slice
+  // (the plain-fp16 form of that kernel has 8-column chunks, i.e. the most column slices and the fewest waves per range:
+  //  the bound is taken for it)
   int nsl = 1;
-  while (nsl * 16 < Rv / 32) nsl *= 2;
-  const long long nws = nsl >= 8 ? 1 : 8 / nsl;
+  while (nsl * 16 < Rv / 8 && nsl < 8) nsl *= 2;
+  const long long nws = 8 / nsl;
   const long long Pr = ((long long)pv_qr_wgs() * palu_num_cus() + G - 1) / G;
   long long c = ((long long)Lcap + 32 * nws - 1) / (32 * nws);
   if (c > Pr) c = Pr;

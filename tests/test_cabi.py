@@ -93,7 +93,9 @@ def test_pv_workspace_covers_every_fill_level():
                         if L < 1 or L > cap:
                             continue
                         ns = lib.palu_pv_direct_nsplit(G, L, Rv, bits)
-                        assert ns >= 1
+                        if ns == 0:                       # (more than 128 chunks per row: the older kernels run)
+                            assert bits == 16 and Rv > 1024
+                            continue
                         assert (64 + H * ns * (Rv + 2)) * 4 <= nbytes, (G, Rv, bits, cap, L, ns, nbytes)
     # the round-1 failure: capacity 16512 was sized for 122 splits while L <= 16384 uses up to 128
     assert lib.palu_pv_nsplit(8, 16384) == 128
