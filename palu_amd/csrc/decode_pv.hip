@@ -445,26 +445,28 @@ __global__ __launch_bounds__(PV_THREADS) void pv_partial_q_kernel(PvQParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Quantised V latents, register-direct: packed rows go HBM -> VGPRs -> MFMA operands with no LDS, no barrier and no
-// transpose read in between (pv_partial_qm_kernel above pays a ds_write + barrier + ds_read_tr round trip per 32 rows
-// and is latency-bound at 3 waves per SIMD).  The MFMA contracts over ROWS, and which row sits in which k-slot is
-// ours to choose as long as both operands agree:
+// Quantised V latents, register-direct (pv_partial_qr_kernel): packed rows go HBM -> VGPRs -> MFMA operands with no LDS, no
+// barrier and no transpose read on the V path.  (Its predecessor wrote an fp16 image of the codes to LDS and read it back
+// transposed: a ds_write + barrier + ds_read_tr round trip per 32 rows, latency-bound; 48 instead of 29 us at C3.)
+// The MFMA contracts over ROWS, and which row sits in which k-slot is ours to choose as long as both operands agree:
 //   v_mfma_f32_16x16x32_f16: D[m, n] += sum_k A[m, k] B[k, n];   lane = (m or n = lane % 16, q = lane / 16) holds
 //   the 8 k-slots e = 0..7 of k-group q.  k-slot (q, e) <-> row 4e + q of a 32-row set, so
-//   A: lane (m, q) loads ITS OWN 8 rows x one 32-code chunk (8 dwordx3 / dwordx4 buffer loads; instruction e covers
+//   B: lane (n, q) loads ITS OWN 8 rows x one 32-code chunk (8 dwordx3 / dwordx4 buffer loads; instruction e covers
 //      rows 4e..4e+3 of the set: whole consecutive rows, coalesced) and turns them into 32 operands (one per code
 //      column j of the chunk) with byte permutes that pair rows (2p, 2p+1) plus one v_and_or per code pair: the code
 //      stays where it is inside the 16-bit half and the fp16 exponent is chosen for that bit position --
 //      ((w & (7 << s)) | fp16(2^(10-s)))  ==  2^(10-s) + code  for s <= 7 -- so most codes need no shift
-//      (0.75-0.8 VALU per code instead of 1.5 + the LDS traffic);
-//   B: lane (n, q) reads the 8 weights w = fp16(e^(x-m) * scale_row) of its rows with one ds_read_b128 (the weight
-//      rows are stored in k-slot order by phase A).
-// m = (row set s, chunk c), n = (row set s, head h): with Rv/32 = 12 chunks one set of 32 rows fills 12 of the 16 m
-// lanes, with 6 or 8 chunks two sets, with 4 chunks four; D[(s,c), (s',h)] is meaningful for s == s' and ignored
-// otherwise.  32 accumulators (one per code column of the chunk) live in registers for the whole range, the per-column
-// offsets 2^(10-s) and the zero points leave at the end:  out = acc - sum_l w_l z_l - off_j sum_l w_l.
-// Wider rows (Rv > 512) are cut into column slices handled by different waves.  Waves walk their units independently
-// (no barrier inside the loop); NSET units are in flight per wave in named register sets.
+//      (0.75-0.81 VALU per code instead of 1.5 + the LDS traffic);
+//   A: lane (m, q) reads the 8 weights w = fp16(e^(x-m) * scale_row) of its rows with one ds_read_b128 (the weight
+//      rows of a 64-row batch sit in the wave's LDS patch in k-slot order).
+// n = (row set s, chunk c), m = (row set s, head h): with Rv/32 = 12 chunks one set of 32 rows fills 12 of the 16 n
+// lanes, with <= 8 chunks two sets share an MFMA; D[(s',h), (s,c)] is meaningful for s == s' and ignored otherwise
+// (D lane (n, q) holds rows m = 4q..4q+3 = the heads of row set q).  One accumulator per code column of the chunk lives
+// in registers for the whole range; the per-column offsets 2^(10-s) and the zero points leave at the end:
+// out = acc - sum_l w_l z_l - off_j sum_l w_l.  Rows wider than 512 codes are cut into column slices handled by different
+// waves.  Statistics are computed online in 64-row batches inside the unit loop (see there); the only workgroup barrier
+// precedes the merge of the waves.  BITS = 16 runs plain fp16 rows through the same structure (8-column chunks, the
+// byte permute is the whole decode).
 template <int BITS>
 struct QrDecode {
   // offsets of the decoded columns (fp16 value = off + code), in MFMA order j % 8 (3 bit) or j % 4 (4 bit)
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
   const int nsl = p.qr_nsl, ncw = p.qr_ncw;                      // slices, chunks per slice (host plan; S = p.qr_s row sets)
   constexpr int RU = 32 * S;
   const int sl = wv % nsl, wph = wv / nsl, nws = NW / nsl;       // this wave: slice, row phase; waves per slice
-  const int rpw = p.rps / nws;                                   // rows per wave: a multiple of RU, <= 576
+  const int rpw = p.rps / nws;                                   // rows per wave: a multiple of RU, any number of batches
   const int r0 = wph * rpw;
   const int nw = max(0, min(n - r0, rpw));                       // valid rows of this wave
   const int nwlast = max(nw - 1, 0);
