@@ -593,8 +593,8 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
 
   // ---- softmax statistics ONLINE, in batches of 64 rows of this wave's range (no workgroup barrier: a wave
   //      is its own split until the epilogue merges the waves with exp(m_wave - m_range)).  Per batch: scaled logits ->
-  //      wave maximum (DPP) -> if it raises the running maximum (a wave-uniform, rare event after the first batches) the
-  //      accumulators and the partial sums are rescaled -> weights fp16(e^(x-m) * scale_row) into the wave's LDS patch in
+  //      does any row beat the running maximum (a ballot)?  If so (wave-uniform, rare after the first batches): wave
+  //      maximum by DPP, accumulators and partial sums rescaled -> weights fp16(e^(x-m) * scale_row) into the wave's LDS patch in
   //      k-slot order -> the batch's units run on the matrix cores.  The raw scores / (scale, zero) of batch b+1 are
   //      requested before the units of batch b run, into the registers batch b has just vacated; the V units stream through
   //      two register sets all along, so HBM never waits for the statistics and a range may have any number of rows.
