@@ -252,3 +252,35 @@ def test_softmax_pv_q_valu_fallback_kernel():
                        env=env, cwd=root, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "passed" in r.stdout
+
+
+@pytest.mark.parametrize("bits,Rv,L,spikes", [(3, 384, 70000, (5, 40000, 69999)), (4, 192, 9000, (4500,)), (3, 128, 3000, (64, 2999))])
+def test_softmax_pv_q_late_maximum_forces_rescale(bits, Rv, L, spikes):
+    """The online statistics of the register-direct kernel rescale the accumulators when a later 64-row batch raises the
+    running maximum -- a rare, data-dependent branch on ordinary inputs.  Here it is forced: flat logits with isolated
+    spikes of increasing height deep inside wave ranges (different heads spike at different rows), checked against the
+    fp64 softmax over the full tensor."""
+    from palu_amd import _lib
+    from palu_amd.kernel import quant as q
+    rng = np.random.default_rng(bits + Rv + L)
+    H, gs = 32, 4
+    G = H // gs
+    s = (rng.standard_normal((H, L)) * 0.5).astype(np.float32)
+    for i, pos in enumerate(spikes):
+        for h in range(H):
+            p_h = min(L - 1, pos + 67 * h)                          # another batch / wave for every head
+            s[h, p_h] += 40.0 * (i + 1) + h                         # each later spike beats the earlier ones
+    scores = torch.from_numpy((s * math.sqrt(128.0)).astype(np.float16)).to(DEV)
+    v = torch.from_numpy(rng.standard_normal((G, L, Rv)).astype(np.float16)).to(DEV)
+    codes, meta, deq = q.quantize_pack(v, bits, want_dequant=True)
+    ws = torch.empty(_lib.lib.palu_pv_workspace_bytes(H, G, L, Rv), dtype=torch.uint8, device=DEV)
+    ctx = torch.empty(H, Rv, dtype=torch.float16, device=DEV)
+    _lib.check(_lib.lib.palu_softmax_pv_q(scores.data_ptr(), scores.stride(0), 0, codes.data_ptr(), codes.stride(0),
+                                          codes.stride(1), meta.data_ptr(), meta.stride(0), meta.stride(1), ctx.data_ptr(),
+                                          0, 0, ws.data_ptr(), H, G, L, Rv, bits, math.sqrt(128.0), _lib.current_stream()),
+               "pv_q")
+    x = (scores.cpu().float() / math.sqrt(128.0)).half()
+    p64 = torch.softmax(x.double(), dim=-1)
+    c64 = torch.matmul(p64.reshape(G, gs, L), deq.cpu().double()).reshape(H, Rv)
+    assert torch.isfinite(ctx).all()
+    assert (ctx.cpu().double() - c64).abs().max().item() <= 1.5e-3 * max(1.0, c64.abs().max().item())
