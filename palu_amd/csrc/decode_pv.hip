@@ -239,7 +239,7 @@ struct PvQParams {
   float* ml;
   int G, gs, L, Rv, nsplit, rps;
   float inv_scale;
-  int exp_flags;   // PALU_PVQ_EXP = 8: timeline dump of pv_partial_qr_kernel (tools/time_pvq.py)
+  int exp_flags;   // 8: timeline dump of pv_partial_qr_kernel (PALU_PVQ_TIMELINE_DUMP, tools/time_pvq.py)
   int qr_nsl, qr_ncw, qr_s;   // register-direct kernel: column slices, chunks per slice, row sets per unit
   unsigned qr_park_off;       // LDS offset of the parked per-lane partial sums [8 waves][3][64 lanes] f32x4
   int qr_prio;                // 1: waves 4-7 run the unit loop at raised priority
@@ -1174,8 +1174,10 @@ static int pv_qr_launch(const void* scores, int64_t ss_h, const void* mask, cons
   {
     static int ex = -1;
     if (ex < 0) {
-      const char* e = getenv("PALU_PVQ_EXP");      // 8: every wave dumps 5 wall-clock stamps behind the workspace (tools/time_pvq.py)
-      ex = e ? atoi(e) : 0;
+      // PALU_PVQ_TIMELINE_DUMP=<bytes the caller added behind the workspace>: every wave dumps 5 wall-clock stamps there
+      // (tools/time_pvq.py).  The explicit size keeps an accidental setting from writing past a normal workspace.
+      const char* e = getenv("PALU_PVQ_TIMELINE_DUMP");
+      ex = (e && atoll(e) >= (long long)G * ns * 8 * 5 * 8) ? 8 : 0;
     }
     p.exp_flags = ex;
   }

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Timeline of pv_partial_qr_kernel (PALU_PVQ_EXP=8 makes every wave dump 5 wall-clock stamps over the partials)."""
+"""Timeline of pv_partial_qr_kernel (PALU_PVQ_TIMELINE_DUMP=<extra bytes behind the workspace> makes every wave dump 5
+wall-clock stamps there)."""
 import math, os, sys
-os.environ["PALU_PVQ_EXP"] = "8"
+os.environ["PALU_PVQ_TIMELINE_DUMP"] = str(4 << 20)
 import numpy as np
 import torch
 from palu_amd import _lib
