@@ -70,19 +70,58 @@ def baseline_metric(rank_k, Lp):
     return "decode-step us + achieved HBM GB/s, rank_k=%d prompt_len=%dk" % (rank_k, Lp // 1024)
 
 
-def time_loop(fn, steps, warmup, sync):
+REPS = 7                      # repetitions of the K-step timed loop; the headline is their median
+
+
+def _gate():
+    """~100 us of device-side spin in front of a timed loop: the host queues the loop's launches while the GPU is still
+    busy, so the device-event time between the two records is back-to-back execution from a full queue -- not the host's
+    first-launch latency (3-16 us per forward, MI355X_MICROARCH.md `graph-replay-floor`) amortised over K steps."""
+    torch.cuda._sleep(200_000)
+
+
+def time_reps(fn, steps, warmup, sync, reps=REPS, settle_ms=20.0):
+    """`warmup` untimed calls, an internal settle phase to a steady clock (>= settle_ms of further calls), then `reps`
+    repetitions, each timing EXACTLY `steps` calls twice: (a) host wall clock between two sync()s, (b) device events on
+    the launch stream between two sync()s, recorded behind a short device-side gate (see _gate).  Returns the
+    per-repetition lists (host wall ms, device-event ms) over `steps` calls."""
     for _ in range(warmup):
         fn()
     sync()
-    t0 = time.perf_counter()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    ev0.record()
-    for _ in range(steps):
+    t0, n = time.perf_counter(), 0
+    while (time.perf_counter() - t0) * 1e3 < settle_ms and n < 4096:
         fn()
-    ev1.record()
-    sync()
-    wall = (time.perf_counter() - t0) * 1e3
-    return wall, ev0.elapsed_time(ev1)      # (host wall between the two syncs, device event time), ms over `steps`
+        n += 1
+        if n % 64 == 0:
+            torch.cuda.synchronize()
+    walls, evs = [], []
+    for _ in range(reps):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        sync()
+        walls.append((time.perf_counter() - t0) * 1e3)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        _gate()
+        ev0.record()
+        for _ in range(steps):
+            fn()
+        ev1.record()
+        sync()
+        evs.append(ev0.elapsed_time(ev1))
+    return walls, evs
+
+
+def _median(v):
+    v = sorted(v)
+    return v[len(v) // 2]
+
+
+def time_loop(fn, steps, warmup, sync, reps=3):
+    """(median host wall ms, median device-event ms) over `steps` calls -- the sub-record / per-kernel form"""
+    walls, evs = time_reps(fn, steps, warmup, sync, reps=reps, settle_ms=5.0)
+    return _median(walls), _median(evs)
 
 
 def cpu_baseline(rank_k, rank_v, L, reps=3):
@@ -155,10 +194,13 @@ def alg_bytes_q(rank_k, rank_v, L, bits):
     return {"abx": abx_b, "softmax_pv": pv_b, "step": abx_b + pv_b + qkv_b + o_b}
 
 
-def bench_quant_config(name, rank_k, rank_v, Lp, bits, steps, dev):
+def bench_quant_config(name, rank_k, rank_v, Lp, bits, steps, dev, parity=True):
     """BASELINE configs 3 / 4: the decode step on a packed 3/4-bit latent cache (palu_decode_step_q): step us (graph
-    replay) + the two attention kernels on their own.  Hadamard (config 3) is folded into the weights offline
-    (LlamaPaluAttention.fuse_hadamard): with random-init weights it changes no shape and adds no kernel."""
+    replay) + the two attention kernels on their own, and -- `parity` -- the step's output against
+    oracle.decode_step(latent_bits=bits) on the SAME inputs at the full size (the oracle fake-quantises the cached rows
+    with quantize_rows, the GPU packs the same fp16 rows with palu_quantize_pack: bit-identical codes).  Hadamard
+    (config 3) is folded into the weights offline (LlamaPaluAttention.fuse_hadamard): with random-init weights it
+    changes no shape and adds no kernel -- the random weights stand for the rotated ones on both sides."""
     from palu_amd import _lib
     from palu_amd.kernel.abx_rope import prepare_b, rope_inv_freq
     from palu_amd.kernel import quant as q
@@ -167,17 +209,34 @@ def bench_quant_config(name, rank_k, rank_v, Lp, bits, steps, dev):
     L = Lp + 1
     cap = (Lp + 64 + 63) // 64 * 64
     torch.manual_seed(4321)
-    wq = (torch.randn(H * D, HIDDEN, device=dev) / 64).half()
-    vtk = (torch.randn(rank_k, HIDDEN, device=dev) / 64).half()
-    vtv = (torch.randn(rank_v, HIDDEN, device=dev) / 64).half()
-    b = (torch.randn(H, Rk, D, device=dev) * Rk ** -0.5).half()
-    wo = (torch.randn(HIDDEN, H * Rv, device=dev) * 0.01).half()
-    kc, km = q.quantize_pack(torch.randn(G, cap, Rk, device=dev, dtype=torch.float16), bits)
-    vc, vm = q.quantize_pack(torch.randn(G, cap, Rv, device=dev, dtype=torch.float16), bits)
-    hidden = torch.randn(HIDDEN, device=dev, dtype=torch.float16)
+    wc = {"wq": (torch.randn(H * D, HIDDEN) / 64).half(), "vt_k": (torch.randn(rank_k, HIDDEN) / 64).half(),
+          "vt_v": (torch.randn(rank_v, HIDDEN) / 64).half(), "b": (torch.randn(H, Rk, D) * Rk ** -0.5).half(),
+          "wo": (torch.randn(HIDDEN, H * Rv) * 0.01).half()}
+    k_cpu = torch.randn(G, Lp, Rk).half()
+    v_cpu = torch.randn(G, Lp, Rv).half()
+    tok = torch.randn(HIDDEN).half()
+    ref = None
+    if parity:
+        import oracle
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            kq = oracle.quantize_rows(k_cpu.reshape(-1, Rk), bits)[0].reshape(G, Lp, Rk)
+            vq = oracle.quantize_rows(v_cpu.reshape(-1, Rv), bits)[0].reshape(G, Lp, Rv)
+            ref = oracle.decode_step(tok, Lp, wc, kq, vq, latent_bits=bits)[0]
+        del kq, vq
+        oracle_s = time.perf_counter() - t0
+    wq, vtk, vtv, b, wo = (wc[n].to(dev) for n in ("wq", "vt_k", "vt_v", "b", "wo"))
+    kf = torch.zeros(G, cap, Rk, device=dev, dtype=torch.float16)
+    vf = torch.zeros(G, cap, Rv, device=dev, dtype=torch.float16)
+    kf[:, :Lp] = k_cpu.to(dev)
+    vf[:, :Lp] = v_cpu.to(dev)
+    kc, km = q.quantize_pack(kf, bits)
+    vc, vm = q.quantize_pack(vf, bits)
+    del kf, vf, k_cpu, v_cpu
+    hidden = tok.to(dev)
     frag = prepare_b(b, G)
     inv = rope_inv_freq(dev)
-    ws = torch.empty(lib.palu_decode_workspace_bytes(H, G, D, cap + 8, Rv), dtype=torch.uint8, device=dev)
+    ws = torch.zeros(lib.palu_decode_workspace_bytes(H, G, D, cap + 8, Rv), dtype=torch.uint8, device=dev)
     out = torch.empty(HIDDEN, dtype=torch.float16, device=dev)
     scores = torch.empty(H, (L + 7) // 8 * 8, dtype=torch.float16, device=dev)
     ctx = torch.empty(H, Rv, dtype=torch.float16, device=dev)
@@ -203,6 +262,16 @@ def bench_quant_config(name, rank_k, rank_v, Lp, bits, steps, dev):
         _lib.check(lib.palu_softmax_pv_q(scores.data_ptr(), scores.stride(0), 0, vc.data_ptr(), vc.stride(0), vc.stride(1),
                                          vm.data_ptr(), vm.stride(0), vm.stride(1), ctx.data_ptr(), 0, 0, pvws.data_ptr(),
                                          H, G, L, Rv, bits, math.sqrt(D), s()), "pv_q")
+    par = None
+    if ref is not None:
+        step()
+        torch.cuda.synchronize()
+        d = float((out.float().cpu() - ref.float()).abs().max())
+        sc = float(ref.float().abs().max())
+        par = {"max_abs_diff_vs_oracle": round(d, 6), "oracle_out_max_abs": round(sc, 5), "positions": L,
+               "oracle": "oracle.decode_step(latent_bits=%d) on quantize_rows() of the same fp16 latents" % bits,
+               "tolerance": "rtol=atol=1e-3 (test_palu_attention.py:183-195)", "ok": bool(d <= 1e-3 + 1e-3 * sc),
+               "oracle_seconds": round(oracle_s, 1)}
     replay = graph_of(step)
     _, ms = time_loop(replay, steps, 10, torch.cuda.synchronize)
     us = ms * 1e3 / steps
@@ -210,13 +279,68 @@ def bench_quant_config(name, rank_k, rank_v, Lp, bits, steps, dev):
     rec = {"workload": "%s: rank_k=%d rank_v=%d prompt_len=%d %d-bit packed latents (asym, per (token, group) row)"
                        % (name, rank_k, rank_v, Lp, bits),
            "step_us": round(us, 2), "step_algorithmic_bytes": alg["step"],
-           "step_hbm_frac": round(alg["step"] / us * 1e-3 / HBM_PEAK_GBPS, 4), "kernels": {}}
+           "step_hbm_frac": round(alg["step"] / us * 1e-3 / HBM_PEAK_GBPS, 4), "kernels": {}, "parity": par}
     for kn, fn in (("abx", k_abx), ("softmax_pv", k_pv)):
         _, kms = time_loop(fn, 50, 5, torch.cuda.synchronize)
         kus = kms * 1e3 / 50
         rec["kernels"][kn] = {"us": round(kus, 2), "algorithmic_bytes": alg[kn],
                               "hbm_frac": round(alg[kn] / kus * 1e-3 / HBM_PEAK_GBPS, 4)}
     return rec
+
+
+def bench_shared_b(rank_k, rank_v, Lp, steps, dev):
+    """Config 2 with the B factor TIED inside every latent group (true-GQA checkpoints: the query heads of a group share
+    one KV head, palu/model/svd_mistral/modeling_palu_mistral.py:37-59): palu_decode_step_sharedb_f16 reconstructs the
+    keys once per group.  The one configuration in which the contract's HBM target for the score kernel is reachable."""
+    from palu_amd import _lib
+    from palu_amd.kernel.abx_rope import prepare_b, rope_inv_freq
+    lib = _lib.lib
+    Rk, Rv = rank_k // G, rank_v // G
+    L = Lp + 1
+    cap = (Lp + 64 + 63) // 64 * 64
+    torch.manual_seed(777)
+    wq = (torch.randn(H * D, HIDDEN, device=dev) / 64).half()
+    vtk = (torch.randn(rank_k, HIDDEN, device=dev) / 64).half()
+    vtv = (torch.randn(rank_v, HIDDEN, device=dev) / 64).half()
+    bg = (torch.randn(G, Rk, D, device=dev) * Rk ** -0.5).half()          # one factor per group
+    wo = (torch.randn(HIDDEN, H * Rv, device=dev) * 0.01).half()
+    kc = torch.randn(G, cap, Rk, device=dev, dtype=torch.float16)
+    vc = torch.randn(G, cap, Rv, device=dev, dtype=torch.float16)
+    hidden = torch.randn(HIDDEN, device=dev, dtype=torch.float16)
+    frag = prepare_b(bg, G)                                               # fragments of the [G, R, D] shared factor
+    inv = rope_inv_freq(dev)
+    ws = torch.zeros(lib.palu_decode_workspace_bytes(H, G, D, cap + 8, Rv), dtype=torch.uint8, device=dev)
+    out = torch.empty(HIDDEN, dtype=torch.float16, device=dev)
+    scores = torch.empty(H, (L + 7) // 8 * 8, dtype=torch.float16, device=dev)
+    q_buf = torch.randn(H * D, device=dev).half()
+    s = _lib.current_stream
+
+    def step():
+        _lib.check(lib.palu_decode_step_sharedb_f16(
+            hidden.data_ptr(), wq.data_ptr(), wq.stride(0), vtk.data_ptr(), vtk.stride(0), vtv.data_ptr(), vtv.stride(0),
+            frag.data_ptr(), wo.data_ptr(), wo.stride(0), kc.data_ptr(), kc.stride(0), kc.stride(1),
+            vc.data_ptr(), vc.stride(0), vc.stride(1), 0, inv.data_ptr(), out.data_ptr(), 0, 0, ws.data_ptr(), cap + 8,
+            H, G, D, HIDDEN, Rk, Rv, Lp, Lp, s()), "decode_step_sharedb")
+
+    def k_abx():
+        _lib.check(lib.palu_abx_rope_shared_f16(q_buf.data_ptr(), D, 1, frag.data_ptr(), kc.data_ptr(), kc.stride(0),
+                                                kc.stride(1), scores.data_ptr(), scores.stride(0), H, G, L, Rk, D,
+                                                inv.data_ptr(), 0, s()), "abx_shared")
+    replay = graph_of(step)
+    _, ms = time_loop(replay, steps, 10, torch.cuda.synchronize)
+    us = ms * 1e3 / steps
+    _, kms = time_loop(k_abx, 50, 5, torch.cuda.synchronize)
+    kus = kms * 1e3 / 50
+    ab_b = 2 * G * L * Rk + 2 * G * Rk * D + 2 * H * D + 2 * H * L          # one B factor per group
+    alg = algorithmic(rank_k, rank_v, L)
+    step_b = alg["step"][0] - alg["abx"][0] + ab_b
+    return {"workload": "C2 shapes with B shared by the %d heads of a group (true-GQA weights): rank_k=%d rank_v=%d "
+                        "prompt_len=%d fp16" % (GS, rank_k, rank_v, Lp),
+            "step_us": round(us, 2), "step_algorithmic_bytes": step_b,
+            "step_hbm_frac": round(step_b / us * 1e-3 / HBM_PEAK_GBPS, 4),
+            "kernels": {"abx_shared": {"us": round(kus, 2), "algorithmic_bytes": ab_b,
+                                       "hbm_GBps": round(ab_b / kus * 1e-3, 1),
+                                       "hbm_frac": round(ab_b / kus * 1e-3 / HBM_PEAK_GBPS, 4)}}}
 
 
 def bench_c5_slice(steps, dev):
@@ -313,16 +437,39 @@ def main():
         dec.step(hidden, Lp, Lp)
 
     sync()
-    use_graph = world == 1 and not args.no_graph
-    # the reference harness replays a captured graph of the step (run_latency_attention.py:81-90, --cache_graph); the
-    # launches are the same 5 kernels either way
-    run = graph_of(step) if use_graph else step
-    ms, ev_ms = time_loop(run, args.steps, args.warmup, sync)
-    t = torch.tensor([ms], device=dev)
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    ms = float(t.item())
-    us_step = ms * 1e3 / args.steps
+    # A/B of the two launch forms of the SAME five kernels: direct launches (two C-ABI calls per step) and the replay of
+    # a captured hipGraph of the step (what the reference harness times with --cache_graph, run_latency_attention.py:81-90).
+    # Every form: W warm-up steps + settle, then REPS repetitions of exactly K steps; medians; the headline is the faster
+    # form's DEVICE-EVENT time (max over ranks), its host wall time is reported beside it.
+    forms = {"direct": step}
+    if not args.no_graph:
+        # N > 1: the step's RCCL collective is captured with it (torch.distributed's NCCL backend records collectives
+        # into the capturing stream), so a replay issues no Python-side launch at all.  Every rank must take the same
+        # decision, or the timed loops would issue different numbers of collectives: agree on min(success) first.
+        replay, ok = None, 1
+        try:
+            replay = graph_of(step)
+        except Exception as e:                              # noqa: BLE001 -- e.g. a collective that cannot be captured
+            ok = 0
+            print("bench.py[rank %d]: graph capture of the step failed (%s)" % (rank, repr(e)[:200]), file=sys.stderr)
+        if dist is not None:
+            t = torch.tensor([ok], device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = int(t.item())
+        if ok:
+            forms["graph_replay"] = replay
+    ab = {}
+    for name, fn in forms.items():
+        walls, evs = time_reps(fn, args.steps, args.warmup, sync)
+        t = torch.tensor([walls, evs], device=dev, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        walls, evs = t[0].tolist(), t[1].tolist()
+        ab[name] = {"device_us": round(_median(evs) * 1e3 / args.steps, 2), "device_us_min": round(min(evs) * 1e3 / args.steps, 2),
+                    "host_wall_us": round(_median(walls) * 1e3 / args.steps, 2),
+                    "host_wall_us_min": round(min(walls) * 1e3 / args.steps, 2)}
+    best = min(ab, key=lambda k_: ab[k_]["device_us"])
+    us_step = ab[best]["device_us"]
     coll_us = None
     if world > 1:
         # collective-only latency: CUDA events around the step's one collective, median over 50 steps, max over ranks
@@ -374,7 +521,7 @@ def main():
                                              dec.out.data_ptr(), HIDDEN, H * Rv, s()), "o")
             n = max(20, min(args.steps, 200))
             for name, fn in (("qkv", k_qkv), ("abx", k_abx), ("softmax_pv", k_pv), ("o_proj", k_o)):
-                _, kms = time_loop(fn, n, 10, torch.cuda.synchronize)
+                _, kms = time_loop(fn, n, 10, torch.cuda.synchronize, reps=5)
                 us = kms * 1e3 / n
                 b, f = alg[name]
                 kern[name] = {"us": round(us, 2), "algorithmic_bytes": b, "hbm_GBps": round(b / us * 1e-3, 1),
@@ -395,7 +542,14 @@ def main():
                                                                        else "column-sharded o_proj + all-reduce of [hidden] fp32"))
                        if world > 1 else "single GPU",
                        "kernels_per_step": 5 if world == 1 else 6,
-                       "launch": "hipGraph replay of the captured step" if use_graph else "direct launches"},
+                       "launch": ("hipGraph replay of the captured step" if best == "graph_replay" else "direct launches")
+                                 + " (the faster of the forms in launch_ab)",
+                       "timing": "value = median over %d repetitions of the device-event time of exactly --steps steps "
+                                 "(events on the launch stream behind a device-side gate, sync + barrier on both sides, "
+                                 "max over ranks) after --warmup steps and a settle phase; host wall of the same loops in "
+                                 "launch_ab" % REPS},
+            "launch_ab": ab,
+            "host_wall_us": ab[best]["host_wall_us"],
             "collective_us": None if coll_us is None else round(coll_us, 2),
             "step_algorithmic_bytes": step_b,
             "step_hbm_GBps": round(step_b / us_step * 1e-3, 1),
@@ -409,8 +563,11 @@ def main():
             if os.path.exists(tf):
                 traffic = json.load(open(tf)).get(dom)
             rec["kernels"] = kern
+            tsrc = ("profiles/traffic.json: (FETCH_SIZE x 2 + WRITE_SIZE) per launch from separate rocprofv3 --pmc passes "
+                    "of this command, committed with the profile it came from; not re-collected by this run")
             rec["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["hbm_GBps"], "peak": HBM_PEAK_GBPS,
-                               "unit": "GB/s", "frac": kern[dom]["hbm_frac"], "traffic": traffic}
+                               "unit": "GB/s", "frac": kern[dom]["hbm_frac"], "traffic": traffic,
+                               "traffic_source": tsrc if traffic is not None else None}
             ab, af = alg["abx"]
             rec["roofline_abx"] = {"kernel": "abx_rope", "bound": "mfma", "achieved": kern["abx"]["tflops"],
                                    "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -421,7 +578,7 @@ def main():
                                    "frac_of_power_wall": round(kern["abx"]["tflops"] / MFMA_WALL_TFLOPS, 4),
                                    "note": "arithmetic intensity gs*D=512 flop/B > ridge: MFMA-bound (SURVEY F4); the "
                                            "power wall is what an MFMA-only random-operand fp16 stream sustains on "
-                                           "this part (profiles/r01_ubench_issue_mi355x.txt)"}
+                                           "this part (profiles/r02_ubench_issue_pmc_clock.txt: 1.69 GHz at 92 % MFMA busy)"}
         if world == 1 and not args.no_cpu_baseline:
             cl = args.cpu_sample_len or L
             t0 = time.perf_counter()
@@ -442,9 +599,15 @@ def main():
             sub = {}
             for nm, rk_, rv_, lp_, bits_ in (("C3", 1024, 3072, 65536, 3), ("C4", 512, 1536, 131072, 4)):
                 try:
-                    sub[nm] = bench_quant_config(nm, rk_, rv_, lp_, bits_, max(50, args.steps // 2), dev)
+                    sub[nm] = bench_quant_config(nm, rk_, rv_, lp_, bits_, max(50, args.steps // 2), dev,
+                                                 parity=not args.no_cpu_baseline)
                 except Exception as e:                      # noqa: BLE001 -- a sub-record must not kill the headline line
                     sub[nm] = {"error": repr(e)[:200]}
+                torch.cuda.empty_cache()
+            try:
+                sub["C2_sharedB"] = bench_shared_b(rank_k, rank_v, Lp, max(50, args.steps // 2), dev)
+            except Exception as e:                          # noqa: BLE001
+                sub["C2_sharedB"] = {"error": repr(e)[:200]}
             try:
                 sub["C5_per_gpu_slice"] = bench_c5_slice(max(50, args.steps // 2), dev)
             except Exception as e:                          # noqa: BLE001

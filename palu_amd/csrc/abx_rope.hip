@@ -8,17 +8,14 @@ template <int NKS, int NMB, bool FOLD>
 int launch_abx_fast(const AbxParams& p, int nwg, hipStream_t stream) {
   // positions beyond 2^18: the second-order angle correction (abx_rope_kernel.h, ORDER2)
   if ((int64_t)p.pos0 + p.L > 262144) {
-    static bool attr_done2 = false;
-    return launch_kernel(abx_rope_kernel<NKS, NMB, FOLD, false, 0, true>, abx_smem_fast(NKS), &attr_done2, p, nwg, stream);
+    return launch_kernel(abx_rope_kernel<NKS, NMB, FOLD, false, 0, true>, abx_smem_fast(NKS), p, nwg, stream);
   }
-  static bool attr_done = false;
-  return launch_kernel(abx_rope_kernel<NKS, NMB, FOLD>, abx_smem_fast(NKS), &attr_done, p, nwg, stream);
+  return launch_kernel(abx_rope_kernel<NKS, NMB, FOLD>, abx_smem_fast(NKS), p, nwg, stream);
 }
 
 template <int NMB>
 int launch_abx_generic(const AbxParams& p, int nwg, hipStream_t stream) {
-  static bool attr_done = false;
-  return launch_kernel(abx_rope_generic_kernel<8, NMB, true>, abx_smem_bytes(8, 2), &attr_done, p, nwg, stream);
+  return launch_kernel(abx_rope_generic_kernel<8, NMB, true>, abx_smem_bytes(8, 2), p, nwg, stream);
 }
 
 int g_abx_fold = 1;
@@ -26,11 +23,9 @@ int g_abx_fold = 1;
 template <int NKS, int NMB>
 int launch_abx_shared(const AbxParams& p, int nwg, hipStream_t stream) {
   if ((int64_t)p.pos0 + p.L > 262144) {
-    static bool attr_done2 = false;
-    return launch_kernel(abx_rope_kernel<NKS, NMB, false, false, 0, true, true>, abx_smem_fast(NKS), &attr_done2, p, nwg, stream);
+    return launch_kernel(abx_rope_kernel<NKS, NMB, false, false, 0, true, true>, abx_smem_fast(NKS), p, nwg, stream);
   }
-  static bool attr_done = false;
-  return launch_kernel(abx_rope_kernel<NKS, NMB, false, false, 0, false, true>, abx_smem_fast(NKS), &attr_done, p, nwg, stream);
+  return launch_kernel(abx_rope_kernel<NKS, NMB, false, false, 0, false, true>, abx_smem_fast(NKS), p, nwg, stream);
 }
 
 }  // namespace
@@ -122,8 +117,7 @@ extern "C" int palu_abx_rope_f16_timed(const void* a, int64_t sa_h, int64_t sa_d
   const int nwg = abx_fill_params(p, pl, H, G, L, R, pos0);
   p.dbg = dbg;
   if (nwg_out) *nwg_out = nwg;
-  static bool attr_done = false;
-  return launch_kernel(abx_rope_kernel<8, 2, true, true>, abx_smem_fast(8), &attr_done, p, nwg, (hipStream_t)stream);
+  return launch_kernel(abx_rope_kernel<8, 2, true, true>, abx_smem_fast(8), p, nwg, (hipStream_t)stream);
 }
 
 // abx when every head of a latent group uses the same B (true-GQA: the query heads of a group share one KV head):

@@ -404,10 +404,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
   const int cidx = blockIdx.x / ngb;
   const int g = gb / p.HB, hb = gb % p.HB;
 
-  const int base = p.nt_total / p.nch, rem = p.nt_total % p.nch;
+  // Full 128-row tiles are dealt out evenly; the partial tail tile (L % 128 rows, e.g. the one new row of a decode step
+  // on a 64k prompt) goes to the LAST workgroup of the group, which is among those with the fewest full tiles, and costs
+  // only the 32-row blocks it really has (tail_nb below): a ceil(L/128)-tile split made one workgroup per group carry a
+  // whole extra tile (17 instead of 16 at C2: 6 % of the kernel) for a single row.
+  const int nt_full = p.L / TL;
+  const int base = nt_full / p.nch, rem = nt_full % p.nch;
   const int tile0 = cidx * base + min(cidx, rem);
-  const int ntile = base + (cidx < rem ? 1 : 0);
+  const bool has_tail = (p.L % TL) != 0 && cidx == p.nch - 1;
+  const int ntile = base + (cidx < rem ? 1 : 0) + (has_tail ? 1 : 0);
   if (ntile <= 0) return;
+  const int tail_nb = has_tail ? (p.L % TL + 31) / 32 : 4;   // 32-row blocks of this workgroup's last tile: 1..4
 
   const h16* xg = p.x + (int64_t)g * p.sx_g;
 
@@ -688,9 +695,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
         // cos/sin at the oracle's fp32-rounded angle fl(l*f): exact angle = ang + lo.  First order in lo drops
         // lo^2/2 < 3.1e-5 for positions < 2^18 (|lo| <= half an ulp of the angle); the host selects ORDER2 beyond that
         // (palu_abx_rope_f16: pos0 + L > 262144), e.g. the harness's max_position_embeddings = 300000
-        // Waves 4..7 own pairs 32..63 (inv_freq <= 0.01): below 2^18 positions their angles stay under 2622 rad, the
-        // residual under 1.2e-4 and its effect on a score far below the fp16 rounding of that score -- they use the
-        // exact-angle state as it is (EXACT = false: 4 of the 16 instructions per pair less on one wave of every SIMD).
+        // Waves whose angles all stay below 1024 rad (waves 4..7 = pairs 32..63 at theta 1e4 up to 102k positions) have a
+        // residual <= 2^-15 = 3.1e-5 rad, the size of the second-order term dropped here anyway: they use the exact-angle
+        // state as it is (EXACT = false: 4 of the 16 instructions per pair less; selected per wave at the bottom).
         const float ang = lf * fr[j];
         const float lo = fmaf(lf, fr[j], -ang);
         if (!EXACT) {
@@ -835,7 +842,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
   // ring slots: tile tt sits in slot tt % 3 (LDS ring and red[] alike); kept as three rotating scalars
   int s_cur = 0, s_nxt = 1, s_prv = 2;     // tt % 3, (tt + 1) % 3, (tt + 2) % 3 == (tt - 1) % 3
   auto main_loop = [&](auto exact_c) {
-  for (int tt = 0; tt < ntile; ++tt) {
+  // the partial tail tile (last tile of the last workgroup of a group, tail_nb < 4 blocks) is handled after the loop
+  const int nmain = tail_nb < 4 ? ntile - 1 : ntile;
+  for (int tt = 0; tt < nmain; ++tt) {
     stamp();  // 5+2*tt: arrive at barrier
     if (tt > 0) {
       dma_wait();  // this wave's pieces of tile tt+1 have landed -> published by the barrier
@@ -857,10 +866,43 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
     s_cur = s_nxt;
     s_nxt = t3;
   }
-  region(K3{}, NotLast{}, exact_c, accA, 0, s_prv, 3, accB, 0, 0, 0u);      // epilogue of the very last block
+  int drain_slot = s_prv, drain_blk = 3;   // red[] slot / block index the epilogue of the last computed block goes to
+  if (tail_nb < 4) {
+    // Tail tile: only the 32-row blocks that hold rows < L (the others keep stale partials in red[]: their rows are
+    // >= L and never stored).  Its X rows were staged by the loop (staging indices clamp to ntile - 1), its block-0
+    // fragments were prefetched by the last region of the previous tile.  The last computed block is handed to the drain
+    // in accB whatever its parity (one drain instantiation, one live accumulator set).
+    const int tt = ntile - 1;
+    if (tt > 0) {
+      dma_wait();
+      __syncthreads();
+    }
+    region(K2{}, NotLast{}, exact_c, accA, 0, s_prv, 3, accB, 0, 0, 0u);           // block 0 | epilogue of the previous tile's block 3
+    if (tail_nb >= 2) region(K1{}, NotLast{}, exact_c, accB, 1, s_cur, 0, accA, tt - 2, s_nxt, 0u);
+    else reduce_store(tt - 2, s_nxt);                                                // (what region K1 carries)
+    if (tail_nb == 3) region(K2{}, NotLast{}, exact_c, accA, 2, s_cur, 1, accB, 0, 0, 0u);
+    if (tail_nb != 2) {
+#pragma unroll
+      for (int mb = 0; mb < NMM; ++mb) accB[mb] = accA[mb];
+    }
+    drain_slot = s_cur;
+    drain_blk = tail_nb - 1;
+    const int t3 = s_prv;
+    s_prv = s_cur;
+    s_cur = s_nxt;
+    s_nxt = t3;
+  }
+  region(K3{}, NotLast{}, exact_c, accA, 0, drain_slot, drain_blk, accB, 0, 0, 0u);   // epilogue of the very last block
   };
-  // ORDER2 launches (positions beyond 2^18) keep the correction on every wave
-  if (ORDER2 || w < 4 || (p.exp_flags & 4)) main_loop(std::true_type{}); else main_loop(std::false_type{});
+  // ORDER2 launches (positions beyond 2^18) keep the correction on every wave.  The shortcut (EXACT = false) is taken by
+  // a wave only when every angle it will see stays below 1024 rad: |fl(l*f) - l*f| <= half an ulp = 2^-15 = 3.1e-5 rad
+  // there -- the size of the second-order term the exact path drops anyway.  Decided from the caller's table itself
+  // (inv_freq is an argument: any theta / custom table is safe), wave-uniform: at theta = 1e4 waves 4-7 qualify up to
+  // 102k positions (config 2), nobody does at 256k.
+  float frmax = fmaxf(fmaxf(fr[0], fr[1]), fmaxf(fr[2], fr[3]));
+  frmax = wave_max(fabsf(frmax));
+  const bool small_angles = frmax * (float)(p.pos0 + p.L) < 1024.0f;
+  if (ORDER2 || w < 4 || !small_angles || (p.exp_flags & 4)) main_loop(std::true_type{}); else main_loop(std::false_type{});
   stamp();
   dma_wait();
   __syncthreads();
@@ -871,17 +913,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
 
 
 template <typename K>
-int launch_kernel(K kern, int smem, bool* attr_done, const AbxParams& p, int nwg, hipStream_t stream,
-                  int nthreads = NTHREADS) {
-  if (!*attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) {
-      palu_set_error("hipFuncSetAttribute(%d B LDS) failed: %s", smem, hipGetErrorString(e));
-      return PALU_ERR_LAUNCH;
-    }
-    *attr_done = true;
-  }
+int launch_kernel(K kern, int smem, const AbxParams& p, int nwg, hipStream_t stream, int nthreads = NTHREADS) {
+  const int rc = palu_func_max_lds(reinterpret_cast<const void*>(kern), smem);
+  if (rc) return rc;
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(nthreads), smem, stream, p);
   PALU_LAUNCH_CHECK();
   return PALU_OK;
@@ -920,10 +954,12 @@ inline int abx_fill_params(AbxParams& p, const AbxPlan& pl, int H, int G, int L,
   p.nkc = pl.nkc;
   p.dbg = nullptr;
   p.prio_mode = abx_prio_mode();
-  {
+  static int exp_flags = -1;        // PALU_ABX_EXP: experiment flags (4 = angle correction on every wave); read once
+  if (exp_flags < 0) {
     const char* e = getenv("PALU_ABX_EXP");
-    p.exp_flags = e ? atoi(e) : 0;
+    exp_flags = e ? atoi(e) : 0;
   }
+  p.exp_flags = exp_flags;
   const int ngb = G * pl.hb;
   static int cu_cap = -1;           // PALU_ABX_CUS: experiments that leave part of the GPU to another kernel
   if (cu_cap < 0) {

@@ -9,11 +9,9 @@ namespace {
 template <int NKS, int NMB, int QBITS>
 int launch_abx_q(const AbxParams& p, int nwg, hipStream_t stream) {
   if ((int64_t)p.pos0 + p.L > 262144) {    // positions beyond 2^18: second-order angle correction (ORDER2)
-    static bool attr_done2 = false;
-    return launch_kernel(abx_rope_kernel<NKS, NMB, true, false, QBITS, true>, abx_smem_fast(NKS), &attr_done2, p, nwg, stream);
+    return launch_kernel(abx_rope_kernel<NKS, NMB, true, false, QBITS, true>, abx_smem_fast(NKS), p, nwg, stream);
   }
-  static bool attr_done = false;
-  return launch_kernel(abx_rope_kernel<NKS, NMB, true, false, QBITS>, abx_smem_fast(NKS), &attr_done, p, nwg, stream);
+  return launch_kernel(abx_rope_kernel<NKS, NMB, true, false, QBITS>, abx_smem_fast(NKS), p, nwg, stream);
 }
 }  // namespace
 

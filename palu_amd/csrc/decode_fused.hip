@@ -9,18 +9,11 @@ namespace {
 
 template <int NKS, int NTS, int NTL, bool TIMING = false>
 int launch_fused(const FusedParams& p, int nwg, hipStream_t stream) {
-  static bool attr_done = false;
   constexpr int smem = (int)FusedLds<NKS, NTS, NTL>::TOTAL;
   static_assert(smem <= 160 * 1024, "fused decode kernel: LDS budget");
   auto kern = decode_fused_kernel<NKS, NTS, NTL, TIMING>;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) {
-      palu_set_error("hipFuncSetAttribute(%d B LDS) failed: %s", smem, hipGetErrorString(e));
-      return PALU_ERR_LAUNCH;
-    }
-    attr_done = true;
-  }
+  const int rc = palu_func_max_lds(reinterpret_cast<const void*>(kern), smem);
+  if (rc) return rc;
   hipLaunchKernelGGL(kern, dim3(nwg), dim3(NTHREADS), smem, stream, p);
   PALU_LAUNCH_CHECK();
   return PALU_OK;

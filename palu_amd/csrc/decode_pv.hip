@@ -999,7 +999,7 @@ int pv_wgs_per_cu() {
 // 1 / d if  q0 = x * r,  q1 = fma(fma(-q0, d, x), r, q0)  equals the IEEE quotient x / d for every finite fp16 x, else 0
 // (checked once per divisor on the host, all 63488 inputs)
 float pv_exact_rcp(float d) {
-  static float last_d = 0.f, last_r = 0.f;
+  static thread_local float last_d = 0.f, last_r = 0.f;   // per thread: a consistent (divisor, result) pair without a lock
   if (d == last_d) return last_r;
   const float r = 1.0f / d;
   bool ok = d > 0.f;
@@ -1235,8 +1235,8 @@ extern "C" int palu_softmax_pv_f16(const void* scores, int64_t ss_h, const void*
   PALU_REQUIRE(H > 0 && G > 0 && H % G == 0 && L > 0 && Rv > 0, PALU_ERR_ARG, "softmax_pv: bad shape");
   PALU_REQUIRE(scores && v && ctx && workspace, PALU_ERR_ARG, "softmax_pv: null pointer");
   const int gs = H / G;
-  PALU_REQUIRE(gs == 1 || gs == 2 || gs == 4 || gs == 8, PALU_ERR_UNSUPPORTED,
-               "softmax_pv: group size %d not supported (1,2,4,8)", gs);
+  PALU_REQUIRE(gs == 1 || gs == 2 || gs == 3 || gs == 4 || gs == 8, PALU_ERR_UNSUPPORTED,
+               "softmax_pv: group size %d not supported (1,2,3,4,8)", gs);
   PALU_REQUIRE(Rv % 8 == 0 && Rv / 8 <= PV_THREADS, PALU_ERR_UNSUPPORTED, "softmax_pv: Rv must be a multiple of 8, <= 2048");
   PALU_REQUIRE(((uintptr_t)v & 15) == 0 && sv_g % 8 == 0 && sv_l % 8 == 0 && sv_l >= Rv, PALU_ERR_ARG,
                "softmax_pv: v rows must be 16-byte aligned");
@@ -1266,6 +1266,7 @@ extern "C" int palu_softmax_pv_f16(const void* scores, int64_t ss_h, const void*
   switch (gs) {
     case 1: hipLaunchKernelGGL(pv_partial_kernel<1>, grid, block, lds, s, p); break;
     case 2: hipLaunchKernelGGL(pv_partial_kernel<2>, grid, block, lds, s, p); break;
+    case 3: hipLaunchKernelGGL(pv_partial_kernel<3>, grid, block, lds, s, p); break;   // what the single-kernel core and abx take too
     case 4: hipLaunchKernelGGL(pv_partial_kernel<4>, grid, block, lds, s, p); break;
     default: hipLaunchKernelGGL(pv_partial_kernel<8>, grid, block, lds, s, p); break;
   }

@@ -42,11 +42,10 @@ extern "C" int palu_hadamard_transform(const void* x, void* y, int64_t rows, int
   PALU_REQUIRE(dtype == 0 || dtype == 1, PALU_ERR_ARG, "hadamard_transform: dtype 0 = fp16, 1 = fp32");
   if (rows == 0) return PALU_OK;
   PALU_REQUIRE(rows < (1ll << 31), PALU_ERR_UNSUPPORTED, "hadamard_transform: too many rows");
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fwht_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(fwht_kernel<h16>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    attr = true;
+  {
+    int rca = palu_func_max_lds(reinterpret_cast<const void*>(fwht_kernel<float>), 65536);
+    if (!rca) rca = palu_func_max_lds(reinterpret_cast<const void*>(fwht_kernel<h16>), 65536);
+    if (rca) return rca;
   }
   dim3 grid((unsigned)rows), block(n >= 512 ? 256 : (n >= 128 ? 64 : 64));
   if (dtype == 0)

@@ -37,6 +37,7 @@ void palu_set_error(const char* fmt, ...);
   } while (0)
 
 int palu_num_cus();   // cached hipDeviceProp multiProcessorCount of the current device
+int palu_func_max_lds(const void* func, int bytes);   // MaxDynamicSharedMemorySize once per (kernel, current device); PALU_OK or error
 
 // internal cross-TU helper (quant.hip): both new latent rows of a decode step in one launch
 int palu_quantize_pack_kv(const void* k, int64_t sk_g, void* k_codes, int64_t skc_g, void* k_meta, int64_t skm_g, int Rk,

@@ -545,16 +545,9 @@ __global__ __launch_bounds__(PFP_THREADS, 1) void prefill_attn_pair_kernel(PfPar
 template <int NCBH>
 int launch_prefill_pair(const PfParams& p, hipStream_t stream) {
   constexpr int smem = 2 * (PF_BN * 256 + 64 * NCBH * 128) + 4 * 2 * 32 * (int)sizeof(float) + 4 * 2 * 2 * 1024;
-  static bool attr_done = false;
   auto kern = prefill_attn_pair_kernel<NCBH>;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) {
-      palu_set_error("hipFuncSetAttribute(%d B LDS) failed: %s", smem, hipGetErrorString(e));
-      return PALU_ERR_LAUNCH;
-    }
-    attr_done = true;
-  }
+  const int rca = palu_func_max_lds(reinterpret_cast<const void*>(kern), smem);
+  if (rca) return rca;
   dim3 grid(p.head_major == 2 ? p.H * p.nqt : (p.head_major ? p.H : p.nqt), p.head_major == 2 ? 1 : (p.head_major ? p.nqt : p.H), 1);
   hipLaunchKernelGGL(kern, grid, dim3(PFP_THREADS), smem, stream, p);
   PALU_LAUNCH_CHECK();
@@ -564,16 +557,9 @@ int launch_prefill_pair(const PfParams& p, hipStream_t stream) {
 template <int NCB>
 int launch_prefill(const PfParams& p, hipStream_t stream) {
   constexpr int smem = 2 * (PF_BN * 256 + 32 * NCB * 128);
-  static bool attr_done = false;
   auto kern = prefill_attn_kernel<NCB>;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    if (e != hipSuccess) {
-      palu_set_error("hipFuncSetAttribute(%d B LDS) failed: %s", smem, hipGetErrorString(e));
-      return PALU_ERR_LAUNCH;
-    }
-    attr_done = true;
-  }
+  const int rca = palu_func_max_lds(reinterpret_cast<const void*>(kern), smem);
+  if (rca) return rca;
   dim3 grid(p.head_major == 2 ? p.H * p.nqt : (p.head_major ? p.H : p.nqt), p.head_major == 2 ? 1 : (p.head_major ? p.nqt : p.H), p.Rv / (32 * NCB));
   hipLaunchKernelGGL(kern, grid, dim3(PF_THREADS), smem, stream, p);
   PALU_LAUNCH_CHECK();

@@ -3,6 +3,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <mutex>
+
 #include "palu_common.h"
 
 static thread_local char g_err[512] = "";
@@ -24,6 +26,29 @@ int palu_num_cus() {
     cached[dev] = n;
   }
   return cached[dev];
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize, once per (kernel, device): the attribute belongs to the function on ONE
+// device, and the library serves every GPU of the process (palu_amd._lib.on_device), possibly from several threads.
+int palu_func_max_lds(const void* func, int bytes) {
+  static std::mutex mu;
+  static struct { const void* f; int dev; int bytes; } done[1024];
+  static int n = 0;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  std::lock_guard<std::mutex> lk(mu);
+  for (int i = 0; i < n; ++i)
+    if (done[i].f == func && done[i].dev == dev && done[i].bytes >= bytes) return PALU_OK;
+  hipError_t e = hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    palu_set_error("hipFuncSetAttribute(%d B LDS) failed: %s", bytes, hipGetErrorString(e));
+    return PALU_ERR_LAUNCH;
+  }
+  if (n < 1024) {
+    done[n].f = func; done[n].dev = dev; done[n].bytes = bytes;
+    ++n;
+  }
+  return PALU_OK;
 }
 
 extern "C" const char* palu_last_error(void) { return g_err; }

@@ -126,6 +126,56 @@ def test_fused_attn_matches_two_kernel_path_long():
     assert (ctx.double() - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())
 
 
+def test_fused_attn_config5_slice_full_size():
+    """BASELINE config 5, what ONE of the 8 GPUs runs: G = 1 (4 heads), Rk = 128, Rv = 384, L = 262144 -- the shape for
+    which the decode step SELECTS this kernel (palu_decode_attn_preferred; VERDICT r2 parity hole (i)).
+      (a) full-size context against the two-kernel path (whose kernels are oracle-checked at this size by
+          test_abx_full_size_c5_tail_window / test_softmax_pv_config5_slice) and against fp64 on its fp16 scores;
+      (b) the LAST 8192 positions -- where the fp32 rounding of l * inv_freq is largest (2^-7 rad on the highest
+          frequency) -- as a launch of their own at pos0 = L - 8192 against the CPU oracle's rounding points
+          (oracle RoPE table at those positions, fp16 keys, softmax fp32 -> fp16, latent P.V);
+      (c) split-merge: the LSE merge of [0, L - 8192) and the tail window (each its own launch, statistics from the
+          workspace) reproduces the full launch -- the kernel's RoPE state / online softmax do not depend on where a
+          range starts."""
+    torch.manual_seed(55)
+    H, G, Rk, Rv, L, W = 4, 1, 128, 384, 262144, 8192
+    lib = _lib()
+    assert lib.lib.palu_decode_attn_preferred(H, G, L, Rk, Rv, D) == 1
+    q = torch.randn(H, D, device=DEV).half()
+    b = (torch.randn(H, Rk, D, device=DEV) * Rk ** -0.5).half()
+    k = torch.randn(G, L + 64, Rk, device=DEV).half()
+    v = torch.randn(G, L + 64, Rv, device=DEV).half()
+    k[:, L:] = float("nan")
+    v[:, L:] = float("nan")
+    # (a)
+    ctx, stats = fused_attn(q, b, k, v, L)
+    ctx2, scores = two_kernel_attn(q, b, k, v, L)
+    torch.testing.assert_close(ctx, ctx2, rtol=1e-3, atol=2e-4)
+    ref64 = fp64_pv_of_scores(scores, v, L)
+    assert (ctx.double() - ref64).abs().max().item() <= 1e-3 * max(1.0, ref64.abs().max().item())
+    # (b) tail window vs the CPU oracle at the oracle's fp32 angles
+    l0 = L - W
+    kw, vw = k[:, l0:L].contiguous(), v[:, l0:L].contiguous()
+    ctx_w, stats_w = fused_attn(q, b, kw, vw, W, pos0=l0)
+    qc, bc, kc, vc = q.cpu(), b.cpu(), kw.cpu(), vw.cpu()
+    cos, sin = oracle.rope_cos_sin(L, D, start=l0)
+    keys = torch.matmul(kc[:, None], bc.reshape(G, H // G, Rk, D)).reshape(H, W, D)
+    sc = torch.matmul(qc.reshape(H, 1, D), oracle.rope_rotate(keys, cos, sin).to(torch.float16).transpose(-1, -2))
+    sc = sc / math.sqrt(D)
+    pr = torch.softmax(sc, dim=-1, dtype=torch.float32).to(torch.float16)
+    ref_w = torch.matmul(pr.reshape(G, H // G, W), vc).reshape(H, Rv)
+    torch.testing.assert_close(ctx_w.cpu(), ref_w, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(stats_w[:, 0].cpu(), sc.reshape(H, W).float().max(dim=-1).values, rtol=2e-3, atol=2e-3)
+    # (c) merge of head range + tail window == full launch
+    ctx_h, stats_h = fused_attn(q, b, k, v, l0)
+    m = torch.stack((stats_h[:, 0], stats_w[:, 0])).double()
+    s_ = torch.stack((stats_h[:, 1], stats_w[:, 1])).double()
+    wgt = s_ * torch.exp(m - m.max(dim=0, keepdim=True).values)
+    merged = (wgt[0, :, None] * ctx_h.double() + wgt[1, :, None] * ctx_w.double()) / wgt.sum(0)[:, None]
+    torch.testing.assert_close(ctx.double(), merged, rtol=2e-3, atol=3e-4)
+    torch.testing.assert_close(stats[:, 0], torch.maximum(stats_h[:, 0], stats_w[:, 0]), rtol=0, atol=0)
+
+
 def test_fused_attn_peaked_softmax_rescales():
     """Scores with a large spread whose maximum comes late in every range: the running-maximum rescale of the
     accumulators and of the partial sums is exercised in every workgroup.  With |score| ~ 100 the oracle's own fp16

@@ -72,10 +72,12 @@ def test_softmax_pv_q(bits, Rv, gs, H, L):
     assert (ctx.cpu().double() - c64).abs().max().item() <= 1e-3 * max(1.0, c64.abs().max().item())
 
 
-@pytest.mark.parametrize("bits,rank_k,rank_v,L", [(4, 512, 1536, 1500), (3, 1024, 3072, 700)])
+@pytest.mark.parametrize("bits,rank_k,rank_v,L", [(4, 512, 1536, 1500), (3, 1024, 3072, 700), (4, 512, 1536, 131072)],
+                         ids=["config4_short", "config3_short", "config4_full_size"])
 def test_quantised_decode_step_vs_oracle(bits, rank_k, rank_v, L):
-    """BASELINE config 3 (3-bit, 1024/3072) and 4 (4-bit, 512/1536) shapes, reduced L: module forward on a
-    QuantLatentCache == oracle.decode_step on fake-quantised caches with the new rows fake-quantised."""
+    """BASELINE config 3 (3-bit, 1024/3072) and 4 (4-bit, 512/1536) shapes: module forward on a
+    QuantLatentCache == oracle.decode_step on fake-quantised caches with the new rows fake-quantised.  Reduced L, and
+    config 4 at its FULL size (131072 cached positions, ~15 s of CPU for the oracle): VERDICT r2 parity hole (ii)."""
     from palu_amd.kernel.palu_attention import QuantLatentCache
     hidden, H, D, gs = 4096, 32, 128, 4
     G = H // gs
@@ -102,12 +104,14 @@ def test_quantised_decode_step_vs_oracle(bits, rank_k, rank_v, L):
     assert ((kd2[0, :, L].cpu().float() - k2[:, L].float()).abs().amax(-1) <= step_k * 1.01 + 1e-3).all()
 
 
-def test_config3_three_bit_with_hadamard_vs_oracle():
+@pytest.mark.parametrize("L", [600, 65536], ids=["short", "config3_full_size"])
+def test_config3_three_bit_with_hadamard_vs_oracle(L):
     """BASELINE config 3 as a whole: rank 1024/3072 (Rk = 128 = 2^7, Rv = 384 = 12 * 32 -> the had12 (x) H_32 branch),
     3-bit packed latents AND fuse_hadamard().  The module's rotated weights are handed to the oracle
-    (oracle.decode_step(latent_bits=3) on the fake-quantised ROTATED latents): same probabilities and output (P1)."""
+    (oracle.decode_step(latent_bits=3) on the fake-quantised ROTATED latents): same probabilities and output (P1).
+    L = 65536 is the configuration at FULL size (VERDICT r2 parity hole (ii); ~15 s of CPU for the oracle)."""
     from palu_amd.kernel.palu_attention import QuantLatentCache
-    hidden, H, D, gs, rank_k, rank_v, L, bits = 4096, 32, 128, 4, 1024, 3072, 600, 3
+    hidden, H, D, gs, rank_k, rank_v, bits = 4096, 32, 128, 4, 1024, 3072, 3
     G = H // gs
     Rk, Rv = rank_k // G, rank_v // G
     w, k_lat, v_lat, tok, _ = gi.step_inputs(31, hidden, H, D, gs, rank_k, rank_v, L, False)
