@@ -20,7 +20,7 @@ from typing import Optional
 import torch
 from torch import nn
 
-from .kernel.palu_attention import LatentCache, LlamaPaluAttention, QuantLatentCache
+from .kernel.palu_attention import LatentCache, LlamaPaluAttention, QuantLatentCache, additive_mask
 
 try:                                   # transformers is an optional dependency of this bridge only
     from transformers.cache_utils import Cache as _HFCache
@@ -39,7 +39,8 @@ class PaluCacheHF(_HFCache):
             except TypeError:          # older Cache.__init__ without arguments
                 super().__init__()
         self.latent = LatentCache(capacity, headroom) if bits >= 16 else QuantLatentCache(bits, capacity, headroom)
-        self.bits = bits
+        self.bits, self._capacity, self._headroom = bits, capacity, headroom
+        self._mask_memo = None            # (mask identity, "is the plain causal mask") of the current forward pass
 
     # -- what transformers' model code asks a cache ------------------------------------------------------------
     def get_seq_length(self, layer_idx: int = 0) -> int:
@@ -63,7 +64,9 @@ class PaluCacheHF(_HFCache):
         raise RuntimeError("PaluCacheHF holds LATENT rows: it is updated by LlamaPaluAttention, not with reconstructed K/V")
 
     def reset(self):
-        self.latent = LatentCache() if self.bits >= 16 else QuantLatentCache(self.bits)
+        self.latent = (LatentCache(self._capacity, self._headroom) if self.bits >= 16
+                       else QuantLatentCache(self.bits, self._capacity, self._headroom))
+        self._mask_memo = None
 
     def __len__(self):
         return len(getattr(self.latent, "_state", {})) if hasattr(self.latent, "_state") else 0
@@ -83,17 +86,37 @@ class PaluAttentionHF(nn.Module):
                 past_key_values=None, position_ids: Optional[torch.LongTensor] = None, **kwargs):
         cache = past_key_values.latent if isinstance(past_key_values, PaluCacheHF) else past_key_values
         q_len = hidden_states.shape[1]
+        is_causal = None
+        if attention_mask is not None and attention_mask.dtype == torch.bool:
+            # transformers 5.x (sdpa / create_causal_mask) hands over BOOLEAN masks, True = attend: the module speaks the
+            # reference's additive convention (kernel/palu_attention.py:229-234), so convert first -- a bool mask cast to
+            # fp16 would add +1 to attended positions and mask nothing
+            attention_mask = additive_mask(attention_mask, hidden_states.dtype)
         if q_len == 1:
-            # one token attends to the whole cache: a mask of zeros carries no information; dropping it keeps the step on
-            # the un-masked kernels (an additive mask that really masks something is passed through)
-            if attention_mask is not None and not bool((attention_mask != 0).any()):
-                attention_mask = None
-        elif attention_mask is not None and attention_mask.dtype == torch.bool:
-            attention_mask = torch.zeros(attention_mask.shape, dtype=hidden_states.dtype, device=hidden_states.device
-                                         ).masked_fill_(~attention_mask, torch.finfo(hidden_states.dtype).min)
+            # one token attends to the whole cache.  The mask (if any) is passed through as it is: testing it for "all
+            # zeros" would be a device-to-host sync per layer and token, and is illegal under graph capture; an all-zero
+            # mask only selects the masked softmax kernel, it changes no result
+            pass
+        elif attention_mask is None:
+            is_causal = True               # the model is causal; without a mask tensor the module would apply none (:229)
+        else:
+            # a mask tensor may carry padding: let the module decide whether it is the plain causal one (flash kernel)
+            # or not (general path).  The test syncs, so it is done once per forward pass, not once per layer.
+            memo = getattr(past_key_values, "_mask_memo", None)
+            key = (attention_mask.data_ptr(), tuple(attention_mask.shape), attention_mask._version)
+            if memo is not None and memo[0] == key:
+                is_causal = memo[1]
+            else:
+                past = cache.get_seq_length(self.layer_idx) if cache is not None else 0
+                is_causal = bool(self.inner._mask_is_causal(attention_mask, q_len, past)) if attention_mask.shape[0] == 1 else False
+                if past_key_values is not None:
+                    try:
+                        past_key_values._mask_memo = (key, is_causal)
+                    except AttributeError:
+                        pass
         out, weights, _ = self.inner(hidden_states, attention_mask=attention_mask, position_ids=position_ids,
                                      past_key_value=cache, output_attentions=bool(kwargs.get("output_attentions", False)),
-                                     is_causal=True if q_len > 1 else None)
+                                     is_causal=is_causal)
         return out, weights
 
 

@@ -368,6 +368,14 @@ class HeadwiseLowRankModule(nn.Module):
 
 
 # --------------------------------------------------------------------------------- attention
+def additive_mask(mask: torch.Tensor, dtype) -> torch.Tensor:
+    """Additive form of an attention mask (kernel/palu_attention.py:229-234 adds it to the scores): boolean masks
+    (True = attend, what newer transformers releases build) become 0 / finfo(dtype).min; others are cast to `dtype`."""
+    if mask.dtype == torch.bool:
+        return torch.zeros(mask.shape, dtype=dtype, device=mask.device).masked_fill_(~mask, torch.finfo(dtype).min)
+    return mask if mask.dtype == dtype else mask.to(dtype)
+
+
 def _rotate_half(x):
     h = x.shape[-1] // 2
     return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
@@ -451,7 +459,7 @@ class LlamaPaluAttention(nn.Module):
         probs = torch.empty((1, H, 1, n + 1), dtype=hidden_states.dtype, device=dev) if output_attentions else None
         mask_ptr = 0
         if attention_mask is not None:
-            attention_mask = attention_mask.reshape(-1).to(hidden_states.dtype).contiguous()
+            attention_mask = additive_mask(attention_mask, hidden_states.dtype).reshape(-1).contiguous()
             mask_ptr = attention_mask.data_ptr()
         wq, vtk, vtv, wo = self.q_proj.weight, self.k_proj.VT.weight, self.v_proj.VT.weight, self.o_proj.weight
         x = hidden_states.reshape(-1)
@@ -495,7 +503,7 @@ class LlamaPaluAttention(nn.Module):
         probs = torch.empty((1, H, 1, n + 1), dtype=hidden_states.dtype, device=dev) if output_attentions else None
         mask_ptr = 0
         if attention_mask is not None:
-            attention_mask = attention_mask.reshape(-1).to(hidden_states.dtype).contiguous()
+            attention_mask = additive_mask(attention_mask, hidden_states.dtype).reshape(-1).contiguous()
             mask_ptr = attention_mask.data_ptr()
         wq, vtk, vtv, wo = self.q_proj.weight, self.k_proj.VT.weight, self.v_proj.VT.weight, self.o_proj.weight
         x = hidden_states.reshape(-1).contiguous()
@@ -664,6 +672,8 @@ class LlamaPaluAttention(nn.Module):
                 "with a layer index.")
         past = 0 if past_key_value is None else past_key_value.get_usable_length(q_len, self.layer_idx)
         kv_seq_len = q_len + past
+        if attention_mask is not None and attention_mask.dtype == torch.bool:
+            attention_mask = additive_mask(attention_mask, hidden_states.dtype)      # True = attend -> 0 / -max
         if attention_mask is not None and attention_mask.size() != (bsz, 1, q_len, kv_seq_len):
             raise ValueError(
                 f"Attention mask should be of size {(bsz, 1, q_len, kv_seq_len)}, but is {attention_mask.size()}")

@@ -440,6 +440,58 @@ def test_whole_llama_model_decodes_through_latent_caches():
     assert qc.get_seq_length() == 38 and torch.isfinite(o2.logits).all() and o.logits.shape == (1, 37, 128)
 
 
+def test_whole_llama_model_padded_prompt_default_sdpa():
+    """ADVICE r2 (palu_amd/hf.py): with a PADDED prompt transformers 5.x builds BOOLEAN masks (True = attend) under its
+    default sdpa implementation -- [1,1,q,kv] for the prompt, [1,1,1,kv] for every decode step.  The adapter must convert
+    them to the reference's additive convention (kernel/palu_attention.py:229-234) and must not take the causal flash
+    path for a mask that carries padding.  Full ranks: logits of the valid positions equal the vanilla model's."""
+    transformers = pytest.importorskip("transformers")
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from palu_amd.hf import PaluCacheHF, convert_llama_to_palu
+    import copy
+    torch.manual_seed(1)
+    cfg = LlamaConfig(vocab_size=128, hidden_size=512, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=4, head_dim=128, max_position_embeddings=512, rope_theta=10000.0,
+                      attention_bias=False, tie_word_embeddings=False)          # _attn_implementation: default (sdpa)
+    ref = LlamaForCausalLM(cfg).to(DEV, torch.float16).eval()
+    palu = convert_llama_to_palu(copy.deepcopy(ref), rank_k=512, rank_v=512, group_size=2)
+    T, pad = 29, 6
+    ids = torch.randint(0, 128, (1, T), device=DEV)
+    am = torch.ones(1, T, dtype=torch.long, device=DEV)
+    am[0, :pad] = 0                                                          # left-padded prompt
+    seen = []
+    inner = palu.model.layers[0].self_attn.inner
+    orig = inner.forward
+
+    def spy(*a, **k):
+        m = k.get("attention_mask")
+        seen.append((None if m is None else m.dtype, k.get("is_causal")))
+        return orig(*a, **k)
+    inner.forward = spy
+    cache = PaluCacheHF(bits=16)
+    with torch.no_grad():
+        r = ref(ids, attention_mask=am, use_cache=True)
+        p = palu(ids, attention_mask=am, past_key_values=cache, use_cache=True)
+    torch.testing.assert_close(p.logits[:, pad:].float(), r.logits[:, pad:].float(), rtol=3e-2, atol=3e-2)
+    assert seen[0] == (torch.float16, False)            # additive mask, NOT declared causal: padding columns are honoured
+    last_prompt = p.logits[:, -1].float().clone()
+    rc, tok = r.past_key_values, r.logits[:, -1:].argmax(-1)
+    for step in range(2):
+        am = torch.cat((am, torch.ones(1, 1, dtype=torch.long, device=DEV)), dim=1)
+        with torch.no_grad():
+            r = ref(tok, attention_mask=am, past_key_values=rc, use_cache=True)
+            p = palu(tok, attention_mask=am, past_key_values=cache, use_cache=True)
+        torch.testing.assert_close(p.logits.float(), r.logits.float(), rtol=3e-2, atol=3e-2)
+        assert seen[-1][0] == torch.float16 and cache.get_seq_length() == T + 1 + step
+        tok = r.logits[:, -1:].argmax(-1)
+    # the same prompt WITHOUT padding must differ (the mask really masked something)
+    with torch.no_grad():
+        r_nopad = ref(ids, use_cache=False)
+    assert (r_nopad.logits[:, -1].float() - last_prompt).abs().max() > 1e-3
+    cache.reset()
+    assert cache.get_seq_length() == 0
+
+
 def test_softmax_pv_fp16_rows_through_the_register_direct_kernel():
     """PALU_PV_DIRECT=1 routes plain fp16 latent rows through pv_partial_qr_kernel<..., 16, ...> (opt-in: DESIGN 4.4).
     The switch is read once per process, so the parametrised cases of test_softmax_pv are re-run in a child process."""
