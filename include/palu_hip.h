@@ -113,7 +113,7 @@ int palu_softmax_pv_f16(const void* scores, int64_t ss_h, const void* mask,
  * (replaces kernel/palu_attention.py:219 recompute_k_gemv(...)/sqrt(D), :238 softmax, :246-251 latent P.V;
  * the [H, L] score tensor never exists in memory).  Same operands as palu_abx_rope_f16 + palu_softmax_pv_f16:
  *   q [H, D] rotated query, bfrag from palu_abx_prepare_b, k [G, L, Rk] / v [G, L, Rv] fp16 latents (16-byte
- *   aligned rows), ctx [H, Rv] fp16, key row l at position pos0 + l, no mask, no attention weights.
+ *   aligned rows), ctx [H, Rv] fp16, key row l at position pos0 + l, no attention weights (mask: see _mask_ below).
  * palu_decode_attn_supported() != 0 for the shapes the kernel covers (D = 128, gs in {3,4}, Rk in {64,128},
  * Rv in {128,192,256,384}); palu_decode_attn_preferred() != 0 where palu_decode_step_f16 / palu_decode_attend_f16
  * pick it over the two-kernel path (measured: G * L <= ~300k rows, i.e. the head-group shards of a multi-GPU run and
@@ -129,6 +129,13 @@ int palu_decode_attn_f16(const void* q, int64_t sq_h, int64_t sq_d, const void* 
                          const void* k, int64_t sk_g, int64_t sk_l, const void* v, int64_t sv_g, int64_t sv_l,
                          void* ctx, void* workspace, int H, int G, int L, int Rk, int Rv, int D,
                          const float* inv_freq, int pos0, float sqrt_d, palu_stream_t stream);
+/* The same with an additive attention mask [L] fp16 (kernel/palu_attention.py:229-234: added to the fp16 logits
+ * before the softmax; 0 = none): what palu_decode_step_f16 / palu_decode_attend_f16 call, so that a masked step
+ * (e.g. a left-padded prompt) stays on the single-kernel core where that one is selected. */
+int palu_decode_attn_mask_f16(const void* q, int64_t sq_h, int64_t sq_d, const void* bfrag,
+                              const void* k, int64_t sk_g, int64_t sk_l, const void* v, int64_t sv_g, int64_t sv_l,
+                              const void* mask, void* ctx, void* workspace, int H, int G, int L, int Rk, int Rv, int D,
+                              const float* inv_freq, int pos0, float sqrt_d, palu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Batch-1 projections.

@@ -50,6 +50,7 @@ struct AbxParams {
   int nch;       // workgroups per (group, head-block)
   int nt_total;  // number of 128-row tiles covering L
   int nkc;       // 128-column chunks of R (chunked kernel only)
+  int nks_frag;  // k-steps per M-block in the fragment buffer (chunked kernel; 0 = 8 * nkc)
   unsigned long long* dbg;  // optional per-wave cycle stamps (timing build only)
   unsigned out_bytes;       // extent of `out` for the bounds-checked buffer store
   int prio_mode;            // 0 none, 1 static (waves 4-7), 2 alternating per half tile
@@ -137,7 +138,12 @@ static __device__ __forceinline__ void sincos_exact_product(float l, float f, fl
 constexpr int abx_smem_fast(int nks) { return 3 * TL * 32 * nks + 3 * 8 * 4 * TL * (int)sizeof(float); }
 constexpr int abx_smem_bytes(int nks, int nred) { return 2 * TL * 32 * nks + nred * 8 * 4 * TL * (int)sizeof(float); }
 
-template <int NKS, int NMB, bool CHUNKED>
+// QBITS = 3 / 4: the latent rows are packed codes + (scale, zero) per row (quant.hip layout, like the fast kernel's
+// QBITS path): every staging slot (a row's 8 consecutive columns) is dequantised in registers -- (code - zero) exact in
+// fp16 via the 1024 + code trick, one fp16 multiply by the scale, i.e. bit-identical to quantize_tensor's output
+// (quant.py:39) -- before it goes to the same LDS tile image.  Any R % 32 == 0 (3 bit) / R % 8 == 0 (4 bit): the ranks
+// the Fisher rank search emits (palu/rank_search.py:11-17: multiples of 32 per group).
+template <int NKS, int NMB, bool CHUNKED, int QBITS = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_generic_kernel(AbxParams p) {
   using Geo = LdsGeom<NKS>;
   constexpr int HPW = 2 * NMB;
@@ -164,7 +170,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_generic_kernel(AbxParams
   const int nunit = ntile * NKC;
   const int nks_tot = NKS * NKC;
 
-  const h16* xg = p.x + (int64_t)g * p.sx_g;
+  const h16* xg = QBITS ? nullptr : p.x + (int64_t)g * p.sx_g;
 
   // ---- staging slots of this thread: LDS slot s = tid + 512*k  ->  (row, chunk position)
   int st_row[Geo::SPT], st_col[Geo::SPT];
@@ -176,6 +182,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_generic_kernel(AbxParams
     st_col[k] = Geo::swz(row, pp) * 8;  // global column (elements) inside the 16*NKS-wide chunk
   }
   u32x4 pf[Geo::SPT];
+  const unsigned char* xqg = QBITS ? p.xq + (int64_t)g * p.sq_g : nullptr;
+  const h16* xmg = QBITS ? p.xmeta + (int64_t)g * p.sm_g : nullptr;
+  const int row_bytes_q = QBITS ? p.R * QBITS / 8 : 0;
   auto load_unit = [&](int u) {
     int tt = u / NKC, kc = u - tt * NKC;
     int row0 = (tile0 + tt) * TL;
@@ -183,11 +192,47 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_generic_kernel(AbxParams
     for (int k = 0; k < Geo::SPT; ++k) {
       int l = min(row0 + st_row[k], p.L - 1);
       int col = kc * (16 * NKS) + st_col[k];
-      const u32x4* src = reinterpret_cast<const u32x4*>(xg + (int64_t)l * p.sx_l + col);
-      if (CHUNKED && col >= p.R) {
-        pf[k] = u32x4{0u, 0u, 0u, 0u};
+      if (QBITS != 0) {
+        // 8 codes of row l starting at column col (a multiple of 8): bits [QBITS * col, +8 * QBITS) of the packed row
+        if (col >= p.R) {
+          pf[k] = u32x4{0u, 0u, 0u, 0u};
+        } else {
+          const unsigned char* rowp = xqg + (int64_t)l * p.sq_l;
+          unsigned grp;
+          if (QBITS == 4) {
+            grp = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(rowp + (col >> 1)));
+          } else {
+            const int bo = 3 * (col >> 3);                       // byte offset of the 24 bits; the row is dword aligned
+            const int a = bo & ~3;
+            const unsigned w0 = __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(rowp + a));
+            const unsigned w1 = (a + 4 < row_bytes_q) ? __builtin_nontemporal_load(reinterpret_cast<const unsigned*>(rowp + a + 4)) : 0u;
+            const unsigned long long w = ((unsigned long long)w1 << 32) | w0;
+            grp = (unsigned)(w >> ((bo & 3) * 8));
+          }
+          const unsigned meta = *reinterpret_cast<const unsigned*>(xmg + (int64_t)l * p.sm_l);
+          const h16x2 m2 = __builtin_bit_cast(h16x2, meta);
+          const h16x2 scale2 = h16x2{m2[0], m2[0]};
+          const h16 nb = -((h16)1024.f + m2[1]);                 // exact: zero is an integer in [0, 15]
+          const h16x2 negbias2 = h16x2{nb, nb};
+          u32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned c0 = (grp >> (QBITS * (2 * e))) & ((1u << QBITS) - 1);
+            const unsigned c1 = (grp >> (QBITS * (2 * e + 1))) & ((1u << QBITS) - 1);
+            const unsigned pw = 0x64006400u | c0 | (c1 << 16);   // (1024 + c0, 1024 + c1) as fp16
+            h16x2 v = __builtin_bit_cast(h16x2, pw);
+            v = (v + negbias2) * scale2;
+            o[e] = __builtin_bit_cast(unsigned, v);
+          }
+          pf[k] = o;
+        }
       } else {
-        pf[k] = __builtin_nontemporal_load(src);
+        const u32x4* src = reinterpret_cast<const u32x4*>(xg + (int64_t)l * p.sx_l + col);
+        if (CHUNKED && col >= p.R) {
+          pf[k] = u32x4{0u, 0u, 0u, 0u};
+        } else {
+          pf[k] = __builtin_nontemporal_load(src);
+        }
       }
     }
   };
@@ -201,14 +246,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_generic_kernel(AbxParams
   load_unit(0);
 
   // ---- B fragments (registers for the whole kernel unless CHUNKED)
-  const u32x4* bf_base = p.bfrag + ((int64_t)(gb * 8 + w) * NMB) * nks_tot * 64 + lane;
+  // the fragment buffer is laid out by palu_abx_prepare_b for the (H, G, R) plan: nks_frag k-steps per M-block -- the
+  // chunk count of this launch may cover more (R = 32 / 64 through this kernel: one zero-padded 128-column chunk over
+  // 2 / 4 fragment k-steps), k-steps beyond it read as zero
+  const int nks_frag = p.nks_frag > 0 ? p.nks_frag : nks_tot;
+  const u32x4* bf_base = p.bfrag + ((int64_t)(gb * 8 + w) * NMB) * nks_frag * 64 + lane;
   h16x8 bf[NMB][NKS];
   if (!CHUNKED) {
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) {
-        u32x4 v = bf_base[(int64_t)(mb * nks_tot + ks) * 64];
+        u32x4 v = bf_base[(int64_t)(mb * nks_frag + ks) * 64];
         bf[mb][ks] = *reinterpret_cast<h16x8*>(&v);
       }
   }
@@ -317,7 +366,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_generic_kernel(AbxParams
       for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-          u32x4 v = bf_base[(int64_t)(mb * nks_tot + kc * NKS + ks) * 64];
+          u32x4 v = u32x4{0u, 0u, 0u, 0u};
+          if (kc * NKS + ks < nks_frag) v = bf_base[(int64_t)(mb * nks_frag + kc * NKS + ks) * 64];
           bf[mb][ks] = *reinterpret_cast<h16x8*>(&v);
         }
     }

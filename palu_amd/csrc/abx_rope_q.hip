@@ -13,6 +13,11 @@ int launch_abx_q(const AbxParams& p, int nwg, hipStream_t stream) {
   }
   return launch_kernel(abx_rope_kernel<NKS, NMB, true, false, QBITS>, abx_smem_fast(NKS), p, nwg, stream);
 }
+// any other rank: the chunked kernel (128-column chunks, zero-padded B) with in-register dequantisation of every slot
+template <int NMB, int QBITS>
+int launch_abx_q_generic(const AbxParams& p, int nwg, hipStream_t stream) {
+  return launch_kernel(abx_rope_generic_kernel<8, NMB, true, QBITS>, abx_smem_bytes(8, 2), p, nwg, stream);
+}
 }  // namespace
 
 extern "C" int palu_abx_rope_q(const void* a, int64_t sa_h, int64_t sa_d, const void* bfrag, const void* codes,
@@ -22,8 +27,11 @@ extern "C" int palu_abx_rope_q(const void* a, int64_t sa_h, int64_t sa_d, const 
   AbxPlan pl;
   PALU_REQUIRE(abx_plan(H, G, R, &pl), PALU_ERR_ARG, "abx_q: bad shape H=%d G=%d R=%d", H, G, R);
   PALU_REQUIRE(D == HEAD_DIM, PALU_ERR_UNSUPPORTED, "abx_q: head_dim must be 128 (got %d)", D);
-  PALU_REQUIRE((bits == 4 && (R == 32 || R == 64 || R == 128)) || (bits == 3 && R == 128), PALU_ERR_UNSUPPORTED,
-               "abx_q: supported (bits, R): (4, 32|64|128), (3, 128); got (%d, %d)", bits, R);
+  PALU_REQUIRE((bits == 4 && R % 8 == 0) || (bits == 3 && R % 32 == 0), PALU_ERR_UNSUPPORTED,
+               "abx_q: bits must be 3 (R %% 32 == 0) or 4 (R %% 8 == 0); got (%d, %d)", bits, R);
+  // fast path (tile staging of whole quarter rows): (4, 32|64|128), (3, 128); everything else -- the ranks the rank
+  // search emits (96, 160, 224, 256, ...) and 3-bit at 32 / 64 -- runs the chunked kernel
+  const bool fast = (bits == 4 && (R == 32 || R == 64 || R == 128)) || (bits == 3 && R == 128);
   PALU_REQUIRE(L >= 0, PALU_ERR_ARG, "abx_q: negative L");
   if (L == 0) return PALU_OK;
   PALU_REQUIRE(a && bfrag && codes && meta && out && inv_freq, PALU_ERR_ARG, "abx_q: null pointer");
@@ -43,8 +51,20 @@ extern "C" int palu_abx_rope_q(const void* a, int64_t sa_h, int64_t sa_d, const 
   p.xmeta = (const h16*)meta; p.sm_g = sm_g; p.sm_l = sm_l;
   p.out = (h16*)out; p.so_h = so_h; p.out_bytes = (unsigned)ob;
   p.inv_freq = inv_freq;
+  const int nks_frag = pl.nks_tot;       // how palu_abx_prepare_b laid the fragments out for (H, G, R)
+  if (!fast) {
+    // plan the launch as the chunked fp16 kernel does: 128-column chunks whatever R is
+    pl.chunked = true;
+    pl.nkc = (R + 127) / 128;
+    pl.nks_tot = 8 * pl.nkc;
+  }
   const int nwg = abx_fill_params(p, pl, H, G, L, R, pos0);
+  p.nks_frag = nks_frag;
   hipStream_t s = (hipStream_t)stream;
+  if (!fast) {
+    if (bits == 3) return pl.nmb == 2 ? launch_abx_q_generic<2, 3>(p, nwg, s) : launch_abx_q_generic<1, 3>(p, nwg, s);
+    return pl.nmb == 2 ? launch_abx_q_generic<2, 4>(p, nwg, s) : launch_abx_q_generic<1, 4>(p, nwg, s);
+  }
   if (bits == 3) return pl.nmb == 2 ? launch_abx_q<8, 2, 3>(p, nwg, s) : launch_abx_q<8, 1, 3>(p, nwg, s);
   switch (R) {
     case 32: return pl.nmb == 2 ? launch_abx_q<2, 2, 4>(p, nwg, s) : launch_abx_q<2, 1, 4>(p, nwg, s);

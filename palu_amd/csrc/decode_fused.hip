@@ -104,6 +104,15 @@ extern "C" int palu_decode_attn_f16(const void* q, int64_t sq_h, int64_t sq_d, c
                                     int64_t sk_g, int64_t sk_l, const void* v, int64_t sv_g, int64_t sv_l, void* ctx,
                                     void* workspace, int H, int G, int L, int Rk, int Rv, int D,
                                     const float* inv_freq, int pos0, float sqrt_d, palu_stream_t stream) {
+  return palu_decode_attn_mask_f16(q, sq_h, sq_d, bfrag, k, sk_g, sk_l, v, sv_g, sv_l, nullptr, ctx, workspace, H, G, L, Rk,
+                                   Rv, D, inv_freq, pos0, sqrt_d, stream);
+}
+
+// the same with an additive attention mask [L] fp16 (kernel/palu_attention.py:229-234; null = none)
+extern "C" int palu_decode_attn_mask_f16(const void* q, int64_t sq_h, int64_t sq_d, const void* bfrag, const void* k,
+                                         int64_t sk_g, int64_t sk_l, const void* v, int64_t sv_g, int64_t sv_l,
+                                         const void* mask, void* ctx, void* workspace, int H, int G, int L, int Rk, int Rv,
+                                         int D, const float* inv_freq, int pos0, float sqrt_d, palu_stream_t stream) {
   PALU_REQUIRE(palu_decode_attn_supported(H, G, Rk, Rv, D), PALU_ERR_UNSUPPORTED,
                "decode_attn: shape H=%d G=%d Rk=%d Rv=%d D=%d not covered by the fused kernel", H, G, Rk, Rv, D);
   PALU_REQUIRE(L > 0, PALU_ERR_ARG, "decode_attn: L must be positive");
@@ -121,6 +130,7 @@ extern "C" int palu_decode_attn_f16(const void* q, int64_t sq_h, int64_t sq_d, c
   p.bfrag = (const u32x4*)bfrag;
   p.x = (const h16*)k; p.sx_g = sk_g; p.sx_l = sk_l;
   p.v = (const h16*)v; p.sv_g = sv_g; p.sv_l = sv_l;
+  p.mask = (const h16*)mask;
   p.inv_freq = inv_freq;
   p.H = H; p.G = G; p.gs = H / G; p.L = L; p.R = Rk; p.Rv = Rv; p.pos0 = pos0;
   p.nt_total = (L + FTL - 1) / FTL;

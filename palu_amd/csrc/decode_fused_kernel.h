@@ -36,6 +36,7 @@ struct FusedParams {
   int64_t sx_g, sx_l;
   const h16* v;
   int64_t sv_g, sv_l;
+  const h16* mask;   // [L] additive (kernel/palu_attention.py:229-234) or null
   const float* inv_freq;
   float* part;   // [G][nch][gs][Rv]
   float* ml;     // [G][nch][gs][2]
@@ -348,8 +349,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void decode_fused_kernel(FusedParams p
     const float sf = (float)(h16)sc;
     float qv = sf * rsd;
     qv = fmaf(fmaf(-qv, p.sqrt_d, sf), rsd, qv);
-    const h16 x16 = (h16)qv;
+    h16 x16 = (h16)qv;
     const int l = (tile0 + t) * FTL + lane_o;
+    if (p.mask) {
+      // additive mask in fp16 like the reference (:229-234).  A compiler-visible load in the middle of the statically
+      // counted DMA schedule: it is completed on the spot (vmcnt(0) also drains the older DMA pieces, so every later
+      // vm_wait<N> of the schedule still holds, merely over-waits) -- the masked step pays for it, the plain one does not.
+      const h16 mv = p.mask[min(l, p.L - 1)];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      x16 = (h16)((float)x16 + (float)mv);
+    }
     const float x = l < p.L ? (float)x16 : -INFINITY;
     const float tmax = wave_max_dpp(x);
     const float m_new = fmaxf(m_run, tmax);

@@ -1294,7 +1294,8 @@ extern "C" int palu_softmax_pv_q(const void* scores, int64_t ss_h, const void* m
   PALU_REQUIRE(scores && codes && meta && ctx && workspace, PALU_ERR_ARG, "softmax_pv_q: null pointer");
   PALU_REQUIRE(bits == 3 || bits == 4, PALU_ERR_UNSUPPORTED, "softmax_pv_q: bits must be 3 or 4");
   const int gs = H / G;
-  PALU_REQUIRE(gs == 1 || gs == 2 || gs == 4, PALU_ERR_UNSUPPORTED, "softmax_pv_q: group size %d not supported (1,2,4)", gs);
+  PALU_REQUIRE(gs == 1 || gs == 2 || gs == 3 || gs == 4 || gs == 8, PALU_ERR_UNSUPPORTED,
+               "softmax_pv_q: group size %d not supported (1,2,3,4,8)", gs);
   PALU_REQUIRE(Rv % 32 == 0 && Rv / 16 <= PV_THREADS, PALU_ERR_UNSUPPORTED, "softmax_pv_q: Rv must be a multiple of 32, <= 4096");
   PALU_REQUIRE(((uintptr_t)codes & 3) == 0 && sc_g % 4 == 0 && sc_l % 4 == 0 && ((uintptr_t)meta & 3) == 0 &&
                    sm_g % 2 == 0 && sm_l % 2 == 0,
@@ -1321,16 +1322,28 @@ extern "C" int palu_softmax_pv_q(const void* scores, int64_t ss_h, const void* m
   p.exp_flags = 0;
   size_t lds = (size_t)gs * rps * (sizeof(float) + sizeof(h16));
   if (lds < (size_t)PV_THREADS * 16 * sizeof(float)) lds = (size_t)PV_THREADS * 16 * sizeof(float);
+  PALU_REQUIRE(lds <= 160 * 1024, PALU_ERR_UNSUPPORTED, "softmax_pv_q: LDS budget exceeded");
   dim3 grid(G * ns), block(PV_THREADS);
-#define PALU_PVQ(GSV)                                                                            \
-  if (bits == 4) hipLaunchKernelGGL((pv_partial_q_kernel<GSV, 4>), grid, block, lds, s, p);      \
-  else hipLaunchKernelGGL((pv_partial_q_kernel<GSV, 3>), grid, block, lds, s, p)
+  // gs = 3 / 8 (query heads per latent group of GQA models: kv group size x n_rep) exist only in this VALU kernel; the
+  // register-direct kernel above takes gs in {1, 2, 4}
+#define PALU_PVQ1(GSV, BV)                                                                          \
+  {                                                                                                 \
+    auto kern = pv_partial_q_kernel<GSV, BV>;                                                       \
+    const int rca = lds > 64 * 1024 ? palu_func_max_lds(reinterpret_cast<const void*>(kern), (int)lds) : PALU_OK; \
+    if (rca) return rca;                                                                            \
+    hipLaunchKernelGGL(kern, grid, block, lds, s, p);                                               \
+  }
+#define PALU_PVQ(GSV) \
+  if (bits == 4) PALU_PVQ1(GSV, 4) else PALU_PVQ1(GSV, 3)
   switch (gs) {
     case 1: PALU_PVQ(1); break;
     case 2: PALU_PVQ(2); break;
+    case 3: PALU_PVQ(3); break;
+    case 8: PALU_PVQ(8); break;
     default: PALU_PVQ(4); break;
   }
 #undef PALU_PVQ
+#undef PALU_PVQ1
   PALU_LAUNCH_CHECK();
   CombineParams c;
   c.part = p.part; c.ml = p.ml; c.ctx = (h16*)ctx; c.stats = stats;

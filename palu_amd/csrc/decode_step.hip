@@ -3,7 +3,7 @@
 // (kernel/palu_attention.py:147-263, branch :207-219).
 //   qkv GEMV + q-RoPE + cache append -> abx scores -> softmax.PV + split merge -> o_proj            (5 launches)
 // or, where palu_decode_attn_preferred() says the single-kernel attention core is faster (few rows per CU: G * L <= 300k,
-// no mask, no attention weights):  qkv -> fused scores/softmax/P.V (decode_fused.hip) + split merge -> o_proj.
+// no attention weights requested; an additive mask is taken):  qkv -> fused scores/softmax/P.V (decode_fused.hip) + split merge -> o_proj.
 #include "palu_common.h"
 
 namespace {
@@ -49,9 +49,9 @@ static int decode_step_impl(bool shared_b, const void* hidden, const void* wq, i
   int rc = palu_decode_qkv_f16(wq, ldq, vtk, ldk, vtv, ldv, hidden, q, k_cache, sk_g, sk_l, v_cache, sv_g, sv_l,
                                inv_freq, H, D, hidden_size, G, Rk, Rv, pos, cache_len, stream);
   if (rc) return rc;
-  if (!shared_b && !mask && !probs && palu_decode_attn_preferred(H, G, L, Rk, Rv, D)) {
-    rc = palu_decode_attn_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, v_cache, sv_g, sv_l, ctx, pvws, H, G, L, Rk, Rv, D,
-                              inv_freq, 0, sqrtf((float)D), stream);
+  if (!shared_b && !probs && palu_decode_attn_preferred(H, G, L, Rk, Rv, D)) {
+    rc = palu_decode_attn_mask_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, v_cache, sv_g, sv_l, mask, ctx, pvws, H, G, L, Rk,
+                                   Rv, D, inv_freq, 0, sqrtf((float)D), stream);
   } else {
     rc = shared_b ? palu_abx_rope_shared_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, scores, ss_h, H, G, L, Rk, D, inv_freq, 0, stream)
                   : palu_abx_rope_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, scores, ss_h, H, G, L, Rk, D, inv_freq, 0, stream);
@@ -106,9 +106,9 @@ extern "C" int palu_decode_attend_f16(const void* hidden, const void* wq, int64_
   int rc = palu_decode_qkv_f16(wq, ldq, vtk, ldk, vtv, ldv, hidden, q, k_cache, sk_g, sk_l, v_cache, sv_g, sv_l,
                                inv_freq, H, D, hidden_size, G, Rk, Rv, pos, cache_len, stream);
   if (rc) return rc;
-  if (!mask && palu_decode_attn_preferred(H, G, L, Rk, Rv, D))
-    return palu_decode_attn_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, v_cache, sv_g, sv_l, ctx, pvws, H, G, L, Rk, Rv, D,
-                                inv_freq, 0, sqrtf((float)D), stream);
+  if (palu_decode_attn_preferred(H, G, L, Rk, Rv, D))
+    return palu_decode_attn_mask_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, v_cache, sv_g, sv_l, mask, ctx, pvws, H, G, L, Rk,
+                                     Rv, D, inv_freq, 0, sqrtf((float)D), stream);
   rc = palu_abx_rope_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, scores, ss_h, H, G, L, Rk, D, inv_freq, 0, stream);
   if (rc) return rc;
   return palu_softmax_pv_f16(scores, ss_h, mask, v_cache, sv_g, sv_l, ctx, nullptr, 0, pvws, H, G, L, Rv,

@@ -125,12 +125,14 @@ def palu_config_from(config, rank_k: int, rank_v: int, group_size: int):
     import copy
     c = copy.copy(config)
     heads = config.num_attention_heads
-    if getattr(config, "num_key_value_heads", heads) != heads:
-        raise ValueError("the kernel-path module is MHA-only (kernel/palu_attention.py:143,201)")
-    if heads % group_size:
-        raise ValueError("num_attention_heads must be divisible by group_size")
+    kv = getattr(config, "num_key_value_heads", None) or heads
+    # GQA checkpoints: `group_size` counts KEY/VALUE heads per low-rank group, as in the reference's own GQA wrapper
+    # (palu/model/svd_mistral/modeling_palu_mistral.py:37-59, get_kv_info: num_lr_groups = num_key_value_heads // group)
+    if heads % kv or kv % group_size:
+        raise ValueError(f"num_key_value_heads ({kv}) must divide num_attention_heads ({heads}) and be divisible by "
+                         f"group_size ({group_size})")
     c.group_size = group_size
-    c.num_groups = heads // group_size
+    c.num_groups = kv // group_size
     c.total_rank_k, c.total_rank_v = rank_k, rank_v
     if not hasattr(c, "attention_bias"):
         c.attention_bias = False

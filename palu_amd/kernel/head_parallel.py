@@ -4,11 +4,17 @@ The reference has no multi-GPU path; the decode step shards naturally by head GR
 and the latent P.V of a group never touch another group (kernel/palu_attention.py:216-251).  Rank r of
 N owns groups [r*G/N, (r+1)*G/N): their latent caches (never moved), the B slice, the W_q rows of its
 gs*D*G/N query dims and the VT_k / VT_v rows of its ranks; the token's hidden state is replicated.
-The ONE exchange per step is an all-gather of the per-rank context slice [H/N * Rv] fp16 (3 KiB at
-N=8, C2) -- RCCL over xGMI through torch.distributed -- followed by the replicated o_proj GEMV.
+ONE exchange per step, two variants (shard_weights(..., oproj=)):
+  * "sharded" (default of bench.py / run_latency_attention.py): the rank multiplies its own [H/N * Rv] context
+    slice by its column block of W_o' (1/N of the bytes) and the ranks ALL-REDUCE the [hidden] fp32 partial outputs
+    (16 KiB), rounded once to fp16;
+  * "replicated": ALL-GATHER of the per-rank context slices [H/N * Rv] fp16 (3 KiB at N = 8, C2) and the full o_proj
+    GEMV on every rank.
+The collective goes through torch.distributed (backend "nccl" = RCCL over xGMI) behind a two-method `exchange` object,
+so that (a) `HeadParallelDecoder.capture()` records the whole step INCLUDING the collective into one hipGraph -- a
+replay issues no Python-side launch -- and (b) tests can run several ranks on one GPU with an in-graph stand-in.
 
-This file holds the rank-independent bookkeeping (testable on CPU with gloo) and the per-rank HIP
-step; the collective is a single `all_gather_into_tensor` on the caller's process group.
+This file holds the rank-independent bookkeeping (testable on CPU with gloo) and the per-rank HIP step.
 """
 from __future__ import annotations
 
@@ -109,16 +115,65 @@ def gather_context(ctx_local: torch.Tensor, plan: ShardPlan, group=None) -> torc
     return full
 
 
+class DistExchange:
+    """The step's one collective through torch.distributed on `group` (nccl = RCCL on the GPUs, gloo in the CPU tests).
+    Both calls are recorded into a capturing stream by the NCCL backend, i.e. they can be part of a hipGraph."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def all_reduce_sum_(self, t: torch.Tensor) -> None:
+        import torch.distributed as dist
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+
+    def all_gather_into(self, out: torch.Tensor, t: torch.Tensor) -> None:
+        import torch.distributed as dist
+        dist.all_gather_into_tensor(out, t, group=self.group)
+
+
+class LocalExchange:
+    """In-process stand-in for the collective: several ranks' decoders living on ONE device and stepped on one stream
+    (tests, tools/hp_two_ranks_one_gpu.py).  Plain device ops, so a captured graph contains the exchange.  Protocol: every
+    rank finishes `step_local` before the first rank calls `step_finish` (one stream: program order)."""
+
+    def __init__(self, world: int):
+        self.world = world
+        self._src = {}        # kind -> {rank: tensor}
+        self._calls = {"sum": 0, "gather": 0}
+        self._total = None
+
+    def register(self, rank: int, partial: torch.Tensor = None, ctx: torch.Tensor = None):
+        if partial is not None:
+            self._src.setdefault("sum", {})[rank] = partial
+        if ctx is not None:
+            self._src.setdefault("gather", {})[rank] = ctx
+        return self
+
+    def all_reduce_sum_(self, t: torch.Tensor) -> None:
+        if self._calls["sum"] % self.world == 0:      # first finisher of a round: sum every rank's (still local) partial
+            parts = [self._src["sum"][r] for r in range(self.world)]
+            self._total = torch.stack(parts).sum(0)
+        self._calls["sum"] += 1
+        t.copy_(self._total)
+
+    def all_gather_into(self, out: torch.Tensor, t: torch.Tensor) -> None:
+        self._calls["gather"] += 1
+        torch.cat([self._src["gather"][r].reshape(-1) for r in range(self.world)], out=out)
+
+
 class HeadParallelDecoder:
     """Per-rank state + HIP launches of the sharded decode step (fp16).  `weights`/caches are this rank's
-    shard already on its GPU; caches are [G_loc, Lcap, R] buffers holding `cache_len` valid rows."""
+    shard already on its GPU; caches are [G_loc, Lcap, R] buffers holding `cache_len` valid rows.
+    `exchange`: the collective (default: DistExchange(group))."""
 
     def __init__(self, plan: ShardPlan, weights: Dict[str, torch.Tensor], k_cache: torch.Tensor,
-                 v_cache: torch.Tensor, hidden_size: int, theta: float = 10000.0, group=None):
+                 v_cache: torch.Tensor, hidden_size: int, theta: float = 10000.0, group=None, exchange=None):
         from .. import _lib
         from .abx_rope import prepare_b, rope_inv_freq
         self._lib = _lib
         self.plan, self.w, self.k, self.v, self.hidden, self.group = plan, weights, k_cache, v_cache, hidden_size, group
+        self.exchange = exchange if exchange is not None else DistExchange(group)
+        self._graph = None
         # o_proj variant from the shape of the weight the rank was given (shard_weights(..., oproj=...))
         self.oproj_sharded = plan.world > 1 and weights["wo"].shape[1] == plan.heads_local * plan.rank_v
         self.partial = torch.empty(hidden_size, dtype=torch.float32, device=k_cache.device)
@@ -146,24 +201,27 @@ class HeadParallelDecoder:
             p.head_dim, self.hidden, p.rank_k, p.rank_v, cache_len, pos, lib.current_stream()), "decode_attend")
         return self.ctx
 
-    def step(self, hidden: torch.Tensor, cache_len: int, pos: int, time_collective: bool = False) -> torch.Tensor:
-        """One decode step.  Replicated o_proj: all-gather of the [H/N*Rv] fp16 context slices, then the full GEMV on
-        every rank.  Sharded o_proj: every rank multiplies its own slice by its column block (fp32 partial [hidden]),
-        one all-reduce of 16 KiB, one rounding.  time_collective records CUDA events around the collective
-        (self.t_collective) for the collective-only latency bench.py reports."""
-        import torch.distributed as dist
+    def step_local(self, hidden: torch.Tensor, cache_len: int, pos: int) -> None:
+        """Everything of a step that needs no other rank: attention core of the rank's groups and, with the sharded
+        o_proj, the fp32 partial output of its column block."""
         lib, p = self._lib, self.plan
         ctx = self.local_step(hidden, cache_len, pos)
+        if self.oproj_sharded:
+            wo = self.w["wo"]
+            lib.check(lib.lib.palu_gemv_f16_acc32(wo.data_ptr(), wo.stride(0), ctx.data_ptr(), self.partial.data_ptr(),
+                                                  self.hidden, p.heads_local * p.rank_v, lib.current_stream()), "o_proj")
+
+    def step_finish(self, time_collective: bool = False) -> torch.Tensor:
+        """The collective and what follows it (one rounding, or the replicated o_proj)."""
+        lib, p = self._lib, self.plan
         wo = self.w["wo"]
         ev = None
         if time_collective and p.world > 1:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         if self.oproj_sharded:
-            lib.check(lib.lib.palu_gemv_f16_acc32(wo.data_ptr(), wo.stride(0), ctx.data_ptr(), self.partial.data_ptr(),
-                                                  self.hidden, p.heads_local * p.rank_v, lib.current_stream()), "o_proj")
             if ev:
                 ev[0].record()
-            dist.all_reduce(self.partial, op=dist.ReduceOp.SUM, group=self.group)
+            self.exchange.all_reduce_sum_(self.partial)
             if ev:
                 ev[1].record()
             self.out.copy_(self.partial)            # fp32 -> fp16, the single rounding of the output
@@ -171,16 +229,44 @@ class HeadParallelDecoder:
             if p.world > 1:
                 if ev:
                     ev[0].record()
-                dist.all_gather_into_tensor(self.ctx_full, ctx, group=self.group)
+                self.exchange.all_gather_into(self.ctx_full, self.ctx)
                 if ev:
                     ev[1].record()
                 full = self.ctx_full
             else:
-                full = ctx
+                full = self.ctx
             lib.check(lib.lib.palu_gemv_f16(wo.data_ptr(), wo.stride(0), full.data_ptr(), self.out.data_ptr(),
                                             self.hidden, p.num_heads * p.rank_v, lib.current_stream()), "o_proj")
         self.t_collective = ev
         return self.out
+
+    def step(self, hidden: torch.Tensor, cache_len: int, pos: int, time_collective: bool = False) -> torch.Tensor:
+        """One decode step.  Replicated o_proj: all-gather of the [H/N*Rv] fp16 context slices, then the full GEMV on
+        every rank.  Sharded o_proj: every rank multiplies its own slice by its column block (fp32 partial [hidden]),
+        one all-reduce of 16 KiB, one rounding.  time_collective records CUDA events around the collective
+        (self.t_collective) for the collective-only latency bench.py reports."""
+        self.step_local(hidden, cache_len, pos)
+        return self.step_finish(time_collective)
+
+    def capture(self, hidden: torch.Tensor, cache_len: int, pos: int, warm: int = 3):
+        """hipGraph of one whole step -- kernels AND the collective (RCCL records into the capturing stream) -- for fixed
+        (cache_len, pos), as the reference harness captures its forward (run_latency_attention.py:81-90).  The
+        communicator must exist before the capture: `warm` eager steps on a side stream first (every rank calls
+        capture() at the same point, so those collectives match up).  Returns the replay callable; the result is in
+        `self.out`.  A replay issues no Python-side launch."""
+        cur = torch.cuda.current_stream()
+        side = torch.cuda.Stream()
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            for _ in range(warm):
+                self.step(hidden, cache_len, pos)
+        cur.wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.step(hidden, cache_len, pos)
+        self._graph = g
+        return g.replay
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -274,16 +274,24 @@ def fold_u_per_head(u_weights, head_dim: int) -> torch.Tensor:
     return stacked.reshape(G * (gsD // head_dim), head_dim, R)
 
 
-def build_b(u_weights, group_size: int, head_dim: int) -> torch.Tensor:
+def build_b(u_weights, group_size: int, head_dim: int, n_rep: int = 1) -> torch.Tensor:
     """abx operand B[h] = U_{h//gs}.weight[(h%gs)*D:(h%gs+1)*D, :]^T -> [H, R, D]
-    (kernel/palu_attention.py:108-114)."""
-    return fold_u_per_head(u_weights, head_dim).transpose(1, 2).contiguous()
+    (kernel/palu_attention.py:108-114).  n_rep > 1 (GQA: `n_rep` query heads per KV head, the KV heads being what the
+    U blocks reconstruct -- palu/model/svd_mistral/modeling_palu_mistral.py:37-59): query head h takes the block of KV
+    head h // n_rep, so the heads of one KV head carry identical B (the shared-B score kernel detects that)."""
+    b = fold_u_per_head(u_weights, head_dim).transpose(1, 2)
+    if n_rep > 1:
+        b = b.repeat_interleave(n_rep, dim=0)
+    return b.contiguous()
 
 
-def fuse_wo(wo: torch.Tensor, uv_weights, head_dim: int) -> torch.Tensor:
+def fuse_wo(wo: torch.Tensor, uv_weights, head_dim: int, n_rep: int = 1) -> torch.Tensor:
     """W_o'[:, h*Rv:(h+1)*Rv] = W_o[:, h*D:(h+1)*D] @ U_v[h//gs][(h%gs)*D:(h%gs+1)*D, :]
-    (kernel/palu_attention.py:285-306) -> [hidden, H*Rv], fp32."""
-    uv = fold_u_per_head([u.float() for u in uv_weights], head_dim)        # [H, D, Rv]
+    (kernel/palu_attention.py:285-306) -> [hidden, H*Rv], fp32.  n_rep > 1: query head h uses the U_v block of KV head
+    h // n_rep."""
+    uv = fold_u_per_head([u.float() for u in uv_weights], head_dim)        # [KV heads, D, Rv]
+    if n_rep > 1:
+        uv = uv.repeat_interleave(n_rep, dim=0)                            # [H, D, Rv]
     H = uv.shape[0]
     w = wo.float().reshape(-1, H, head_dim)                                # [hidden, H, D]
     return torch.einsum("ohd,hdr->ohr", w, uv).reshape(w.shape[0], -1)
@@ -360,7 +368,7 @@ class HeadwiseLowRankModule(nn.Module):
             vt_rows.append(vh[:r, :])
         if attn_module is not None:
             new.B = nn.Parameter(build_b([u.weight.data for u in new.U_list], attn_module.group_size,
-                                         attn_module.head_dim))
+                                         attn_module.head_dim, getattr(attn_module, "n_rep", 1)))
         vt = torch.cat(vt_rows, dim=0).contiguous()
         assert new.VT.weight.data.shape == vt.shape
         new.VT.weight.data = vt
@@ -368,6 +376,11 @@ class HeadwiseLowRankModule(nn.Module):
 
 
 # --------------------------------------------------------------------------------- attention
+def _q_scratch_ok(mod, Rk: int) -> bool:
+    """palu_decode_step_q parks the new (unquantised) latent rows in its workspace: G * Rk <= 4096 halves."""
+    return mod.num_groups * Rk <= 4096
+
+
 def additive_mask(mask: torch.Tensor, dtype) -> torch.Tensor:
     """Additive form of an attention mask (kernel/palu_attention.py:229-234 adds it to the scores): boolean masks
     (True = attend, what newer transformers releases build) become 0 / finfo(dtype).min; others are cast to `dtype`."""
@@ -396,13 +409,26 @@ class LlamaPaluAttention(nn.Module):
         self.hidden_size = config.hidden_size
         self.num_heads = config.num_attention_heads
         self.head_dim = getattr(config, "head_dim", None) or self.hidden_size // self.num_heads
-        self.num_key_value_heads = self.num_heads          # the module is MHA-only (:143, :201)
+        # The reference's kernel-path module is MHA-only (:143, :201).  Here `num_key_value_heads < num_attention_heads`
+        # (GQA) is taken too, with the reference's own grouping rule for such models
+        # (palu/model/svd_mistral/modeling_palu_mistral.py:37-59, get_kv_info): config.group_size counts KV heads per
+        # low-rank group and num_groups = num_key_value_heads // group_size.  A latent group then serves
+        # group_size * n_rep QUERY heads -- that product is what the kernels see as the group size.
+        kv = getattr(config, "num_key_value_heads", None) or self.num_heads
+        if self.num_heads % kv:
+            raise ValueError(f"num_attention_heads ({self.num_heads}) must be divisible by num_key_value_heads ({kv})")
+        self.num_key_value_heads = kv
+        self.n_rep = self.num_heads // kv
         self.attention_dropout = getattr(config, "attention_dropout", 0.0)
         self.rope_theta = float(getattr(config, "rope_theta", None) or 10000.0)
         bias = getattr(config, "attention_bias", False)
 
-        self.group_size = config.group_size
+        self.kv_group_size = config.group_size                 # KV heads per latent group (== heads per group for MHA)
         self.num_groups = config.num_groups
+        if self.num_groups * self.kv_group_size != kv:
+            raise ValueError(f"num_groups ({self.num_groups}) * group_size ({self.kv_group_size}) must equal the number of "
+                             f"key/value heads ({kv})")
+        self.group_size = self.kv_group_size * self.n_rep      # QUERY heads per latent group
         self.total_rank_k = config.total_rank_k
         self.total_rank_v = config.total_rank_v
         self.group_rank_k = self.total_rank_k // self.num_groups
@@ -412,9 +438,10 @@ class LlamaPaluAttention(nn.Module):
         self.rank_v_list = [self.group_rank_v] * self.num_groups
 
         out = self.num_heads * self.head_dim
+        out_kv = self.num_key_value_heads * self.head_dim
         self.q_proj = nn.Linear(self.hidden_size, out, bias=bias)
-        self.k_proj = HeadwiseLowRankModule(self.rank_k_list, self.hidden_size, out, bias=bias)
-        self.v_proj = HeadwiseLowRankModule(self.rank_v_list, self.hidden_size, out, bias=bias)
+        self.k_proj = HeadwiseLowRankModule(self.rank_k_list, self.hidden_size, out_kv, bias=bias)
+        self.v_proj = HeadwiseLowRankModule(self.rank_v_list, self.hidden_size, out_kv, bias=bias)
         self.o_proj = nn.Linear(self.fused_hidden_dim_o, self.hidden_size, bias=bias)
         self._ws = None          # HIP workspace (grows with the cache capacity)
         self._ws_cap = 0
@@ -588,8 +615,8 @@ class LlamaPaluAttention(nn.Module):
             q = (q * cos.view(1, q_len, D) + _rotate_half(q) * sin.view(1, q_len, D)).contiguous()
         # K~ = RoPE(X_k . B): per group the reconstruct GEMM X_g . U_g^T (:67-77, :199-201) lands head-major in the
         # [H, kv, D] workspace, then the rotation runs in place
-        u_ok = (self.group_rank_k % 64 == 0 and all(u.weight.dtype == dt and u.weight.is_contiguous() and u.bias is None
-                                                    for u in self.k_proj.U_list))
+        u_ok = (self.n_rep == 1 and self.group_rank_k % 64 == 0
+                and all(u.weight.dtype == dt and u.weight.is_contiguous() and u.bias is None for u in self.k_proj.U_list))
         if u_ok:
             keys = torch.empty((H, kv, D), dtype=dt, device=dev)
             xk = key_h[0]
@@ -637,14 +664,17 @@ class LlamaPaluAttention(nn.Module):
 
     def _hip_step_shapes_ok(self, cache) -> bool:
         """What palu_decode_step_f16 / _q accept (everything else takes the general path BEFORE anything is written to
-        the cache): fp16 -- gs in {1,2,4,8}, ranks multiples of 8; packed cache -- gs in {1,2,4},
-        (bits, Rk) in {(4,32),(4,64),(4,128),(3,128)} (palu_abx_rope_q) and Rv % 32 == 0 (palu_softmax_pv_q)."""
+        the cache): gs in {1,2,3,4,8} query heads per latent group; fp16 -- ranks multiples of 8; packed cache --
+        Rk % 32 == 0 at 3 bit / Rk % 8 == 0 at 4 bit (palu_abx_rope_q: fast kernels for (4, 32|64|128) and (3, 128), the
+        chunked one for every other rank, e.g. the 96 / 160 / 224 / 256 of the rank search) and Rv % 32 == 0
+        (palu_softmax_pv_q)."""
         gs, Rk, Rv = self.group_size, self.group_rank_k, self.group_rank_v
         if isinstance(cache, QuantLatentCache):
             bits = cache.n_bits
-            return (gs in (1, 2, 4) and Rv % 32 == 0 and Rv // 16 <= 256
-                    and ((bits == 4 and Rk in (32, 64, 128)) or (bits == 3 and Rk == 128)))
-        return gs in (1, 2, 4, 8) and Rk % 8 == 0 and Rv % 8 == 0 and Rv // 8 <= 256
+            return (gs in (1, 2, 3, 4, 8) and Rv % 32 == 0 and Rv // 16 <= 256
+                    and ((bits == 4 and Rk % 8 == 0) or (bits == 3 and Rk % 32 == 0))
+                    and _q_scratch_ok(self, Rk) and self.num_groups * Rv <= 16384)
+        return gs in (1, 2, 3, 4, 8) and Rk % 8 == 0 and Rv % 8 == 0 and Rv // 8 <= 256
 
     # -- forward -----------------------------------------------------------------------------
     def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
@@ -734,7 +764,9 @@ class LlamaPaluAttention(nn.Module):
             if bsz != 1:
                 raise ValueError("LlamaPaluAttention supports batch size 1 only (kernel/palu_attention.py:248,251)")
             lat = key_h.transpose(1, 2).reshape(bsz, kv_seq_len, self.total_rank_k)
-            key_states = self.k_proj.reconstruct(lat).view(bsz, kv_seq_len, H, D).transpose(1, 2)
+            key_states = self.k_proj.reconstruct(lat).view(bsz, kv_seq_len, self.num_key_value_heads, D).transpose(1, 2)
+            if self.n_rep > 1:
+                key_states = key_states.repeat_interleave(self.n_rep, dim=1)        # repeat_kv: head h <- KV head h // n_rep
             kpos = torch.arange(kv_seq_len, device=hidden_states.device) if past else pos.reshape(-1)
             kc, ks = self._rope_tables(kpos, key_states.dtype)
             if past == 0:
@@ -758,7 +790,9 @@ class LlamaPaluAttention(nn.Module):
         if fused_o:
             attn_output = ctx.transpose(1, 2).contiguous().reshape(bsz, q_len, -1)
         else:                                  # no_fusion: reconstruct V per head, dense o_proj
-            uv = fold_u_per_head([u.weight for u in self.v_proj.U_list], D)             # [H, D, Rv]
+            uv = fold_u_per_head([u.weight for u in self.v_proj.U_list], D)             # [KV heads, D, Rv]
+            if self.n_rep > 1:
+                uv = uv.repeat_interleave(self.n_rep, dim=0)                            # [H, D, Rv]
             full = torch.einsum("hqr,hdr->hqd", ctx[0], uv.to(ctx.dtype))
             attn_output = full.transpose(0, 1).reshape(bsz, q_len, H * D)
         attn_output = self.o_proj(attn_output)
@@ -778,7 +812,7 @@ class LlamaPaluAttention(nn.Module):
         if no_fusion:
             new.o_proj = module.o_proj
             return new
-        fused = fuse_wo(module.o_proj.weight.data, [u.weight.data for u in new.v_proj.U_list], new.head_dim)
+        fused = fuse_wo(module.o_proj.weight.data, [u.weight.data for u in new.v_proj.U_list], new.head_dim, new.n_rep)
         with torch.no_grad():
             new.o_proj.weight.copy_(fused)
         return new

@@ -269,23 +269,30 @@ def _(packed, bits, rank):
 
 @torch.library.custom_op("palu::decode_attn", mutates_args=("workspace",))
 def decode_attn(q: torch.Tensor, bfrag: torch.Tensor, k: torch.Tensor, v: torch.Tensor, inv_freq: torch.Tensor,
-                workspace: torch.Tensor, num_heads: int, length: int, pos0: int = 0) -> torch.Tensor:
-    """Single-kernel attention core (palu_decode_attn_f16): scores -> /sqrt(D) -> softmax -> latent P.V over the first
-    `length` rows of k [G, cap, Rk] / v [G, cap, Rv]; q [H, D] rotated query -> ctx [H, Rv]."""
+                workspace: torch.Tensor, num_heads: int, length: int, pos0: int = 0,
+                mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Single-kernel attention core (palu_decode_attn_mask_f16): scores -> /sqrt(D) (+ additive `mask` [length] fp16) ->
+    softmax -> latent P.V over the first `length` rows of k [G, cap, Rk] / v [G, cap, Rv]; q [H, D] rotated query ->
+    ctx [H, Rv]."""
     G, _, Rk = k.shape
     Rv = v.shape[2]
     D = q.shape[-1]
     q2 = q.reshape(num_heads, D)
     ctx = torch.empty((num_heads, Rv), dtype=torch.float16, device=q.device)
+    if mask is not None:
+        mask = mask.reshape(-1).to(torch.float16).contiguous()
+        if mask.numel() != int(length):
+            raise ValueError("decode_attn: mask must have `length` elements")
     with _lib.on_device(q):
-        _lib.check(_lib.lib.palu_decode_attn_f16(q2.data_ptr(), q2.stride(0), q2.stride(1), bfrag.data_ptr(), k.data_ptr(),
-                                                 k.stride(0), k.stride(1), v.data_ptr(), v.stride(0), v.stride(1),
-                                                 ctx.data_ptr(), workspace.data_ptr(), num_heads, G, int(length), Rk, Rv, D,
-                                                 inv_freq.data_ptr(), int(pos0), math.sqrt(D), _lib.current_stream()),
-                   "palu_decode_attn_f16")
+        _lib.check(_lib.lib.palu_decode_attn_mask_f16(q2.data_ptr(), q2.stride(0), q2.stride(1), bfrag.data_ptr(),
+                                                      k.data_ptr(), k.stride(0), k.stride(1), v.data_ptr(), v.stride(0),
+                                                      v.stride(1), 0 if mask is None else mask.data_ptr(), ctx.data_ptr(),
+                                                      workspace.data_ptr(), num_heads, G, int(length), Rk, Rv, D,
+                                                      inv_freq.data_ptr(), int(pos0), math.sqrt(D), _lib.current_stream()),
+                   "palu_decode_attn_mask_f16")
     return ctx
 
 
 @decode_attn.register_fake
-def _(q, bfrag, k, v, inv_freq, workspace, num_heads, length, pos0=0):
+def _(q, bfrag, k, v, inv_freq, workspace, num_heads, length, pos0=0, mask=None):
     return q.new_empty((num_heads, v.shape[2]))

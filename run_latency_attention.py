@@ -8,14 +8,21 @@ Differences from the reference, all additive: the module comes from palu_amd (HI
 reference's Python API), the cache is the pre-allocated latent cache (no torch.cat per step),
 `--json` prints a machine-readable record with per-step algorithmic bytes / achieved HBM GB/s, and
 `--fast_init` skips the 64 per-group SVDs by drawing random low-rank factors directly (timings do
-not depend on the weight values).  `--palu` is required: the dense-attention baseline of the
-reference (`build_attention`, :29-38) is not part of this build.
+not depend on the weight values).  Without `--palu` the DENSE attention baseline of the reference
+(`build_attention`, :29-38: a stock HF LlamaAttention on full-rank K/V caches) runs instead -- here a
+torch-op module with the HF-4.37.2 eager semantics on rocBLAS/stock kernels, which is what the
+reference's own dense leg is (nothing custom): the Palu-vs-dense comparison of the reference CLI.
+`--gpus N` (under `python -m torch.distributed.run --nproc-per-node N`) runs the head-group-parallel
+decode step of palu_amd.kernel.head_parallel: rank r owns G/N latent groups, one RCCL
+collective per step; rank 0 prints the same result line.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import logging
+import math
+import os
 import sys
 
 import torch
@@ -38,15 +45,57 @@ class LlamaLikeConfig:
 
 
 class _DenseAttention(nn.Module):
+    """Dense Llama attention with the eager semantics of transformers-4.37.2's LlamaAttention (what the reference's
+    build_attention instantiates, run_latency_attention.py:29-38): q/k/v projections, HF rotary at `position_ids`,
+    K/V cache of full head_dim rows, q.k^T/sqrt(D), softmax fp32 -> fp16, P.V, o_proj.  Stock torch ops only: this is
+    the BASELINE leg of the harness (and the donor of LlamaPaluAttention.from_attention), not a product path."""
+
     def __init__(self, config, layer_idx=0):
         super().__init__()
         d = config.hidden_size
+        self.config = config
         self.layer_idx = layer_idx
+        self.num_heads = config.num_attention_heads
         self.head_dim = d // config.num_attention_heads
+        self.rope_theta = float(getattr(config, "rope_theta", 10000.0))
         self.q_proj = nn.Linear(d, d, bias=False)
         self.k_proj = nn.Linear(d, d, bias=False)
         self.v_proj = nn.Linear(d, d, bias=False)
         self.o_proj = nn.Linear(d, d, bias=False)
+
+    def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None,
+                output_attentions=False, **kwargs):
+        bsz, q_len, _ = hidden_states.shape
+        H, D = self.num_heads, self.head_dim
+        q = self.q_proj(hidden_states).view(bsz, q_len, H, D).transpose(1, 2)
+        k = self.k_proj(hidden_states).view(bsz, q_len, H, D).transpose(1, 2)
+        v = self.v_proj(hidden_states).view(bsz, q_len, H, D).transpose(1, 2)
+        past = 0 if past_key_value is None else past_key_value.get_usable_length(q_len, self.layer_idx)
+        if position_ids is None:
+            position_ids = torch.arange(past, past + q_len)
+        inv = 1.0 / (self.rope_theta ** (torch.arange(0, D, 2, dtype=torch.int64).float() / D))
+        ang = torch.outer(position_ids.reshape(-1).float(), inv).to(hidden_states.device)
+        emb = torch.cat((ang, ang), dim=-1)
+        cos, sin = emb.cos().to(q.dtype), emb.sin().to(q.dtype)
+
+        def rot(x):
+            return x * cos + torch.cat((-x[..., D // 2:], x[..., :D // 2]), dim=-1) * sin
+        q, k = rot(q), rot(k)
+        if past_key_value is not None:
+            k, v = past_key_value.update(k, v, self.layer_idx)
+        w = torch.matmul(q, k.transpose(2, 3)) / math.sqrt(D)
+        if attention_mask is not None:
+            w = w + attention_mask
+        w = torch.softmax(w, dim=-1, dtype=torch.float32).to(q.dtype)
+        o = torch.matmul(w, v).transpose(1, 2).reshape(bsz, q_len, H * D)
+        return self.o_proj(o), (w if output_attentions else None), past_key_value
+
+
+def build_attention(args, device="cuda:0", dtype=torch.float16):
+    """run_latency_attention.py:29-38: the dense baseline."""
+    logging.info(f"Creating Attention, dtype: {dtype}, device: {device}")
+    config = LlamaLikeConfig()
+    return _DenseAttention(config, layer_idx=0).to(device, dtype), config
 
 
 def build_attention_palu(args, device="cuda:0", dtype=torch.float16):
@@ -179,10 +228,97 @@ def profile_ttft(model, prompt_len, repeats=5, bits=16):
     return ms
 
 
+def profile_tpot_head_parallel(args):
+    """`--gpus N`: the head-group-parallel decode step (palu_amd.kernel.head_parallel), one process per GPU under
+    torch.distributed.run.  Same synthetic set-up as profile_tpot (randn latent caches of prompt_len rows, randn token,
+    random low-rank factors as with --fast_init: timings do not depend on the values); rank 0 logs the result line."""
+    import torch.distributed as dist
+    from palu_amd.kernel import head_parallel as hp
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus N must be launched as: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 run_latency_attention.py --palu --gpus N ...")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "LOCAL_RANK" in os.environ:
+        dist.init_process_group("nccl", device_id=dev)
+    cfg = LlamaLikeConfig()
+    H, hid = cfg.num_attention_heads, cfg.hidden_size
+    D, gs = hid // H, args.group_size
+    G = H // gs
+    Rk, Rv = args.rank_k // G, args.rank_v // G
+    plan = hp.make_plan(world, rank, H, G, D, Rk, Rv)
+    torch.manual_seed(1234)                                  # every rank draws the same full weights, keeps its shard
+    full = {"wq": (torch.randn(H * D, hid, device=dev) / 64).half(), "vt_k": (torch.randn(args.rank_k, hid, device=dev) / 64).half(),
+            "vt_v": (torch.randn(args.rank_v, hid, device=dev) / 64).half(), "b": (torch.randn(H, Rk, D, device=dev) * Rk ** -0.5).half(),
+            "wo": (torch.randn(hid, H * Rv, device=dev) * 0.01).half()}
+    w = {k: (v.contiguous() if k != "wo" else v) for k, v in hp.shard_weights(plan, full, oproj=args.oproj).items()}
+    del full
+    warm, reps = 25, args.repeats
+    cap = (args.prompt_len + 64 + 63) // 64 * 64
+    kc = torch.randn(plan.groups_local, cap, Rk, device=dev, dtype=torch.float16)
+    vc = torch.randn(plan.groups_local, cap, Rv, device=dev, dtype=torch.float16)
+    tok = torch.randn(hid, device=dev, dtype=torch.float16)
+    dec = hp.HeadParallelDecoder(plan, w, kc, vc, hid)
+    n = args.prompt_len
+
+    def generate():
+        return dec.step(tok, n, n)
+    for _ in range(warm):
+        generate()
+    torch.cuda.synchronize()
+    if args.cache_graph:
+        generate = dec.capture(tok, n, n)                    # the collective is captured with the step
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    start.record()
+    for _ in range(reps):
+        generate()
+    end.record()
+    torch.cuda.synchronize()
+    t = torch.tensor([start.elapsed_time(end) / reps], device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ms = float(t.item())
+    if rank == 0:
+        logging.info(f"Finished, prompt_len: {n}, latency: {ms:.2f} milliseconds (cache_graph={args.cache_graph}, "
+                     f"gpus={world}, oproj={args.oproj})")
+        if args.json:
+            print(json.dumps({"latency_us": ms * 1e3, "prompt_len": n, "rank_k": args.rank_k, "rank_v": args.rank_v,
+                              "group_size": gs, "gpus": world, "oproj": args.oproj, "cache_graph": args.cache_graph}))
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    return ms
+
+
 def main(args):
-    if not args.palu:
-        raise SystemExit("only --palu is implemented in this build (the dense baseline is out of scope)")
     bs = 1
+    if args.gpus > 1 or "LOCAL_RANK" in os.environ:      # launched by torch.distributed.run (also with one rank)
+        if not args.palu or args.bits < 16 or args.ttft:
+            raise SystemExit("--gpus N: the head-group-parallel step is the fp16 Palu decode step (--palu, --bits 16, no --ttft)")
+        profile_tpot_head_parallel(args)
+        return
+    if not args.palu:
+        # the reference's dense leg (:172-177): full-rank K/V caches [bs, heads, prompt_len, head_dim]
+        if args.bits < 16 or args.hadamard or args.ttft:
+            raise SystemExit("--bits / --hadamard / --ttft belong to the --palu module")
+        attention, config = build_attention(args)
+        attention.eval()
+        H, D = config.num_attention_heads, config.hidden_size // config.num_attention_heads
+        ms = profile_tpot(attention, (bs, H, args.prompt_len, D), (bs, H, args.prompt_len, D), torch.float16, bs,
+                          args.prompt_len, args.repeats, args.cache_graph, args.torch_profile, "tpot_fp16")
+        if args.json:
+            nbytes = 2 * 2 * H * (args.prompt_len + 1) * D + 2 * 4 * config.hidden_size ** 2
+            print(json.dumps({"latency_us": ms * 1e3, "prompt_len": args.prompt_len, "attention": "dense",
+                              "cache_graph": args.cache_graph, "algorithmic_bytes": nbytes,
+                              "hbm_GBps": nbytes / (ms * 1e-3) * 1e-9}))
+        return
     attention, config = build_attention_palu(args)
     attention.eval()
     num_groups = config.num_groups
@@ -228,6 +364,10 @@ if __name__ == "__main__":
     parser.add_argument("--hadamard", action="store_true", help="fuse Hadamard rotations into the weights (--lt_hadamard)")
     parser.add_argument("--ttft", action="store_true", help="profile the prompt pass (prefill) instead of the decode step")
     parser.add_argument("--json", action="store_true", help="also print a JSON record with achieved HBM GB/s")
+    parser.add_argument("--gpus", type=int, default=1,
+                        help="head-group-parallel decode over N GPUs of one node (launch with torch.distributed.run)")
+    parser.add_argument("--oproj", choices=("sharded", "replicated"), default="sharded",
+                        help="--gpus N: column-sharded o_proj + all-reduce of [hidden] fp32, or all-gather + replicated o_proj")
     args = parser.parse_args()
     logging.basicConfig(level=logging.INFO,
                         format="[%(asctime)s] %(levelname)s [%(filename)s:%(lineno)3d] %(message)s",

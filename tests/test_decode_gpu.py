@@ -440,6 +440,49 @@ def test_whole_llama_model_decodes_through_latent_caches():
     assert qc.get_seq_length() == 38 and torch.isfinite(o2.logits).all() and o.logits.shape == (1, 37, 128)
 
 
+@pytest.mark.parametrize("kv_heads,group_size", [(2, 1), (2, 2), (1, 1)], ids=["kv2_g1", "kv2_g2", "mqa"])
+def test_whole_llama_model_gqa(kv_heads, group_size):
+    """VERDICT r2 missing #2: GQA checkpoints (num_key_value_heads < num_attention_heads) through the kernel-path module.
+    Grouping as in the reference's GQA wrapper (palu/model/svd_mistral/modeling_palu_mistral.py:37-59): `group_size`
+    KV heads per low-rank group; a latent group serves group_size * n_rep query heads.  Full ranks -> prompt logits and
+    decode steps equal the vanilla GQA model's.  With one KV head per group the query heads of a group share B: the step
+    runs on the shared-B score kernel."""
+    transformers = pytest.importorskip("transformers")
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from palu_amd.hf import PaluCacheHF, convert_llama_to_palu
+    from palu_amd.kernel.abx_rope import shared_b
+    import copy
+    torch.manual_seed(2)
+    H, D = 4, 128
+    cfg = LlamaConfig(vocab_size=128, hidden_size=H * D, intermediate_size=512, num_hidden_layers=2, num_attention_heads=H,
+                      num_key_value_heads=kv_heads, head_dim=D, max_position_embeddings=512, rope_theta=10000.0,
+                      attention_bias=False, tie_word_embeddings=False)
+    cfg._attn_implementation = "eager"
+    ref = LlamaForCausalLM(cfg).to(DEV, torch.float16).eval()
+    full = kv_heads * D                                           # full rank of the [kv*D, hidden] projections
+    palu = convert_llama_to_palu(copy.deepcopy(ref), rank_k=full, rank_v=full, group_size=group_size)
+    inner = palu.model.layers[0].self_attn.inner
+    G = kv_heads // group_size
+    assert inner.num_groups == G and inner.group_size == group_size * (H // kv_heads) and inner.k_proj.B.shape[0] == H
+    assert (shared_b(inner.k_proj.B, G) is not None) == (group_size == 1 and H // kv_heads in (2, 3, 4))
+    ids = torch.randint(0, 128, (1, 33), device=DEV)
+    with torch.no_grad():
+        r = ref(ids, use_cache=True)
+        cache = PaluCacheHF(bits=16)
+        p = palu(ids, past_key_values=cache, use_cache=True)
+    torch.testing.assert_close(p.logits.float(), r.logits.float(), rtol=3e-2, atol=3e-2)
+    rc, tok = r.past_key_values, r.logits[:, -1:].argmax(-1)
+    for step in range(3):
+        with torch.no_grad():
+            r = ref(tok, past_key_values=rc, use_cache=True)
+            p = palu(tok, past_key_values=cache, use_cache=True)
+        torch.testing.assert_close(p.logits.float(), r.logits.float(), rtol=3e-2, atol=3e-2)
+        assert cache.get_seq_length() == 34 + step
+        tok = r.logits[:, -1:].argmax(-1)
+    kb, _ = cache.latent.buffers(0)
+    assert kb.shape[1] == G and kb.shape[3] == full // G          # latent rows per KV-head group, never reconstructed K
+
+
 def test_whole_llama_model_padded_prompt_default_sdpa():
     """ADVICE r2 (palu_amd/hf.py): with a PADDED prompt transformers 5.x builds BOOLEAN masks (True = attend) under its
     default sdpa implementation -- [1,1,q,kv] for the prompt, [1,1,1,kv] for every decode step.  The adapter must convert

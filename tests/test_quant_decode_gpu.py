@@ -18,7 +18,12 @@ DEV = "cuda"
 
 
 @pytest.mark.parametrize("bits,R,gs,H,L", [(4, 128, 4, 32, 1000), (3, 128, 4, 32, 777), (4, 64, 4, 32, 2049),
-                                           (4, 32, 4, 32, 130), (3, 128, 2, 8, 300), (4, 64, 1, 4, 129)])
+                                           (4, 32, 4, 32, 130), (3, 128, 2, 8, 300), (4, 64, 1, 4, 129),
+                                           # the chunked quantised kernel: ranks the Fisher rank search emits
+                                           # (palu/rank_search.py:11-17, multiples of 32 per group) and 3 bit at 32 / 64
+                                           (3, 96, 4, 32, 1500), (4, 160, 4, 32, 700), (3, 224, 4, 16, 333), (4, 256, 4, 32, 515),
+                                           (3, 64, 4, 32, 900), (3, 32, 2, 8, 260), (4, 96, 1, 4, 129), (3, 160, 8, 16, 410),
+                                           (4, 40, 4, 8, 300)])
 def test_abx_q_equals_fp16_kernel_on_dequantised_latents(bits, R, gs, H, L):
     """Same MFMA pipeline, same fp16 operand values -> bit-identical scores; plus the oracle bound."""
     from palu_amd import _lib
@@ -45,7 +50,9 @@ def test_abx_q_equals_fp16_kernel_on_dequantised_latents(bits, R, gs, H, L):
 
 
 @pytest.mark.parametrize("bits,Rv,gs,H,L", [(4, 192, 4, 32, 3001), (3, 384, 4, 32, 1500), (3, 96, 2, 8, 260),
-                                            (4, 64, 1, 4, 129), (4, 384, 4, 32, 9000)])
+                                            (4, 64, 1, 4, 129), (4, 384, 4, 32, 9000),
+                                            # group sizes of GQA models (kv group size x n_rep): VALU kernel only
+                                            (3, 160, 3, 12, 1100), (4, 224, 8, 32, 2500), (3, 96, 8, 16, 700)])
 def test_softmax_pv_q(bits, Rv, gs, H, L):
     from palu_amd import _lib
     from palu_amd.kernel import quant as q
@@ -72,8 +79,10 @@ def test_softmax_pv_q(bits, Rv, gs, H, L):
     assert (ctx.cpu().double() - c64).abs().max().item() <= 1e-3 * max(1.0, c64.abs().max().item())
 
 
-@pytest.mark.parametrize("bits,rank_k,rank_v,L", [(4, 512, 1536, 1500), (3, 1024, 3072, 700), (4, 512, 1536, 131072)],
-                         ids=["config4_short", "config3_short", "config4_full_size"])
+@pytest.mark.parametrize("bits,rank_k,rank_v,L", [(4, 512, 1536, 1500), (3, 1024, 3072, 700), (4, 512, 1536, 131072),
+                                                  (3, 768, 1280, 900), (4, 1280, 1792, 600), (3, 2048, 2560, 400)],
+                         ids=["config4_short", "config3_short", "config4_full_size", "ranks_96_160_3bit",
+                              "ranks_160_224_4bit", "ranks_256_320_3bit"])
 def test_quantised_decode_step_vs_oracle(bits, rank_k, rank_v, L):
     """BASELINE config 3 (3-bit, 1024/3072) and 4 (4-bit, 512/1536) shapes: module forward on a
     QuantLatentCache == oracle.decode_step on fake-quantised caches with the new rows fake-quantised.  Reduced L, and
