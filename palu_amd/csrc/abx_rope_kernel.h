@@ -557,16 +557,28 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
     }
   };
 
-  if (QBITS == 0) {
-    dma_tile(0, 0);
-    dma_tile(min(1, ntile - 1), 1);
-  } else {
-    load_q(0);
-    store_q(0);
-    load_q(min(1, ntile - 1));
-    store_q(1);
-    load_q(min(2, ntile - 1));
-  }
+  // Prologue order (PALU_ABX_B_FIRST): the B fragments go out BEFORE the first X tiles.  Loads return in issue order, and
+  // the fold below consumes the fragments one by one as they land: with the fragments first, the ~600 VALU operations of
+  // fold + RoPE initialisation run underneath the rest of the prologue's 192 KB of ingest instead of after it.
+#ifndef PALU_ABX_B_FIRST
+#define PALU_ABX_B_FIRST 1
+#endif
+#ifndef PALU_ABX_PIN_PROLOGUE
+#define PALU_ABX_PIN_PROLOGUE 1
+#endif
+  auto first_tiles = [&]() {
+    if (QBITS == 0) {
+      dma_tile(0, 0);
+      dma_tile(min(1, ntile - 1), 1);
+    } else {
+      load_q(0);
+      store_q(0);
+      load_q(min(1, ntile - 1));
+      store_q(1);
+      load_q(min(2, ntile - 1));
+    }
+  };
+  if (!PALU_ABX_B_FIRST || QBITS != 0) first_tiles();
 
   // ---- B fragments (issued early; consumed by the fold / first MFMA)
   const u32x4* bf_base = p.bfrag + ((int64_t)(gb * 8 + w) * NMM) * NKS * 64 + lane;
@@ -578,6 +590,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
       u32x4 v = bf_base[(int64_t)(mb * NKS + ks) * 64];
       bf[mb][ks] = *reinterpret_cast<h16x8*>(&v);
     }
+  if (PALU_ABX_B_FIRST && QBITS == 0) first_tiles();
 
   stamp();  // 1: B loads issued
   // ---- RoPE state of this lane (C layout: position n, pairs i = 8w + 2j + hi), started one block
@@ -589,6 +602,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
     fr[j] = p.inv_freq[8 * w + 2 * j + hi];
     sincos_exact_product(lf, fr[j], &sn[j], &cs[j]);
     sincos_exact_product(32.0f, fr[j], &rs[j], &rc[j]);
+#if PALU_ABX_PIN_PROLOGUE
+    // pin: left alone, hipcc sinks this arithmetic (fp64 reductions included) and most of the fold below BEHIND the
+    // barrier that publishes the first tiles -- ~640 VALU operations per wave on the critical path of every workgroup,
+    // serialised between the two waves of a SIMD (tools/time_abx.py: first barrier left at 14.7k / 19.9k ticks instead
+    // of ~10k).  An empty asm that takes the values as read-write operands makes them exist here, i.e. while the
+    // prologue's loads are still in flight.
+    asm volatile("" : "+v"(sn[j]), "+v"(cs[j]), "+v"(rs[j]), "+v"(rc[j]));
+#endif
   }
   stamp();  // 2: rope init done
   // ---- query: either folded into the fragments (FOLD) or kept per (pair, head) for the epilogue
@@ -630,6 +651,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
           res[e] = __builtin_bit_cast(unsigned, r2);
         }
         bf[mb][ks] = __builtin_bit_cast(h16x8, res);
+#if PALU_ABX_PIN_PROLOGUE
+        asm volatile("" : "+v"(bf[mb][ks]));      // folded here, fragment by fragment as the loads land (see above)
+#endif
       }
     }
   } else if (!SHARED) {

@@ -43,7 +43,14 @@ def test_abx_q_equals_fp16_kernel_on_dequantised_latents(bits, R, gs, H, L):
                                         codes.stride(0), codes.stride(1), meta.data_ptr(), meta.stride(0), meta.stride(1),
                                         out.data_ptr(), out.stride(0), H, G, L, R, 128, bits, inv.data_ptr(), 0,
                                         _lib.current_stream()), "abx_q")
-    assert torch.equal(out, ref)
+    # same kernel class on both sides (fast/fast or chunked/chunked) -> the same MFMA stream on the same fp16 operands:
+    # bit-identical.  3 bit at R = 32 / 64 has no fast quantised kernel (quarter rows are not whole dwords): the codes go
+    # through the chunked kernel (q kept in fp32) while the fp16 reference takes the fast one (q folded into B): equal to
+    # rounding only, both within the oracle bound below
+    if not (bits == 3 and R in (32, 64)):
+        assert torch.equal(out, ref)
+    else:
+        assert (out.float() - ref.float()).abs().max().item() <= 2e-3 * ref.float().abs().max().item()
     o = oracle.abx_scores(a.cpu(), b.cpu(), oracle.quantize_rows(x.cpu().reshape(-1, R), bits)[0].reshape(G, L, R))
     scale = o.float().abs().max().item()
     assert (out.cpu().float() - o.float()).abs().max().item() <= 1e-3 * scale
