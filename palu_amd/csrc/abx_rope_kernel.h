@@ -557,15 +557,40 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
     }
   };
 
-  // Prologue order (PALU_ABX_B_FIRST): the B fragments go out BEFORE the first X tiles.  Loads return in issue order, and
-  // the fold below consumes the fragments one by one as they land: with the fragments first, the ~600 VALU operations of
-  // fold + RoPE initialisation run underneath the rest of the prologue's 192 KB of ingest instead of after it.
+  // Prologue order.  Loads return in issue order, so what the RoPE initialisation and the fold need besides the B
+  // fragments -- this lane's four inverse frequencies and its query elements, a few bytes -- is requested FIRST: behind
+  // the 24 KB of fragments and first tiles a wave issues below they would arrive last, and the ~300 VALU operations of
+  // the RoPE initialisation (which depend on nothing else) could not start before the whole prologue ingest has landed.
+  // With PALU_ABX_PIN_PROLOGUE both the initialisation and the fold are made to run in front of the first barrier
+  // (left alone, hipcc sinks them behind it; see the pins below).  PALU_ABX_B_FIRST requests the fragments before the
+  // first X tiles.  Measured (profiles/r03_abx_prologue_variants.txt).
 #ifndef PALU_ABX_B_FIRST
-#define PALU_ABX_B_FIRST 1
+#define PALU_ABX_B_FIRST 0
 #endif
 #ifndef PALU_ABX_PIN_PROLOGUE
-#define PALU_ABX_PIN_PROLOGUE 1
+#define PALU_ABX_PIN_PROLOGUE 0
 #endif
+#ifndef PALU_ABX_EARLY_SMALL_LOADS
+#define PALU_ABX_EARLY_SMALL_LOADS 1
+#endif
+  float fr[4];
+  h16 fold_qi[NMB], fold_qj[NMB];
+  if (PALU_ABX_EARLY_SMALL_LOADS) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) fr[j] = p.inv_freq[8 * w + 2 * j + hi];
+    if (FOLD) {
+      const int m = lane & 31;
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb) {
+        const int hloc = hb * HPW + 2 * mb + (m & 1);
+        const bool valid = hloc < p.gs;
+        const int h = g * p.gs + (valid ? hloc : 0);
+        const int i = 8 * w + (m >> 2);
+        fold_qi[mb] = valid ? p.a[h * p.sa_h + i * p.sa_d] : (h16)0.f;
+        fold_qj[mb] = valid ? p.a[h * p.sa_h + (i + 64) * p.sa_d] : (h16)0.f;
+      }
+    }
+  }
   auto first_tiles = [&]() {
     if (QBITS == 0) {
       dma_tile(0, 0);
@@ -595,11 +620,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
   stamp();  // 1: B loads issued
   // ---- RoPE state of this lane (C layout: position n, pairs i = 8w + 2j + hi), started one block
   //      early because the pipeline runs one (discarded) epilogue before the first real block.
-  float fr[4], rc[4], rs[4], cs[4], sn[4];
+  float rc[4], rs[4], cs[4], sn[4];
   float lf = (float)(p.pos0 + tile0 * TL + n - 32);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    fr[j] = p.inv_freq[8 * w + 2 * j + hi];
+    if (!PALU_ABX_EARLY_SMALL_LOADS) fr[j] = p.inv_freq[8 * w + 2 * j + hi];
     sincos_exact_product(lf, fr[j], &sn[j], &cs[j]);
     sincos_exact_product(32.0f, fr[j], &rs[j], &rc[j]);
 #if PALU_ABX_PIN_PROLOGUE
@@ -628,8 +653,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
       bool valid = hloc < p.gs;
       int h = g * p.gs + (valid ? hloc : 0);
       int i = 8 * w + pair;
-      h16 qi = valid ? p.a[h * p.sa_h + i * p.sa_d] : (h16)0.f;
-      h16 qj = valid ? p.a[h * p.sa_h + (i + 64) * p.sa_d] : (h16)0.f;
+      h16 qi, qj;
+      if (PALU_ABX_EARLY_SMALL_LOADS) {
+        qi = fold_qi[mb];
+        qj = fold_qj[mb];
+      } else {
+        qi = valid ? p.a[h * p.sa_h + i * p.sa_d] : (h16)0.f;
+        qj = valid ? p.a[h * p.sa_h + (i + 64) * p.sa_d] : (h16)0.f;
+      }
       h16x2 coef;
       coef[0] = u ? -qi : qi;
       coef[1] = qj;

@@ -187,6 +187,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void decode_fused_kernel(FusedParams p
     fr[j] = p.inv_freq[8 * w + 2 * j + hi];
     sincos_exact_product(lf, fr[j], &sn[j], &cs[j]);
     sincos_exact_product(32.0f, fr[j], &rs[j], &rc[j]);
+    // pinned in front of the first barrier together with the fold below (abx_rope_kernel.h, PALU_ABX_PIN_PROLOGUE):
+    // otherwise hipcc sinks this arithmetic behind the barrier, onto every workgroup's critical path
+    asm volatile("" : "+v"(sn[j]), "+v"(cs[j]), "+v"(rs[j]), "+v"(rc[j]));
   }
   stamp();  // 2
 
@@ -223,6 +226,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void decode_fused_kernel(FusedParams p
           res[e] = __builtin_bit_cast(unsigned, r2);
         }
         bf[mb][ks] = __builtin_bit_cast(h16x8, res);
+        asm volatile("" : "+v"(bf[mb][ks]));
       }
     }
   }

@@ -920,9 +920,15 @@ constexpr int CB_WAVES = 8;
 __global__ __launch_bounds__(64 * CB_WAVES) void pv_combine_kernel(CombineParams p) {
   __shared__ float red[CB_WAVES][64];
   __shared__ float redt[CB_WAVES];
-  const int h = blockIdx.x, g = h / p.gs, hh = h - g * p.gs;
+  // 1-D grid of H * ceil(Rv / 64) workgroups; workgroup b -> (group, head in group, column block) with group = b % G:
+  // the partials of latent group g were written by workgroups with id % G == g (pv_partial*, decode_fused), i.e. with
+  // G = 8 on XCD g -- the merge reads them from that XCD's L2 instead of from memory (placement: speed only)
+  const int g = blockIdx.x % p.G;
+  const int rest = blockIdx.x / p.G;
+  const int hh = rest % p.gs, yb = rest / p.gs;
+  const int h = g * p.gs + hh;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int r = blockIdx.y * 64 + lane;
+  const int r = yb * 64 + lane;
   const float* ml = p.ml + ((size_t)g * p.nsplit * p.gs + hh) * 2;
   const size_t ml_stride = (size_t)p.gs * 2;
   const float* part = p.part + ((size_t)g * p.nsplit * p.gs + hh) * p.Rv + min(r, p.Rv - 1);
@@ -965,7 +971,7 @@ __global__ __launch_bounds__(64 * CB_WAVES) void pv_combine_kernel(CombineParams
       a += red[k][lane];
       t += redt[k];
     }
-    if (blockIdx.y == 0 && lane == 0) {
+    if (yb == 0 && lane == 0) {
       p.stats[2 * h] = M;
       p.stats[2 * h + 1] = t;
     }
@@ -1077,7 +1083,7 @@ int palu_pv_combine_launch(float* ws, void* ctx, int H, int G, int Rv, int ns, h
   c.ctx = (h16*)ctx;
   c.stats = ws;
   c.G = G; c.gs = H / G; c.Rv = Rv; c.nsplit = ns;
-  hipLaunchKernelGGL(pv_combine_kernel, dim3(H, (Rv + 63) / 64), dim3(64 * CB_WAVES), 0, s, c);
+  hipLaunchKernelGGL(pv_combine_kernel, dim3(H * ((Rv + 63) / 64)), dim3(64 * CB_WAVES), 0, s, c);
   PALU_LAUNCH_CHECK();
   return PALU_OK;
 }
@@ -1274,7 +1280,7 @@ extern "C" int palu_softmax_pv_f16(const void* scores, int64_t ss_h, const void*
   CombineParams c;
   c.part = p.part; c.ml = p.ml; c.ctx = (h16*)ctx; c.stats = stats;
   c.G = G; c.gs = gs; c.Rv = Rv; c.nsplit = ns;
-  hipLaunchKernelGGL(pv_combine_kernel, dim3(H, (Rv + 63) / 64), dim3(64 * CB_WAVES), 0, s, c);
+  hipLaunchKernelGGL(pv_combine_kernel, dim3(H * ((Rv + 63) / 64)), dim3(64 * CB_WAVES), 0, s, c);
   PALU_LAUNCH_CHECK();
   if (probs) {
     int bx = (L + 255) / 256;
@@ -1348,7 +1354,7 @@ extern "C" int palu_softmax_pv_q(const void* scores, int64_t ss_h, const void* m
   CombineParams c;
   c.part = p.part; c.ml = p.ml; c.ctx = (h16*)ctx; c.stats = stats;
   c.G = G; c.gs = gs; c.Rv = Rv; c.nsplit = ns;
-  hipLaunchKernelGGL(pv_combine_kernel, dim3(H, (Rv + 63) / 64), dim3(64 * CB_WAVES), 0, s, c);
+  hipLaunchKernelGGL(pv_combine_kernel, dim3(H * ((Rv + 63) / 64)), dim3(64 * CB_WAVES), 0, s, c);
   PALU_LAUNCH_CHECK();
   if (probs) {
     int bx = (L + 255) / 256;
