@@ -203,22 +203,23 @@ __global__ __launch_bounds__(PV_THREADS) void pv_partial_kernel(PvParams p) {
   }
   __syncthreads();   // everyone is done reading the probabilities: reuse the buffer for the reduction
 
-  // ---- phase C: sum the row groups -> partial context [GS][Rv]
-  float* redb = pl;   // [rpp][GS][Rv]
-  if (rg < rpp) {
+  // ---- phase C: sum the row groups -> partial context [GS][Rv], one head at a time: the reduce buffer [rpp][Rv] stays
+  //      below 8 KB (a workgroup of this kernel then fits in the LDS a score-kernel workgroup leaves free on its CU)
+  float* redb = pl;   // [rpp][Rv]
 #pragma unroll
-    for (int h = 0; h < GS; ++h) {
-      float* d = redb + ((size_t)rg * GS + h) * p.Rv + cc * 8;
+  for (int h = 0; h < GS; ++h) {
+    if (h > 0) __syncthreads();
+    if (rg < rpp) {
+      float* d = redb + (size_t)rg * p.Rv + cc * 8;
       *reinterpret_cast<f32x4*>(d) = f32x4{acc[h][0], acc[h][1], acc[h][2], acc[h][3]};
       *reinterpret_cast<f32x4*>(d + 4) = f32x4{acc[h][4], acc[h][5], acc[h][6], acc[h][7]};
     }
-  }
-  __syncthreads();
-  const int tot = GS * p.Rv;
-  for (int o = tid; o < tot; o += PV_THREADS) {
-    float s = 0.f;
-    for (int r = 0; r < rpp; ++r) s += redb[(size_t)r * tot + o];
-    part[o] = s;
+    __syncthreads();
+    for (int o = tid; o < p.Rv; o += PV_THREADS) {
+      float s = 0.f;
+      for (int r = 0; r < rpp; ++r) s += redb[(size_t)r * p.Rv + o];
+      part[h * p.Rv + o] = s;
+    }
   }
 }
 
@@ -1265,7 +1266,7 @@ extern "C" int palu_softmax_pv_f16(const void* scores, int64_t ss_h, const void*
   p.G = G; p.gs = gs; p.L = L; p.Rv = Rv; p.nsplit = ns; p.rps = rps;
   p.inv_scale = sqrt_d;
   size_t lds = (size_t)gs * rps * sizeof(float);
-  size_t lds_red = (size_t)(PV_THREADS / (Rv / 8)) * gs * Rv * sizeof(float);
+  size_t lds_red = (size_t)(PV_THREADS / (Rv / 8)) * Rv * sizeof(float);
   if (lds_red > lds) lds = lds_red;
   PALU_REQUIRE(lds <= 64 * 1024, PALU_ERR_UNSUPPORTED, "softmax_pv: LDS budget exceeded");
   dim3 grid(G * ns), block(PV_THREADS);
