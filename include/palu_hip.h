@@ -238,8 +238,13 @@ int palu_hadamard_transform(const void* x, void* y, int64_t rows, int n, float s
  * Quantised-latent variants (3/4-bit codes + per-row (scale, zero), layout above).  The reference has
  * no such kernels (README.md:24 TODO); semantics = the fp16 entry points applied to the fake-quantised
  * latents quantize_tensor(x) (svd_linear.py:84-90,124-139), i.e. dequantised values bit-identical.
- * abx_q supports (bits, R) in {(4,32), (4,64), (4,128), (3,128)}; softmax_pv_q needs Rv % 32 == 0,
- * gs in {1,2,4}.  Byte strides for codes, element strides for meta.
+ * abx_q: 3 bit with R % 32 == 0, 4 bit with R % 8 == 0 -- (4,32), (4,64), (4,128), (3,128) on the fast kernels, every
+ * other rank (the 96 / 160 / 224 / 256 of palu/rank_search.py:11-17 ...) on the chunked one; softmax_pv_q needs
+ * Rv % 32 == 0, gs in {1,2,3,4,8}.  Byte strides for codes, element strides for meta.
+ * The *_qg entry points take rows quantised in column groups (quantize_tensor(..., group_size > 0), quant.py:11-13, the
+ * --lt_group_size option of utils.py:105): meta [G, L, R / group_size, 2] (sm_l >= 2 R / group_size); the packed codes
+ * are laid out exactly as for whole-row quantisation (group_size % 8 == 0; % 32 for P.V and the step); group_size = 0
+ * or = R is the whole-row form.
  */
 int palu_abx_rope_q(const void* a, int64_t sa_h, int64_t sa_d, const void* bfrag,
                     const void* codes, int64_t sc_g, int64_t sc_l, const void* meta, int64_t sm_g, int64_t sm_l,
@@ -249,6 +254,22 @@ int palu_softmax_pv_q(const void* scores, int64_t ss_h, const void* mask,
                       const void* codes, int64_t sc_g, int64_t sc_l, const void* meta, int64_t sm_g, int64_t sm_l,
                       void* ctx, void* probs, int64_t sp_h, void* workspace,
                       int H, int G, int L, int Rv, int bits, float sqrt_d, palu_stream_t stream);
+int palu_abx_rope_qg(const void* a, int64_t sa_h, int64_t sa_d, const void* bfrag,
+                     const void* codes, int64_t sc_g, int64_t sc_l, const void* meta, int64_t sm_g, int64_t sm_l,
+                     void* out, int64_t so_h, int H, int G, int L, int R, int D, int bits, int group_size,
+                     const float* inv_freq, int pos0, palu_stream_t stream);
+int palu_softmax_pv_qg(const void* scores, int64_t ss_h, const void* mask,
+                       const void* codes, int64_t sc_g, int64_t sc_l, const void* meta, int64_t sm_g, int64_t sm_l,
+                       void* ctx, void* probs, int64_t sp_h, void* workspace,
+                       int H, int G, int L, int Rv, int bits, int group_size, float sqrt_d, palu_stream_t stream);
+int palu_decode_step_qg(const void* hidden,
+                        const void* wq, int64_t ldq, const void* vtk, int64_t ldk, const void* vtv, int64_t ldv,
+                        const void* bfrag, const void* wo, int64_t ldo,
+                        void* k_codes, int64_t skc_g, int64_t skc_l, void* k_meta, int64_t skm_g, int64_t skm_l,
+                        void* v_codes, int64_t svc_g, int64_t svc_l, void* v_meta, int64_t svm_g, int64_t svm_l,
+                        const void* mask, const float* inv_freq, void* out, void* probs, int64_t sp_h,
+                        void* workspace, int Lcap, int H, int G, int D, int hidden_size, int Rk, int Rv,
+                        int bits, int group_size, int cache_len, int pos, palu_stream_t stream);
 int palu_decode_step_q(const void* hidden,
                        const void* wq, int64_t ldq, const void* vtk, int64_t ldk, const void* vtv, int64_t ldv,
                        const void* bfrag, const void* wo, int64_t ldo,

@@ -176,7 +176,8 @@ def prefill(hidden: torch.Tensor, weights: Dict[str, torch.Tensor], attention_ma
 def decode_step(hidden: torch.Tensor, position: int, weights: Dict[str, torch.Tensor],
                 k_lat: torch.Tensor, v_lat: torch.Tensor,
                 attention_mask: Optional[torch.Tensor] = None,
-                theta: float = 10000.0, max_pos: Optional[int] = None, latent_bits: int = 16):
+                theta: float = 10000.0, max_pos: Optional[int] = None, latent_bits: int = 16,
+                latent_group_size: int = 0):
     """One-token decode of the low-rank attention module (batch 1), fp16 tensors on CPU.
 
     hidden [hidden] fp16; weights: wq [H*D,hidden], vt_k [G*Rk,hidden], vt_v [G*Rv,hidden],
@@ -201,8 +202,9 @@ def decode_step(hidden: torch.Tensor, position: int, weights: Dict[str, torch.Te
     if latent_bits < 16:
         # accuracy-path semantics: project -> fake-quantise each (token, group) latent row -> attend
         # (palu/model/modules/svd_linear.py:84-90,124-139); the caches passed in are already fake-quantised
-        k_new = quantize_rows(k_new.reshape(G, Rk), latent_bits)[0].reshape(G, 1, Rk)
-        v_new = quantize_rows(v_new.reshape(G, Rv), latent_bits)[0].reshape(G, 1, Rv)
+        # (latent_group_size: the Quantizer's group_size, quant.py:60-79 / --lt_group_size of utils.py:105)
+        k_new = quantize_rows(k_new.reshape(G, Rk), latent_bits, latent_group_size)[0].reshape(G, 1, Rk)
+        v_new = quantize_rows(v_new.reshape(G, Rv), latent_bits, latent_group_size)[0].reshape(G, 1, Rv)
     k_all = torch.cat((k_lat, k_new), dim=1)
     v_all = torch.cat((v_lat, v_new), dim=1)
     L = k_all.shape[1]

@@ -65,6 +65,11 @@ SIGNATURES = {
     "palu_decode_step_q": (i32, [vp, vp, i64, vp, i64, vp, i64, vp, vp, i64,
                                  vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64,
                                  vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "palu_abx_rope_qg": (i32, [vp, i64, i64, vp, vp, i64, i64, vp, i64, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
+    "palu_softmax_pv_qg": (i32, [vp, i64, vp, vp, i64, i64, vp, i64, i64, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, f32, vp]),
+    "palu_decode_step_qg": (i32, [vp, vp, i64, vp, i64, vp, i64, vp, vp, i64,
+                                  vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64,
+                                  vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "palu_lowrank_project_gemm": (i32, [vp, i64, vp, i64, vp, i64, i64, i32, i32, i32, i32, i32, vp]),
     "palu_rope_f16": (i32, [vp, i64, i64, i32, i32, i32, i32, vp, vp]),
     "palu_prefill_attn_f16": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i32, i32, i32, i32, i32, i32,

@@ -60,6 +60,7 @@ struct AbxParams {
   int64_t sq_g, sq_l;       // bytes
   const h16* xmeta;
   int64_t sm_g, sm_l;       // elements
+  int qgroup;               // columns per (scale, zero) pair: 0 = one pair per row, else R / qgroup pairs (chunked kernel)
 };
 
 // heads per workgroup = 2*NMB; each MFMA M-block carries 2 heads x 8 pairs x {i, i+64}
@@ -209,7 +210,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_generic_kernel(AbxParams
             const unsigned long long w = ((unsigned long long)w1 << 32) | w0;
             grp = (unsigned)(w >> ((bo & 3) * 8));
           }
-          const unsigned meta = *reinterpret_cast<const unsigned*>(xmg + (int64_t)l * p.sm_l);
+          // (scale, zero) of this slot's quantisation group: the whole row, or columns [qgroup * k, qgroup * (k + 1))
+          // (quantize_tensor with group_size > 0, quant.py:11-13; qgroup % 8 == 0, so a slot never straddles two groups)
+          const unsigned meta = *reinterpret_cast<const unsigned*>(xmg + (int64_t)l * p.sm_l + (p.qgroup > 0 ? 2 * (col / p.qgroup) : 0));
           const h16x2 m2 = __builtin_bit_cast(h16x2, meta);
           const h16x2 scale2 = h16x2{m2[0], m2[0]};
           const h16 nb = -((h16)1024.f + m2[1]);                 // exact: zero is an integer in [0, 15]

@@ -20,10 +20,38 @@ int launch_abx_q_generic(const AbxParams& p, int nwg, hipStream_t stream) {
 }
 }  // namespace
 
+static int abx_rope_q_impl(const void* a, int64_t sa_h, int64_t sa_d, const void* bfrag, const void* codes,
+                           int64_t sc_g, int64_t sc_l, const void* meta, int64_t sm_g, int64_t sm_l, void* out,
+                           int64_t so_h, int H, int G, int L, int R, int D, int bits, int group_size, const float* inv_freq,
+                           int pos0, palu_stream_t stream);
+
 extern "C" int palu_abx_rope_q(const void* a, int64_t sa_h, int64_t sa_d, const void* bfrag, const void* codes,
                                int64_t sc_g, int64_t sc_l, const void* meta, int64_t sm_g, int64_t sm_l, void* out,
                                int64_t so_h, int H, int G, int L, int R, int D, int bits, const float* inv_freq,
                                int pos0, palu_stream_t stream) {
+  return abx_rope_q_impl(a, sa_h, sa_d, bfrag, codes, sc_g, sc_l, meta, sm_g, sm_l, out, so_h, H, G, L, R, D, bits, 0, inv_freq,
+                         pos0, stream);
+}
+
+// the same on rows quantised in column groups (quantize_tensor(..., group_size > 0), quant.py:11-13, --lt_group_size):
+// meta [G, L, R / group_size, 2]; the packed codes are laid out exactly as for whole-row quantisation
+extern "C" int palu_abx_rope_qg(const void* a, int64_t sa_h, int64_t sa_d, const void* bfrag, const void* codes,
+                                int64_t sc_g, int64_t sc_l, const void* meta, int64_t sm_g, int64_t sm_l, void* out,
+                                int64_t so_h, int H, int G, int L, int R, int D, int bits, int group_size,
+                                const float* inv_freq, int pos0, palu_stream_t stream) {
+  if (group_size == R) group_size = 0;
+  PALU_REQUIRE(group_size == 0 || (group_size > 0 && R % group_size == 0 && group_size % 8 == 0), PALU_ERR_UNSUPPORTED,
+               "abx_qg: group_size %d must divide R %d and be a multiple of 8", group_size, R);
+  PALU_REQUIRE(group_size == 0 || sm_l >= 2 * (R / group_size), PALU_ERR_ARG,
+               "abx_qg: meta rows hold R / group_size (scale, zero) pairs");
+  return abx_rope_q_impl(a, sa_h, sa_d, bfrag, codes, sc_g, sc_l, meta, sm_g, sm_l, out, so_h, H, G, L, R, D, bits, group_size,
+                         inv_freq, pos0, stream);
+}
+
+static int abx_rope_q_impl(const void* a, int64_t sa_h, int64_t sa_d, const void* bfrag, const void* codes,
+                           int64_t sc_g, int64_t sc_l, const void* meta, int64_t sm_g, int64_t sm_l, void* out,
+                           int64_t so_h, int H, int G, int L, int R, int D, int bits, int group_size, const float* inv_freq,
+                           int pos0, palu_stream_t stream) {
   AbxPlan pl;
   PALU_REQUIRE(abx_plan(H, G, R, &pl), PALU_ERR_ARG, "abx_q: bad shape H=%d G=%d R=%d", H, G, R);
   PALU_REQUIRE(D == HEAD_DIM, PALU_ERR_UNSUPPORTED, "abx_q: head_dim must be 128 (got %d)", D);
@@ -31,7 +59,7 @@ extern "C" int palu_abx_rope_q(const void* a, int64_t sa_h, int64_t sa_d, const 
                "abx_q: bits must be 3 (R %% 32 == 0) or 4 (R %% 8 == 0); got (%d, %d)", bits, R);
   // fast path (tile staging of whole quarter rows): (4, 32|64|128), (3, 128); everything else -- the ranks the rank
   // search emits (96, 160, 224, 256, ...) and 3-bit at 32 / 64 -- runs the chunked kernel
-  const bool fast = (bits == 4 && (R == 32 || R == 64 || R == 128)) || (bits == 3 && R == 128);
+  const bool fast = group_size == 0 && ((bits == 4 && (R == 32 || R == 64 || R == 128)) || (bits == 3 && R == 128));
   PALU_REQUIRE(L >= 0, PALU_ERR_ARG, "abx_q: negative L");
   if (L == 0) return PALU_OK;
   PALU_REQUIRE(a && bfrag && codes && meta && out && inv_freq, PALU_ERR_ARG, "abx_q: null pointer");
@@ -60,6 +88,7 @@ extern "C" int palu_abx_rope_q(const void* a, int64_t sa_h, int64_t sa_d, const 
   }
   const int nwg = abx_fill_params(p, pl, H, G, L, R, pos0);
   p.nks_frag = nks_frag;
+  p.qgroup = group_size;
   hipStream_t s = (hipStream_t)stream;
   if (!fast) {
     if (bits == 3) return pl.nmb == 2 ? launch_abx_q_generic<2, 3>(p, nwg, s) : launch_abx_q_generic<1, 3>(p, nwg, s);

@@ -910,10 +910,15 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
 struct CombineParams {
   const float* part;
   const float* ml;
-  h16* ctx;        // [H, Rv]
+  h16* ctx;        // [H, Rv] (row stride ctx_ld)
   float* stats;    // [H][2] global (max, sum) -- consumed by the probs kernel
   int G, gs, Rv, nsplit;
+  int ctx_ld;      // elements between the context rows of consecutive heads (Rv unless a column group is written, _qg)
 };
+
+// row stride of the context the merge writes: 0 = Rv.  Set (per thread) by palu_softmax_pv_qg around its per-column-group
+// calls, so that each group's [H, group] slice lands in place inside the [H, Rv] context.
+thread_local int g_ctx_ld = 0;
 
 // grid (H, ceil(Rv/64)), 512 threads: the 8 waves share the splits of one head for 64 context columns
 // (8 independent loads in flight per lane: the merge is latency-, not bandwidth-bound), LDS sum at the end.
@@ -976,7 +981,7 @@ __global__ __launch_bounds__(64 * CB_WAVES) void pv_combine_kernel(CombineParams
       p.stats[2 * h] = M;
       p.stats[2 * h + 1] = t;
     }
-    if (r < p.Rv) p.ctx[(size_t)h * p.Rv + r] = (h16)(a / t);
+    if (r < p.Rv) p.ctx[(size_t)h * p.ctx_ld + r] = (h16)(a / t);
   }
 }
 
@@ -1084,6 +1089,7 @@ int palu_pv_combine_launch(float* ws, void* ctx, int H, int G, int Rv, int ns, h
   c.ctx = (h16*)ctx;
   c.stats = ws;
   c.G = G; c.gs = H / G; c.Rv = Rv; c.nsplit = ns;
+  c.ctx_ld = g_ctx_ld ? g_ctx_ld : Rv;
   hipLaunchKernelGGL(pv_combine_kernel, dim3(H * ((Rv + 63) / 64)), dim3(64 * CB_WAVES), 0, s, c);
   PALU_LAUNCH_CHECK();
   return PALU_OK;
@@ -1281,6 +1287,7 @@ extern "C" int palu_softmax_pv_f16(const void* scores, int64_t ss_h, const void*
   CombineParams c;
   c.part = p.part; c.ml = p.ml; c.ctx = (h16*)ctx; c.stats = stats;
   c.G = G; c.gs = gs; c.Rv = Rv; c.nsplit = ns;
+  c.ctx_ld = g_ctx_ld ? g_ctx_ld : Rv;
   hipLaunchKernelGGL(pv_combine_kernel, dim3(H * ((Rv + 63) / 64)), dim3(64 * CB_WAVES), 0, s, c);
   PALU_LAUNCH_CHECK();
   if (probs) {
@@ -1355,6 +1362,7 @@ extern "C" int palu_softmax_pv_q(const void* scores, int64_t ss_h, const void* m
   CombineParams c;
   c.part = p.part; c.ml = p.ml; c.ctx = (h16*)ctx; c.stats = stats;
   c.G = G; c.gs = gs; c.Rv = Rv; c.nsplit = ns;
+  c.ctx_ld = g_ctx_ld ? g_ctx_ld : Rv;
   hipLaunchKernelGGL(pv_combine_kernel, dim3(H * ((Rv + 63) / 64)), dim3(64 * CB_WAVES), 0, s, c);
   PALU_LAUNCH_CHECK();
   if (probs) {
@@ -1365,4 +1373,32 @@ extern "C" int palu_softmax_pv_q(const void* scores, int64_t ss_h, const void* m
     PALU_LAUNCH_CHECK();
   }
   return PALU_OK;
+}
+
+// Quantised latents with per-COLUMN-GROUP (scale, zero) pairs -- quantize_tensor(..., group_size > 0), quant.py:11-13, the
+// --lt_group_size option: a row of Rv codes carries Rv / group_size metas.  The packed code stream of such a row is the
+// concatenation of its groups' streams (group_size % 8 == 0), i.e. identical to the whole-row layout; only the meta differs:
+// meta [G, L, Rv / group_size, 2].  Each column group is a P.V problem of width group_size with its own row scales: the
+// kernels above run once per group on offset pointers and write their [H, group_size] slice of ctx in place.
+extern "C" int palu_softmax_pv_qg(const void* scores, int64_t ss_h, const void* mask, const void* codes, int64_t sc_g,
+                                  int64_t sc_l, const void* meta, int64_t sm_g, int64_t sm_l, void* ctx, void* probs,
+                                  int64_t sp_h, void* workspace, int H, int G, int L, int Rv, int bits, int group_size,
+                                  float sqrt_d, palu_stream_t stream) {
+  if (group_size <= 0 || group_size == Rv)
+    return palu_softmax_pv_q(scores, ss_h, mask, codes, sc_g, sc_l, meta, sm_g, sm_l, ctx, probs, sp_h, workspace, H, G, L, Rv,
+                             bits, sqrt_d, stream);
+  PALU_REQUIRE(Rv % group_size == 0 && group_size % 32 == 0, PALU_ERR_UNSUPPORTED,
+               "softmax_pv_qg: group_size %d must divide Rv %d and be a multiple of 32", group_size, Rv);
+  PALU_REQUIRE(bits == 3 || bits == 4, PALU_ERR_UNSUPPORTED, "softmax_pv_qg: bits must be 3 or 4");
+  PALU_REQUIRE(sm_l >= 2 * (Rv / group_size), PALU_ERR_ARG, "softmax_pv_qg: meta rows hold Rv / group_size (scale, zero) pairs");
+  const int ng = Rv / group_size;
+  const int gbytes = group_size * bits / 8;
+  int rc = PALU_OK;
+  g_ctx_ld = Rv;
+  for (int q = 0; q < ng && rc == PALU_OK; ++q)
+    rc = palu_softmax_pv_q(scores, ss_h, mask, (const char*)codes + (size_t)q * gbytes, sc_g, sc_l, (const h16*)meta + 2 * q,
+                           sm_g, sm_l, (h16*)ctx + (size_t)q * group_size, q == 0 ? probs : nullptr, sp_h, workspace, H, G, L,
+                           group_size, bits, sqrt_d, stream);
+  g_ctx_ld = 0;
+  return rc;
 }

@@ -125,8 +125,27 @@ extern "C" int palu_decode_step_q(const void* hidden, const void* wq, int64_t ld
                                   const void* mask, const float* inv_freq, void* out, void* probs, int64_t sp_h,
                                   void* workspace, int Lcap, int H, int G, int D, int hidden_size, int Rk, int Rv,
                                   int bits, int cache_len, int pos, palu_stream_t stream) {
+  return palu_decode_step_qg(hidden, wq, ldq, vtk, ldk, vtv, ldv, bfrag, wo, ldo, k_codes, skc_g, skc_l, k_meta, skm_g, skm_l,
+                             v_codes, svc_g, svc_l, v_meta, svm_g, svm_l, mask, inv_freq, out, probs, sp_h, workspace, Lcap, H,
+                             G, D, hidden_size, Rk, Rv, bits, 0, cache_len, pos, stream);
+}
+
+// The same step when the latents are quantised in column groups of `group_size` (quantize_tensor(..., group_size),
+// quant.py:11-13; --lt_group_size of utils.py:105): k_meta [G, Lcap, Rk / group_size, 2], v_meta [G, Lcap, Rv / group_size, 2]
+// (group_size = 0: one pair per row).  The new rows are quantised group by group (each group a row of the quantiser),
+// the score kernel looks the pair of a column up by its group, P.V runs once per column group.
+extern "C" int palu_decode_step_qg(const void* hidden, const void* wq, int64_t ldq, const void* vtk, int64_t ldk,
+                                   const void* vtv, int64_t ldv, const void* bfrag, const void* wo, int64_t ldo,
+                                   void* k_codes, int64_t skc_g, int64_t skc_l, void* k_meta, int64_t skm_g, int64_t skm_l,
+                                   void* v_codes, int64_t svc_g, int64_t svc_l, void* v_meta, int64_t svm_g, int64_t svm_l,
+                                   const void* mask, const float* inv_freq, void* out, void* probs, int64_t sp_h,
+                                   void* workspace, int Lcap, int H, int G, int D, int hidden_size, int Rk, int Rv,
+                                   int bits, int group_size, int cache_len, int pos, palu_stream_t stream) {
   PALU_REQUIRE(workspace && Lcap > cache_len && cache_len >= 0, PALU_ERR_ARG,
                "decode_step_q: cache_len %d must be < workspace capacity %d", cache_len, Lcap);
+  PALU_REQUIRE(group_size == 0 || (group_size > 0 && Rk % group_size == 0 && Rv % group_size == 0 && group_size % 32 == 0),
+               PALU_ERR_UNSUPPORTED, "decode_step_qg: group_size %d must divide Rk %d and Rv %d and be a multiple of 32",
+               group_size, Rk, Rv);
   PALU_REQUIRE((size_t)G * Rk <= 4096 && (size_t)G * Rv <= 16384, PALU_ERR_UNSUPPORTED, "decode_step_q: rank too large");
   const StepWs w = step_layout(H, G, D, Lcap, Rv);
   char* ws = (char*)workspace;
@@ -141,16 +160,28 @@ extern "C" int palu_decode_step_q(const void* hidden, const void* wq, int64_t ld
   int rc = palu_decode_qkv_f16(wq, ldq, vtk, ldk, vtv, ldv, hidden, q, knew, Rk, 0, vnew, Rv, 0, inv_freq, H, D,
                                hidden_size, G, Rk, Rv, pos, 0, stream);
   if (rc) return rc;
-  rc = palu_quantize_pack_kv(knew, Rk, (char*)k_codes + (int64_t)cache_len * skc_l, skc_g,
-                             (h16*)k_meta + (int64_t)cache_len * skm_l, skm_g, Rk, vnew, Rv,
-                             (char*)v_codes + (int64_t)cache_len * svc_l, svc_g,
-                             (h16*)v_meta + (int64_t)cache_len * svm_l, svm_g, Rv, G, bits, stream);
+  if (group_size == 0) {
+    rc = palu_quantize_pack_kv(knew, Rk, (char*)k_codes + (int64_t)cache_len * skc_l, skc_g,
+                               (h16*)k_meta + (int64_t)cache_len * skm_l, skm_g, Rk, vnew, Rv,
+                               (char*)v_codes + (int64_t)cache_len * svc_l, svc_g,
+                               (h16*)v_meta + (int64_t)cache_len * svm_l, svm_g, Rv, G, bits, stream);
+  } else {
+    // every column group of the new row is one row of the quantiser: [G, R / group_size, group_size]
+    const int gb = group_size * bits / 8;
+    rc = palu_quantize_pack(knew, Rk, group_size, (char*)k_codes + (int64_t)cache_len * skc_l, skc_g, gb,
+                            (h16*)k_meta + (int64_t)cache_len * skm_l, skm_g, 2, nullptr, 0, 0, G, Rk / group_size, group_size,
+                            bits, stream);
+    if (rc) return rc;
+    rc = palu_quantize_pack(vnew, Rv, group_size, (char*)v_codes + (int64_t)cache_len * svc_l, svc_g, gb,
+                            (h16*)v_meta + (int64_t)cache_len * svm_l, svm_g, 2, nullptr, 0, 0, G, Rv / group_size, group_size,
+                            bits, stream);
+  }
   if (rc) return rc;
-  rc = palu_abx_rope_q(q, D, 1, bfrag, k_codes, skc_g, skc_l, k_meta, skm_g, skm_l, scores, ss_h, H, G, L, Rk, D, bits,
-                       inv_freq, 0, stream);
+  rc = palu_abx_rope_qg(q, D, 1, bfrag, k_codes, skc_g, skc_l, k_meta, skm_g, skm_l, scores, ss_h, H, G, L, Rk, D, bits,
+                        group_size, inv_freq, 0, stream);
   if (rc) return rc;
-  rc = palu_softmax_pv_q(scores, ss_h, mask, v_codes, svc_g, svc_l, v_meta, svm_g, svm_l, ctx, probs, sp_h, pvws, H, G, L,
-                         Rv, bits, sqrtf((float)D), stream);
+  rc = palu_softmax_pv_qg(scores, ss_h, mask, v_codes, svc_g, svc_l, v_meta, svm_g, svm_l, ctx, probs, sp_h, pvws, H, G, L,
+                          Rv, bits, group_size, sqrtf((float)D), stream);
   if (rc) return rc;
   return palu_gemv_f16(wo, ldo, ctx, out, hidden_size, H * Rv, stream);
 }

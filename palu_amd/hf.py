@@ -155,5 +155,6 @@ def convert_llama_to_palu(model, rank_k: int, rank_v: int, group_size: int = 4, 
         inner = inner.to(device=att.q_proj.weight.device, dtype=att.q_proj.weight.dtype)
         if hadamard:
             inner.fuse_hadamard()
+        inner.prepare_decode()            # fragments + shared-B decision now, not inside the first (possibly captured) step
         layer.self_attn = PaluAttentionHF(inner)
     return model

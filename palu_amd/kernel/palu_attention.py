@@ -111,10 +111,16 @@ class QuantLatentCache:
     Same protocol as LatentCache; `update` quantises the incoming fp16 latents on the GPU and returns the
     DEQUANTISED [1, G, L, R] tensors (the fake-quant values the reference's accuracy path attends over)."""
 
-    def __init__(self, n_bits: int, capacity: int = 0, headroom: int = 256):
+    def __init__(self, n_bits: int, capacity: int = 0, headroom: int = 256, group_size: int = 0):
         if n_bits not in (3, 4):
             raise ValueError("QuantLatentCache: n_bits must be 3 or 4")
+        if group_size < 0 or group_size % 32:
+            raise ValueError("QuantLatentCache: group_size must be 0 (one (scale, zero) pair per row) or a multiple of 32")
         self.n_bits = n_bits
+        # quantize_tensor's group_size (quant.py:11-13, --lt_group_size): every `group_size` consecutive columns of a row
+        # carry their own (scale, zero); the meta tensors are then [1, G, capacity, 2 * R / group_size] (pair q at
+        # [..., 2q : 2q + 2]); the packed codes do not change
+        self.group_size = int(group_size)
         self._store = []          # per layer: dict(kc, km, vc, vm, Rk, Rv)
         self._len: List[int] = []
         self._min_capacity, self._headroom = int(capacity), int(headroom)
@@ -146,11 +152,14 @@ class QuantLatentCache:
         cap = (max(rows, self._min_capacity, 2 * cur) + 63) // 64 * 64
         n = self._len[layer_idx]
         old = self._store[layer_idx]
+        gsz = self.group_size
+        if gsz and (Rk % gsz or Rv % gsz):
+            raise ValueError(f"QuantLatentCache: group_size {gsz} must divide the group ranks ({Rk}, {Rv})")
         new = {"Rk": Rk, "Rv": Rv,
                "kc": torch.zeros((1, G, cap, packed_row_bytes(Rk, self.n_bits)), dtype=torch.uint8, device=device),
                "vc": torch.zeros((1, G, cap, packed_row_bytes(Rv, self.n_bits)), dtype=torch.uint8, device=device),
-               "km": torch.zeros((1, G, cap, 2), dtype=torch.float16, device=device),
-               "vm": torch.zeros((1, G, cap, 2), dtype=torch.float16, device=device)}
+               "km": torch.zeros((1, G, cap, 2 * (Rk // gsz if gsz else 1)), dtype=torch.float16, device=device),
+               "vm": torch.zeros((1, G, cap, 2 * (Rv // gsz if gsz else 1)), dtype=torch.float16, device=device)}
         if old is not None and n:
             for k in ("kc", "vc", "km", "vm"):
                 new[k][:, :, :n].copy_(old[k][:, :, :n])
@@ -165,9 +174,28 @@ class QuantLatentCache:
     def dequantized(self, layer_idx: int = 0):
         from .quant import unpack_dequant
         st, n = self._store[layer_idx], self._len[layer_idx]
-        k = unpack_dequant(st["kc"][:, :, :n].contiguous(), st["km"][:, :, :n].contiguous(), self.n_bits, st["Rk"])
-        v = unpack_dequant(st["vc"][:, :, :n].contiguous(), st["vm"][:, :, :n].contiguous(), self.n_bits, st["Rv"])
-        return k, v
+        gsz = self.group_size
+
+        def deq(codes, meta, R):
+            codes, meta = codes[:, :, :n].contiguous(), meta[:, :, :n].contiguous()
+            if not gsz:
+                return unpack_dequant(codes, meta, self.n_bits, R)
+            ng = R // gsz                       # every column group is a row of width group_size to the unpacker
+            out = unpack_dequant(codes.reshape(*codes.shape[:-1], ng, -1), meta.reshape(*meta.shape[:-1], ng, 2), self.n_bits, gsz)
+            return out.reshape(*codes.shape[:-1], R)
+        return deq(st["kc"], st["km"], st["Rk"]), deq(st["vc"], st["vm"], st["Rv"])
+
+    def _quantize(self, x: torch.Tensor):
+        """[..., R] fp16 -> (codes [..., R*bits/8], meta [..., 2] or [..., 2 R / group_size]) with quantize_tensor's
+        semantics (quant.py:5-41: whole rows, or rows cut into groups of group_size columns)."""
+        from .quant import quantize_pack
+        x = x.half().contiguous()
+        gsz = self.group_size
+        if not gsz:
+            return quantize_pack(x, self.n_bits)
+        R = x.shape[-1]
+        c, m = quantize_pack(x.reshape(*x.shape[:-1], R // gsz, gsz), self.n_bits)
+        return c.reshape(*x.shape[:-1], -1), m.reshape(*x.shape[:-1], -1)
 
     def update(self, key_states: torch.Tensor, value_states: torch.Tensor, layer_idx: int, cache_kwargs=None):
         from .quant import quantize_pack
@@ -179,8 +207,8 @@ class QuantLatentCache:
         n = self._len[layer_idx]
         self.reserve(layer_idx, n + t + self._headroom, G, Rk, Rv, key_states.device)
         st = self._store[layer_idx]
-        kc, km = quantize_pack(key_states.half().contiguous(), self.n_bits)
-        vc, vm = quantize_pack(value_states.half().contiguous(), self.n_bits)
+        kc, km = self._quantize(key_states)
+        vc, vm = self._quantize(value_states)
         st["kc"][:, :, n:n + t].copy_(kc)
         st["km"][:, :, n:n + t].copy_(km)
         st["vc"][:, :, n:n + t].copy_(vc)
@@ -203,7 +231,7 @@ def save_cache(cache, path: str) -> None:
     from safetensors.torch import save_file
     tensors, meta = {}, {"format": CACHE_FORMAT, "version": CACHE_FORMAT_VERSION, "layers": str(len(cache))}
     if isinstance(cache, QuantLatentCache):
-        meta.update(kind="packed", bits=str(cache.n_bits))
+        meta.update(kind="packed", bits=str(cache.n_bits), group_size=str(cache.group_size))
         for i in range(len(cache)):
             st, n = cache.buffers(i), cache.get_seq_length(i)
             if st is None:
@@ -237,7 +265,7 @@ def load_cache(path: str, device="cpu", capacity: int = 0, headroom: int = 256):
         layers = int(meta["layers"])
         names = set(f.keys())
         if meta["kind"] == "packed":
-            cache = QuantLatentCache(int(meta["bits"]), capacity, headroom)
+            cache = QuantLatentCache(int(meta["bits"]), capacity, headroom, int(meta.get("group_size", "0")))
             for i in range(layers):
                 if f"layer{i}.k_codes" not in names:
                     cache._ensure_layer(i)
@@ -538,10 +566,11 @@ class LlamaPaluAttention(nn.Module):
         if probs is None:
             from .. import ops as _ops  # noqa: F401
             o = torch.ops.palu.decode_step_q(x, wq, vtk, vtv, frag, wo, kc[0], km[0], vc[0], vm[0], inv, ws, self._ws_cap, H,
-                                             self.group_rank_k, self.group_rank_v, cache.n_bits, n, int(pos), attention_mask)
+                                             self.group_rank_k, self.group_rank_v, cache.n_bits, n, int(pos), attention_mask,
+                                             cache.group_size)
             cache.advance(li, 1)
             return o.view(1, 1, self.hidden_size), None
-        _lib.check(_lib.lib.palu_decode_step_q(
+        _lib.check(_lib.lib.palu_decode_step_qg(
             x.data_ptr(), wq.data_ptr(), wq.stride(0), vtk.data_ptr(), vtk.stride(0), vtv.data_ptr(), vtv.stride(0),
             frag.data_ptr(), wo.data_ptr(), wo.stride(0),
             kc.data_ptr(), kc.stride(1), kc.stride(2), km.data_ptr(), km.stride(1), km.stride(2),
@@ -549,7 +578,7 @@ class LlamaPaluAttention(nn.Module):
             mask_ptr, inv.data_ptr(), out.data_ptr(),
             0 if probs is None else probs.data_ptr(), 0 if probs is None else probs.stride(1),
             ws.data_ptr(), self._ws_cap, H, G, D, self.hidden_size, self.group_rank_k, self.group_rank_v,
-            cache.n_bits, n, int(pos), _lib.current_stream()), "palu_decode_step_q")
+            cache.n_bits, cache.group_size, n, int(pos), _lib.current_stream()), "palu_decode_step_qg")
         cache.advance(li, 1)
         return out, probs
 
@@ -662,6 +691,19 @@ class LlamaPaluAttention(nn.Module):
             self.o_proj.weight.data = apply_hadamard(w.reshape(w.shape[0], self.num_heads, Rv).contiguous()).reshape(w.shape)
         return self
 
+    def prepare_decode(self):
+        """Build what the HIP decode step derives from the weights -- the MFMA fragments of B and the "do the heads of a
+        group share B" decision (one device comparison = one host sync) -- NOW, i.e. outside any stream capture and off
+        the first token's path.  Idempotent and cached per weight tensor; call it after the module sits on its GPU and
+        again after its weights changed (`fuse_hadamard` and `load_state_dict` invalidate the cache themselves).  Without
+        it the first decode step does the same lazily (which raises inside a hipGraph capture: warm up or call this first)."""
+        if hasattr(self.k_proj, "B") and self.k_proj.B.is_cuda:
+            with _lib.on_device(self.k_proj.B):
+                bg = shared_b(self.k_proj.B, self.num_groups)
+                prepare_b(self.k_proj.B if bg is None else bg, self.num_groups)
+                rope_inv_freq(self.k_proj.B.device, self.head_dim, self.rope_theta)
+        return self
+
     def _hip_step_shapes_ok(self, cache) -> bool:
         """What palu_decode_step_f16 / _q accept (everything else takes the general path BEFORE anything is written to
         the cache): gs in {1,2,3,4,8} query heads per latent group; fp16 -- ranks multiples of 8; packed cache --
@@ -671,8 +713,10 @@ class LlamaPaluAttention(nn.Module):
         gs, Rk, Rv = self.group_size, self.group_rank_k, self.group_rank_v
         if isinstance(cache, QuantLatentCache):
             bits = cache.n_bits
+            gsz = cache.group_size
             return (gs in (1, 2, 3, 4, 8) and Rv % 32 == 0 and Rv // 16 <= 256
                     and ((bits == 4 and Rk % 8 == 0) or (bits == 3 and Rk % 32 == 0))
+                    and (gsz == 0 or (Rk % gsz == 0 and Rv % gsz == 0))
                     and _q_scratch_ok(self, Rk) and self.num_groups * Rv <= 16384)
         return gs in (1, 2, 3, 4, 8) and Rk % 8 == 0 and Rv % 8 == 0 and Rv // 8 <= 256
 

