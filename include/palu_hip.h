@@ -70,6 +70,15 @@ int palu_abx_rope_f16(const void* a, int64_t sa_h, int64_t sa_d,
                       void* out, int64_t so_h,
                       int H, int G, int L, int R, int D,
                       const float* inv_freq, int pos0, palu_stream_t stream);
+/* Ranks above 128 (R % 8 == 0) run as ceil(R / 128) passes of the 128-column kernel when the caller provides an fp32
+ * scratch of palu_abx_scratch_bytes(H, G, L, R) bytes (16-byte aligned; 0 for R <= 128): partial scores are accumulated
+ * in fp32 and rounded once.  Without scratch (palu_abx_rope_f16, or scratch = 0) such ranks take the slower chunked kernel.
+ * Ranks below 128 other than 32 / 64 (e.g. 96) always run the 128-column kernel with the missing columns masked. */
+size_t palu_abx_scratch_bytes(int H, int G, int L, int R);
+int palu_abx_rope_ws_f16(const void* a, int64_t sa_h, int64_t sa_d, const void* bfrag,
+                         const void* x, int64_t sx_g, int64_t sx_l, void* out, int64_t so_h,
+                         int H, int G, int L, int R, int D, const float* inv_freq, int pos0, void* scratch,
+                         palu_stream_t stream);
 
 /* Shared-B fast path: when b[h] is identical for the gs heads of every group (true-GQA checkpoints,
  * palu/model/svd_mistral/modeling_palu_mistral.py:37-59) the keys are reconstructed once per group instead of once per
@@ -257,7 +266,8 @@ int palu_softmax_pv_q(const void* scores, int64_t ss_h, const void* mask,
 int palu_abx_rope_qg(const void* a, int64_t sa_h, int64_t sa_d, const void* bfrag,
                      const void* codes, int64_t sc_g, int64_t sc_l, const void* meta, int64_t sm_g, int64_t sm_l,
                      void* out, int64_t so_h, int H, int G, int L, int R, int D, int bits, int group_size,
-                     const float* inv_freq, int pos0, palu_stream_t stream);
+                     const float* inv_freq, int pos0, void* scratch /* palu_abx_scratch_bytes() or 0 */,
+                     palu_stream_t stream);
 int palu_softmax_pv_qg(const void* scores, int64_t ss_h, const void* mask,
                        const void* codes, int64_t sc_g, int64_t sc_l, const void* meta, int64_t sm_g, int64_t sm_l,
                        void* ctx, void* probs, int64_t sp_h, void* workspace,

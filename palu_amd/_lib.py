@@ -42,6 +42,8 @@ SIGNATURES = {
     "palu_abx_set_fold": (i32, [i32]),
     "palu_abx_prepare_b": (i32, [vp, i64, i64, i64, i32, i32, i32, i32, vp, vp]),
     "palu_abx_rope_f16": (i32, [vp, i64, i64, vp, vp, i64, i64, vp, i64, i32, i32, i32, i32, i32, vp, i32, vp]),
+    "palu_abx_scratch_bytes": (sz, [i32, i32, i32, i32]),
+    "palu_abx_rope_ws_f16": (i32, [vp, i64, i64, vp, vp, i64, i64, vp, i64, i32, i32, i32, i32, i32, vp, i32, vp, vp]),
     "palu_abx_rope_shared_f16": (i32, [vp, i64, i64, vp, vp, i64, i64, vp, i64, i32, i32, i32, i32, i32, vp, i32, vp]),
     "palu_pv_nsplit": (i32, [i32, i32]),
     "palu_pv_direct_nsplit": (i32, [i32, i32, i32, i32]),
@@ -65,7 +67,7 @@ SIGNATURES = {
     "palu_decode_step_q": (i32, [vp, vp, i64, vp, i64, vp, i64, vp, vp, i64,
                                  vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64,
                                  vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
-    "palu_abx_rope_qg": (i32, [vp, i64, i64, vp, vp, i64, i64, vp, i64, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
+    "palu_abx_rope_qg": (i32, [vp, i64, i64, vp, vp, i64, i64, vp, i64, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp]),
     "palu_softmax_pv_qg": (i32, [vp, i64, vp, vp, i64, i64, vp, i64, i64, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, f32, vp]),
     "palu_decode_step_qg": (i32, [vp, vp, i64, vp, i64, vp, i64, vp, vp, i64,
                                   vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64,

@@ -61,6 +61,11 @@ struct AbxParams {
   const h16* xmeta;
   int64_t sm_g, sm_l;       // elements
   int qgroup;               // columns per (scale, zero) pair: 0 = one pair per row, else R / qgroup pairs (chunked kernel)
+  int ncols;                // fast fp16 kernel: valid columns of the 16*NKS-column window (0 = all); the rest reads as zero
+  // multi-pass use of the fast kernel (ranks above 128: one launch per 128-column window of x, fp32 accumulation):
+  int ks0;                  // first fragment k-step of this pass (0)
+  float* acc;               // fp32 scores [H][acc_ld] of the ACC = 1 / 2 instantiations (store / atomic add of the partials)
+  int64_t acc_ld;
 };
 
 // heads per workgroup = 2*NMB; each MFMA M-block carries 2 heads x 8 pairs x {i, i+64}
@@ -425,7 +430,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_generic_kernel(AbxParams
 // per wave (half of its rows unused) instead of one per head pair, a quarter of the useful MFMA work -- and the 2*NMB
 // query heads are applied in the epilogue: rotate (k_i, k_i+64) once per pair, two FMAs per head.  The fragments come
 // from palu_abx_prepare_b on the [G, R, D] shared factor (one head per group); FOLD is not used.
-template <int NKS, int NMB, bool FOLD, bool TIMING = false, int QBITS = 0, bool ORDER2 = false, bool SHARED = false>
+// ACC: 0 = scores rounded to fp16 and stored to `out` (single pass); 1 / 2 = this launch is one pass over a 128-column
+// window of a wider rank: fp32 partial scores stored to (1) / added to (2) p.acc.
+template <int NKS, int NMB, bool FOLD, bool TIMING = false, int QBITS = 0, bool ORDER2 = false, bool SHARED = false, int ACC = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
   using Geo = LdsGeom<NKS>;
   static_assert(!SHARED || !FOLD, "the shared-B variant keeps q in the epilogue");
@@ -484,10 +491,23 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
     const unsigned long long xb = reinterpret_cast<unsigned long long>(xg);
     xrs[0] = __builtin_amdgcn_readfirstlane((unsigned)xb);
     xrs[1] = __builtin_amdgcn_readfirstlane((unsigned)(xb >> 32));
-    xrs[2] = __builtin_amdgcn_readfirstlane((unsigned)(((int64_t)(p.L - 1) * p.sx_l + 16 * NKS) * 2));
+    const int ncols = (QBITS == 0 && p.ncols > 0 && p.ncols < 16 * NKS) ? p.ncols : 16 * NKS;
+    xrs[2] = __builtin_amdgcn_readfirstlane((unsigned)(((int64_t)(p.L - 1) * p.sx_l + ncols) * 2));
     xrs[3] = 0x00020000u;
   }
-  const unsigned dma_voff = (unsigned)((tid / Geo::CPR) * p.sx_l * 2 + Geo::swz(tid / Geo::CPR, tid % Geo::CPR) * 16);
+  unsigned dma_voff = (unsigned)((tid / Geo::CPR) * p.sx_l * 2 + Geo::swz(tid / Geo::CPR, tid % Geo::CPR) * 16);
+  if (QBITS == 0 && p.ncols > 0 && p.ncols < 16 * NKS) {
+    // Rank below the 16*NKS-column window (e.g. R = 96 on the 128-column kernel; the B fragments are zero-padded by
+    // palu_abx_prepare_b): lanes whose 16-byte source chunk lies beyond the row get an offset at the end of the
+    // descriptor's range -- out of range whatever the scalar offset adds -- so they never read the NEXT row (which, for
+    // the last cached row, is uninitialised memory: 0 x NaN would poison a score).  Their LDS slots are zeroed once here:
+    // correct whether the hardware zero-fills or drops an out-of-range DMA lane.
+    if (Geo::swz(tid / Geo::CPR, tid % Geo::CPR) * 8 >= p.ncols) dma_voff = xrs[2];
+#pragma unroll
+    for (int k = 0; k < NRING * Geo::SPT; ++k)
+      *reinterpret_cast<u32x4*>(smem + (size_t)(tid + NTHREADS * k) * 16) = u32x4{0u, 0u, 0u, 0u};
+    __syncthreads();
+  }
   const unsigned row_bytes = __builtin_amdgcn_readfirstlane((unsigned)(p.sx_l * 2));
   auto dma_piece = [&](int tt, int slot, int k) {
     const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)((tile0 + tt) * TL + k * RPP) * row_bytes);
@@ -523,8 +543,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
     const int row = tid >> 2, quarter = tid & 3;
     const int l = min((tile0 + tt) * TL + row, p.L - 1);
     const unsigned* src = reinterpret_cast<const unsigned*>(xqg + (int64_t)l * p.sq_l) + quarter * NW;
+    // p.ncols < 16 * NKS: this launch covers a 128-column WINDOW of which only ncols are real (rank 96, or the last
+    // window of rank 160): dwords beyond the window's packed bytes are not read (they may lie behind the allocation);
+    // their codes read as 0 and dequantise to a finite value that meets zero-padded B fragments
+    const int qwin_dw = (p.ncols > 0 && p.ncols < 16 * NKS) ? (p.ncols * QBITS) / 32 : 4 * NW;
 #pragma unroll
-    for (int k = 0; k < NW; ++k) qraw[k] = __builtin_nontemporal_load(src + k);
+    for (int k = 0; k < NW; ++k) qraw[k] = (quarter * NW + k < qwin_dw) ? __builtin_nontemporal_load(src + k) : 0u;
     qmeta = *reinterpret_cast<const unsigned*>(xmg + (int64_t)l * p.sm_l);
   };
   auto store_q = [&](int slot) {
@@ -609,13 +633,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
   if (!PALU_ABX_B_FIRST || QBITS != 0) first_tiles();
 
   // ---- B fragments (issued early; consumed by the fold / first MFMA)
-  const u32x4* bf_base = p.bfrag + ((int64_t)(gb * 8 + w) * NMM) * NKS * 64 + lane;
+  // (nks_frag: k-steps per M-block in the fragment buffer -- NKS, or 8 * chunks when this launch is one pass over a
+  //  128-column window of a wider rank; ks0: first k-step of the window)
+  const int nks_frag = p.nks_frag > 0 ? p.nks_frag : NKS;
+  const u32x4* bf_base = p.bfrag + ((int64_t)(gb * 8 + w) * NMM) * nks_frag * 64 + (int64_t)p.ks0 * 64 + lane;
   h16x8 bf[NMM][NKS];
 #pragma unroll
   for (int mb = 0; mb < NMM; ++mb)
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) {
-      u32x4 v = bf_base[(int64_t)(mb * NKS + ks) * 64];
+      u32x4 v = bf_base[(int64_t)(mb * nks_frag + ks) * 64];
       bf[mb][ks] = *reinterpret_cast<h16x8*>(&v);
     }
   if (PALU_ABX_B_FIRST && QBITS == 0) first_tiles();
@@ -727,6 +754,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
   // scores leave through a buffer store: invalid (row >= L, padded head, pipeline warm-up) lanes get an
   // out-of-range offset that the hardware drops, so the store needs no branch inside the MFMA stream
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+  // multi-pass: partial scores of this 128-column window go to an fp32 array instead (same [head][position] indexing);
+  // the descriptor range (2 x the fp16 extent) drops the invalid lanes exactly like the fp16 store does
+  u32x4 arsrc;
+  {
+    const unsigned long long ab = reinterpret_cast<unsigned long long>(p.acc);
+    arsrc[0] = __builtin_amdgcn_readfirstlane((unsigned)ab);
+    arsrc[1] = __builtin_amdgcn_readfirstlane((unsigned)(ab >> 32));
+    arsrc[2] = __builtin_amdgcn_readfirstlane((unsigned)((((int64_t)(p.H - 1) * p.acc_ld + p.L) * 4)));
+    arsrc[3] = 0x00020000u;
+  }
 
   // cross-wave reduction of tile tt (partials in red[rslot]) and the fp16 store
   auto reduce_store = [&](int tt, int rslot) {
@@ -741,8 +778,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
     const int l = (tile0 + tt) * TL + pos;
     const int hloc = hb * HPW + slot;
     const bool ok = tt >= 0 && slot < HPW && l < p.L && hloc < p.gs;
-    const unsigned off = ok ? (unsigned)(((int64_t)(g * p.gs + hloc) * p.so_h + l) * 2) : 0xFFFFFFF0u;
-    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (h16)s), orsrc, off, 0, 0);
+    if (ACC == 0) {
+      const unsigned off = ok ? (unsigned)(((int64_t)(g * p.gs + hloc) * p.so_h + l) * 2) : 0xFFFFFFF0u;
+      __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (h16)s), orsrc, off, 0, 0);
+    } else {
+      const unsigned aoff = ok ? (unsigned)(((int64_t)(g * p.gs + hloc) * p.acc_ld + l) * 4) : 0xFFFFFFF0u;
+      if (ACC == 1) {
+        asm volatile("buffer_store_dword %0, %1, %2, 0 offen\n\ts_nop 0" ::"v"(s), "v"(aoff), "s"(arsrc) : "memory");
+      } else {
+        // every (head, position) is added to exactly once per pass, passes are stream-ordered: deterministic
+        asm volatile("buffer_atomic_add_f32 %0, %1, %2, 0 offen\n\ts_nop 0" ::"v"(s), "v"(aoff), "s"(arsrc) : "memory");
+      }
+    }
   };
 
   // X fragments are prefetched XD k-steps ahead through a ring of XD registers-sets: the fragment of

@@ -13,7 +13,22 @@ int launch_abx_q(const AbxParams& p, int nwg, hipStream_t stream) {
   }
   return launch_kernel(abx_rope_kernel<NKS, NMB, true, false, QBITS>, abx_smem_fast(NKS), p, nwg, stream);
 }
-// any other rank: the chunked kernel (128-column chunks, zero-padded B) with in-register dequantisation of every slot
+// any other rank with whole-row (scale, zero): 128-column WINDOWS through the fast 128-column kernel (masked staging of
+// the missing columns; with more than one window the partial scores are accumulated in an fp32 scratch, ACC = 1 / 2)
+template <int NMB, int QBITS, int ACC>
+int launch_abx_q_window(const AbxParams& p, int nwg, hipStream_t stream) {
+  if ((int64_t)p.pos0 + p.L > 262144)
+    return launch_kernel(abx_rope_kernel<8, NMB, true, false, QBITS, true, false, ACC>, abx_smem_fast(8), p, nwg, stream);
+  return launch_kernel(abx_rope_kernel<8, NMB, true, false, QBITS, false, false, ACC>, abx_smem_fast(8), p, nwg, stream);
+}
+__global__ void abx_q_round_kernel(const float* __restrict__ acc, int64_t acc_ld, h16* __restrict__ out, int64_t so_h, int L) {
+  const int h = blockIdx.y;
+  for (int l = blockIdx.x * blockDim.x + threadIdx.x; l < L; l += gridDim.x * blockDim.x)
+    out[(int64_t)h * so_h + l] = (h16)acc[(int64_t)h * acc_ld + l];
+}
+
+// group-wise (scale, zero) pairs, or no scratch for a rank above 128: the chunked kernel (128-column chunks, zero-padded
+// B, fragments re-read per chunk) with in-register dequantisation of every slot
 template <int NMB, int QBITS>
 int launch_abx_q_generic(const AbxParams& p, int nwg, hipStream_t stream) {
   return launch_kernel(abx_rope_generic_kernel<8, NMB, true, QBITS>, abx_smem_bytes(8, 2), p, nwg, stream);
@@ -23,35 +38,37 @@ int launch_abx_q_generic(const AbxParams& p, int nwg, hipStream_t stream) {
 static int abx_rope_q_impl(const void* a, int64_t sa_h, int64_t sa_d, const void* bfrag, const void* codes,
                            int64_t sc_g, int64_t sc_l, const void* meta, int64_t sm_g, int64_t sm_l, void* out,
                            int64_t so_h, int H, int G, int L, int R, int D, int bits, int group_size, const float* inv_freq,
-                           int pos0, palu_stream_t stream);
+                           int pos0, void* scratch, palu_stream_t stream);
 
 extern "C" int palu_abx_rope_q(const void* a, int64_t sa_h, int64_t sa_d, const void* bfrag, const void* codes,
                                int64_t sc_g, int64_t sc_l, const void* meta, int64_t sm_g, int64_t sm_l, void* out,
                                int64_t so_h, int H, int G, int L, int R, int D, int bits, const float* inv_freq,
                                int pos0, palu_stream_t stream) {
   return abx_rope_q_impl(a, sa_h, sa_d, bfrag, codes, sc_g, sc_l, meta, sm_g, sm_l, out, so_h, H, G, L, R, D, bits, 0, inv_freq,
-                         pos0, stream);
+                         pos0, nullptr, stream);
 }
 
 // the same on rows quantised in column groups (quantize_tensor(..., group_size > 0), quant.py:11-13, --lt_group_size):
 // meta [G, L, R / group_size, 2]; the packed codes are laid out exactly as for whole-row quantisation
+// scratch: optional fp32 array of palu_abx_scratch_bytes(H, G, L, R) bytes -- with it a whole-row-quantised rank above 128
+// runs as passes of the fast kernel instead of the chunked one
 extern "C" int palu_abx_rope_qg(const void* a, int64_t sa_h, int64_t sa_d, const void* bfrag, const void* codes,
                                 int64_t sc_g, int64_t sc_l, const void* meta, int64_t sm_g, int64_t sm_l, void* out,
                                 int64_t so_h, int H, int G, int L, int R, int D, int bits, int group_size,
-                                const float* inv_freq, int pos0, palu_stream_t stream) {
+                                const float* inv_freq, int pos0, void* scratch, palu_stream_t stream) {
   if (group_size == R) group_size = 0;
   PALU_REQUIRE(group_size == 0 || (group_size > 0 && R % group_size == 0 && group_size % 8 == 0), PALU_ERR_UNSUPPORTED,
                "abx_qg: group_size %d must divide R %d and be a multiple of 8", group_size, R);
   PALU_REQUIRE(group_size == 0 || sm_l >= 2 * (R / group_size), PALU_ERR_ARG,
                "abx_qg: meta rows hold R / group_size (scale, zero) pairs");
   return abx_rope_q_impl(a, sa_h, sa_d, bfrag, codes, sc_g, sc_l, meta, sm_g, sm_l, out, so_h, H, G, L, R, D, bits, group_size,
-                         inv_freq, pos0, stream);
+                         inv_freq, pos0, scratch, stream);
 }
 
 static int abx_rope_q_impl(const void* a, int64_t sa_h, int64_t sa_d, const void* bfrag, const void* codes,
                            int64_t sc_g, int64_t sc_l, const void* meta, int64_t sm_g, int64_t sm_l, void* out,
                            int64_t so_h, int H, int G, int L, int R, int D, int bits, int group_size, const float* inv_freq,
-                           int pos0, palu_stream_t stream) {
+                           int pos0, void* scratch, palu_stream_t stream) {
   AbxPlan pl;
   PALU_REQUIRE(abx_plan(H, G, R, &pl), PALU_ERR_ARG, "abx_q: bad shape H=%d G=%d R=%d", H, G, R);
   PALU_REQUIRE(D == HEAD_DIM, PALU_ERR_UNSUPPORTED, "abx_q: head_dim must be 128 (got %d)", D);
@@ -80,6 +97,39 @@ static int abx_rope_q_impl(const void* a, int64_t sa_h, int64_t sa_d, const void
   p.out = (h16*)out; p.so_h = so_h; p.out_bytes = (unsigned)ob;
   p.inv_freq = inv_freq;
   const int nks_frag = pl.nks_tot;       // how palu_abx_prepare_b laid the fragments out for (H, G, R)
+  // windows of 128 columns through the fast kernel: whole-row metas, fragments in the chunked layout (8 k-steps per
+  // window: every rank that is not 32 / 64 / 128), and an fp32 scratch when there is more than one window
+  const int nwin = (R + 127) / 128;
+  if (!fast && group_size == 0 && pl.chunked && (nwin == 1 || (scratch && ((uintptr_t)scratch & 15) == 0))) {
+    hipStream_t sw = (hipStream_t)stream;
+    const int nwg = abx_fill_params(p, pl, H, G, L, R, pos0);
+    const int64_t acc_ld = ((int64_t)L + 7) & ~(int64_t)7;
+    for (int kc = 0; kc < nwin; ++kc) {
+      AbxParams pk = p;
+      pk.xq = (const unsigned char*)codes + (size_t)kc * 128 * bits / 8;
+      pk.ncols = R - 128 * kc < 128 ? R - 128 * kc : 128;
+      pk.nks_frag = nks_frag;
+      pk.ks0 = 8 * kc;
+      pk.acc = (float*)scratch;
+      pk.acc_ld = acc_ld;
+      int rc;
+#define PALU_ABXQ_WIN(ACCV)                                                                                   \
+  (bits == 3 ? (pl.nmb == 2 ? launch_abx_q_window<2, 3, ACCV>(pk, nwg, sw) : launch_abx_q_window<1, 3, ACCV>(pk, nwg, sw)) \
+             : (pl.nmb == 2 ? launch_abx_q_window<2, 4, ACCV>(pk, nwg, sw) : launch_abx_q_window<1, 4, ACCV>(pk, nwg, sw)))
+      if (nwin == 1) rc = PALU_ABXQ_WIN(0);
+      else if (kc == 0) rc = PALU_ABXQ_WIN(1);
+      else rc = PALU_ABXQ_WIN(2);
+#undef PALU_ABXQ_WIN
+      if (rc) return rc;
+    }
+    if (nwin > 1) {
+      int bx = (L + 255) / 256;
+      if (bx > 256) bx = 256;
+      hipLaunchKernelGGL(abx_q_round_kernel, dim3(bx, H), dim3(256), 0, sw, (const float*)scratch, acc_ld, (h16*)out, so_h, L);
+      PALU_LAUNCH_CHECK();
+    }
+    return PALU_OK;
+  }
   if (!fast) {
     // plan the launch as the chunked fp16 kernel does: 128-column chunks whatever R is
     pl.chunked = true;

@@ -9,7 +9,7 @@
 namespace {
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 struct StepWs {
-  size_t q, scores, ctx, pv, knew, vnew, total;
+  size_t q, scores, ctx, pv, knew, vnew, acc, total;
 };
 StepWs step_layout(int H, int G, int D, int Lcap, int Rv) {
   StepWs w;
@@ -20,6 +20,7 @@ StepWs step_layout(int H, int G, int D, int Lcap, int Rv) {
   w.pv = o;     o += align256(palu_pv_workspace_bytes(H, G, Lcap, Rv));
   w.knew = o;   o += align256((size_t)4096 * 2);   // new latent rows before quantisation (G*Rk <= 4096)
   w.vnew = o;   o += align256((size_t)16384 * 2);
+  w.acc = o;    o += align256((size_t)H * (((size_t)Lcap + 8 + 7) & ~(size_t)7) * 4);   // fp32 scores of a multi-pass rank (> 128)
   w.total = o;
   return w;
 }
@@ -54,7 +55,8 @@ static int decode_step_impl(bool shared_b, const void* hidden, const void* wq, i
                                    Rv, D, inv_freq, 0, sqrtf((float)D), stream);
   } else {
     rc = shared_b ? palu_abx_rope_shared_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, scores, ss_h, H, G, L, Rk, D, inv_freq, 0, stream)
-                  : palu_abx_rope_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, scores, ss_h, H, G, L, Rk, D, inv_freq, 0, stream);
+                  : palu_abx_rope_ws_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, scores, ss_h, H, G, L, Rk, D, inv_freq, 0,
+                                         ws + w.acc, stream);
     if (rc) return rc;
     rc = palu_softmax_pv_f16(scores, ss_h, mask, v_cache, sv_g, sv_l, ctx, probs, sp_h, pvws, H, G, L, Rv,
                              sqrtf((float)D), stream);
@@ -109,7 +111,7 @@ extern "C" int palu_decode_attend_f16(const void* hidden, const void* wq, int64_
   if (palu_decode_attn_preferred(H, G, L, Rk, Rv, D))
     return palu_decode_attn_mask_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, v_cache, sv_g, sv_l, mask, ctx, pvws, H, G, L, Rk,
                                      Rv, D, inv_freq, 0, sqrtf((float)D), stream);
-  rc = palu_abx_rope_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, scores, ss_h, H, G, L, Rk, D, inv_freq, 0, stream);
+  rc = palu_abx_rope_ws_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, scores, ss_h, H, G, L, Rk, D, inv_freq, 0, ws + w.acc, stream);
   if (rc) return rc;
   return palu_softmax_pv_f16(scores, ss_h, mask, v_cache, sv_g, sv_l, ctx, nullptr, 0, pvws, H, G, L, Rv,
                              sqrtf((float)D), stream);
@@ -178,7 +180,7 @@ extern "C" int palu_decode_step_qg(const void* hidden, const void* wq, int64_t l
   }
   if (rc) return rc;
   rc = palu_abx_rope_qg(q, D, 1, bfrag, k_codes, skc_g, skc_l, k_meta, skm_g, skm_l, scores, ss_h, H, G, L, Rk, D, bits,
-                        group_size, inv_freq, 0, stream);
+                        group_size, inv_freq, 0, ws + w.acc, stream);
   if (rc) return rc;
   rc = palu_softmax_pv_qg(scores, ss_h, mask, v_codes, svc_g, svc_l, v_meta, svm_g, svm_l, ctx, probs, sp_h, pvws, H, G, L,
                           Rv, bits, group_size, sqrtf((float)D), stream);

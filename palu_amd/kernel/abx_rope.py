@@ -133,9 +133,13 @@ def abx(a: torch.Tensor, b: torch.Tensor, x: torch.Tensor, *, theta: float = 100
                                                          _lib.current_stream()), "palu_abx_rope_shared_f16")
             return out
         frag = prepare_b(b, G)
-        _lib.check(_lib.lib.palu_abx_rope_f16(a.data_ptr(), a.stride(0), a.stride(2), frag.data_ptr(),
-                                              x.data_ptr(), x.stride(0), x.stride(1),
-                                              out.data_ptr(), out.stride(0), H, G, L, R, D,
-                                              inv.data_ptr(), int(pos_offset), _lib.current_stream()),
-                   "palu_abx_rope_f16")
+        # ranks above 128: fp32 scratch for the multi-pass form of the fast kernel (0 bytes otherwise)
+        nscr = _lib.lib.palu_abx_scratch_bytes(H, G, L, R)
+        scratch = torch.empty(nscr, dtype=torch.uint8, device=x.device) if nscr else None
+        _lib.check(_lib.lib.palu_abx_rope_ws_f16(a.data_ptr(), a.stride(0), a.stride(2), frag.data_ptr(),
+                                                 x.data_ptr(), x.stride(0), x.stride(1),
+                                                 out.data_ptr(), out.stride(0), H, G, L, R, D,
+                                                 inv.data_ptr(), int(pos_offset), 0 if scratch is None else scratch.data_ptr(),
+                                                 _lib.current_stream()),
+                   "palu_abx_rope_ws_f16")
     return out

@@ -39,18 +39,29 @@ def test_abx_q_equals_fp16_kernel_on_dequantised_latents(bits, R, gs, H, L):
     out = torch.empty(H, 1, L, dtype=torch.float16, device=DEV)
     frag = prepare_b(b, G)
     inv = rope_inv_freq(x.device)
-    _lib.check(_lib.lib.palu_abx_rope_q(a.data_ptr(), a.stride(0), a.stride(2), frag.data_ptr(), codes.data_ptr(),
-                                        codes.stride(0), codes.stride(1), meta.data_ptr(), meta.stride(0), meta.stride(1),
-                                        out.data_ptr(), out.stride(0), H, G, L, R, 128, bits, inv.data_ptr(), 0,
-                                        _lib.current_stream()), "abx_q")
-    # same kernel class on both sides (fast/fast or chunked/chunked) -> the same MFMA stream on the same fp16 operands:
-    # bit-identical.  3 bit at R = 32 / 64 has no fast quantised kernel (quarter rows are not whole dwords): the codes go
-    # through the chunked kernel (q kept in fp32) while the fp16 reference takes the fast one (q folded into B): equal to
-    # rounding only, both within the oracle bound below
+    # ranks above 128 run as passes of the 128-column kernel when an fp32 scratch is handed over (palu_abx_rope_qg)
+    nscr = _lib.lib.palu_abx_scratch_bytes(H, G, L, R)
+    scratch = torch.empty(max(nscr, 16), dtype=torch.uint8, device=DEV)
+    _lib.check(_lib.lib.palu_abx_rope_qg(a.data_ptr(), a.stride(0), a.stride(2), frag.data_ptr(), codes.data_ptr(),
+                                         codes.stride(0), codes.stride(1), meta.data_ptr(), meta.stride(0), meta.stride(1),
+                                         out.data_ptr(), out.stride(0), H, G, L, R, 128, bits, 0, inv.data_ptr(), 0,
+                                         scratch.data_ptr() if nscr else 0, _lib.current_stream()), "abx_qg")
+    # The quantised kernel stages the SAME fp16 values the fp16 kernel reads; where both run the same pipeline -- the
+    # 128-column kernel with q folded into B, one or several column windows -- the scores are bit-identical.  Only 3 bit
+    # at R = 32 / 64 differs (no fast quantised kernel: quarter rows are not whole dwords; the codes take the chunked
+    # kernel with q kept in fp32): equal to rounding, both within the oracle bound below.
     if not (bits == 3 and R in (32, 64)):
         assert torch.equal(out, ref)
     else:
         assert (out.float() - ref.float()).abs().max().item() <= 2e-3 * ref.float().abs().max().item()
+    # without scratch a rank above 128 falls back to the chunked kernel: same scores to rounding
+    if nscr:
+        out2 = torch.empty_like(out)
+        _lib.check(_lib.lib.palu_abx_rope_q(a.data_ptr(), a.stride(0), a.stride(2), frag.data_ptr(), codes.data_ptr(),
+                                            codes.stride(0), codes.stride(1), meta.data_ptr(), meta.stride(0), meta.stride(1),
+                                            out2.data_ptr(), out2.stride(0), H, G, L, R, 128, bits, inv.data_ptr(), 0,
+                                            _lib.current_stream()), "abx_q")
+        assert (out2.float() - ref.float()).abs().max().item() <= 2e-3 * ref.float().abs().max().item()
     o = oracle.abx_scores(a.cpu(), b.cpu(), oracle.quantize_rows(x.cpu().reshape(-1, R), bits)[0].reshape(G, L, R))
     scale = o.float().abs().max().item()
     assert (out.cpu().float() - o.float()).abs().max().item() <= 1e-3 * scale

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""The CHUNKED score kernel (ranks outside {32, 64, 128}: 128-column chunks, zero-padded B, fragments re-read per chunk):
-us, MFMA TFLOP/s on the useful flops and HBM fraction, fp16 and packed latents, at the ranks the rank search emits
-(palu/rank_search.py:11-17) and the reference test's 512 -- VERDICT r2 item 8 asked for these numbers."""
+"""The score kernel at ranks outside {32, 64, 128} -- the ranks the rank search emits (palu/rank_search.py:11-17) and the
+reference test's 512: us, MFMA TFLOP/s on the useful flops and HBM fraction, fp16 and packed latents.  Round 2 ran all of
+them on the chunked kernel (128-column chunks, fragments re-read per chunk, spilling); since round 3 they are column
+windows of the 128-column fast kernel (masked staging, fp32 accumulation across windows).  VERDICT r2 item 8."""
 import math
 import torch
 from palu_amd import _lib
@@ -42,10 +43,13 @@ for R in (96, 128, 160, 224, 256, 512):
         if bits == 3 and R % 32:
             continue
         codes, meta = q.quantize_pack(x, bits)
-        fq = lambda: _lib.check(lib.palu_abx_rope_q(a.data_ptr(), a.stride(0), a.stride(2), frag.data_ptr(), codes.data_ptr(),
-                                                    codes.stride(0), codes.stride(1), meta.data_ptr(), meta.stride(0),
-                                                    meta.stride(1), out.data_ptr(), out.stride(0), H, G, L, R, 128, bits,
-                                                    inv.data_ptr(), 0, _lib.current_stream()), "abx_q")
+        nscr = lib.palu_abx_scratch_bytes(H, G, L, R)
+        scr = torch.empty(max(nscr, 16), dtype=torch.uint8, device=dev)
+        fq = lambda: _lib.check(lib.palu_abx_rope_qg(a.data_ptr(), a.stride(0), a.stride(2), frag.data_ptr(), codes.data_ptr(),
+                                                     codes.stride(0), codes.stride(1), meta.data_ptr(), meta.stride(0),
+                                                     meta.stride(1), out.data_ptr(), out.stride(0), H, G, L, R, 128, bits, 0,
+                                                     inv.data_ptr(), 0, scr.data_ptr() if nscr else 0,
+                                                     _lib.current_stream()), "abx_qg")
         uq = t(fq)
         line += f" | {bits}-bit {uq:8.1f} us"
     print(line, flush=True)
