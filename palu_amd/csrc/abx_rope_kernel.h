@@ -866,7 +866,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
           cc = fmaf(lo, sn[j], cs[j]);
           ss = fmaf(-lo, cs[j], sn[j]);
         }
-        asm volatile("" : "+v"(cc), "+v"(ss));
+        // (no empty-asm pin on cc / ss here: hipcc pads one s_nop behind an asm whose outputs the next VALU reads --
+        //  16 of the loop's 20 s_nop per tile -- and the 4-VALU-per-gap interleave holds without it; -0.7 us at C2)
       } else if (t <= NMB) {
         const int mb = t - 1;
         if (SHARED) {
