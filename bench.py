@@ -77,7 +77,10 @@ def _gate():
     """~100 us of device-side spin in front of a timed loop: the host queues the loop's launches while the GPU is still
     busy, so the device-event time between the two records is back-to-back execution from a full queue -- not the host's
     first-launch latency (3-16 us per forward, MI355X_MICROARCH.md `graph-replay-floor`) amortised over K steps."""
-    torch.cuda._sleep(200_000)
+    try:
+        torch.cuda._sleep(200_000)
+    except Exception:                      # noqa: BLE001 -- private torch API: without it the events see the first launch latency
+        pass
 
 
 def time_reps(fn, steps, warmup, sync, reps=REPS, settle_ms=20.0):

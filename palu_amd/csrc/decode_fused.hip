@@ -3,7 +3,7 @@
 // Replaces kernel/palu_attention.py:219 (recompute_k_gemv + /sqrt(D)), :238 (softmax) and :246-251 (latent P.V).
 #include "decode_fused_kernel.h"
 
-int palu_pv_combine_launch(float* ws, void* ctx, int H, int G, int Rv, int ns, hipStream_t s);   // decode_pv.hip
+int palu_pv_combine_launch(float* ws, void* ctx, int H, int G, int Rv, int ns, hipStream_t s, int ctx_ld);   // decode_pv.hip
 
 namespace {
 
@@ -157,7 +157,7 @@ extern "C" int palu_decode_attn_mask_f16(const void* q, int64_t sq_h, int64_t sq
   else rc = PALU_FUSED(4);
 #undef PALU_FUSED
   if (rc) return rc;
-  return palu_pv_combine_launch(ws, ctx, H, G, Rv, ns, s);
+  return palu_pv_combine_launch(ws, ctx, H, G, Rv, ns, s, 0);
 }
 
 // Debug/profiling entry (not part of the stable ABI): C2-class shape only (Rk = 128, Rv = 384); per-wave cycle stamps

@@ -916,9 +916,6 @@ struct CombineParams {
   int ctx_ld;      // elements between the context rows of consecutive heads (Rv unless a column group is written, _qg)
 };
 
-// row stride of the context the merge writes: 0 = Rv.  Set (per thread) by palu_softmax_pv_qg around its per-column-group
-// calls, so that each group's [H, group] slice lands in place inside the [H, Rv] context.
-thread_local int g_ctx_ld = 0;
 
 // grid (H, ceil(Rv/64)), 512 threads: the 8 waves share the splits of one head for 64 context columns
 // (8 independent loads in flight per lane: the merge is latency-, not bandwidth-bound), LDS sum at the end.
@@ -1082,14 +1079,14 @@ int pv_nsplit_bound(int G, int Lcap, int Rv) {
 }  // namespace
 
 // split merge shared with the fused decode kernel (decode_fused.hip): ws = stats [H][2] (padded) | part [H][ns][Rv] | ml [H][ns][2]
-int palu_pv_combine_launch(float* ws, void* ctx, int H, int G, int Rv, int ns, hipStream_t s) {
+int palu_pv_combine_launch(float* ws, void* ctx, int H, int G, int Rv, int ns, hipStream_t s, int ctx_ld) {
   CombineParams c;
   c.part = ws + pv_ws_stats_floats(H);
   c.ml = c.part + (size_t)H * ns * Rv;
   c.ctx = (h16*)ctx;
   c.stats = ws;
   c.G = G; c.gs = H / G; c.Rv = Rv; c.nsplit = ns;
-  c.ctx_ld = g_ctx_ld ? g_ctx_ld : Rv;
+  c.ctx_ld = ctx_ld > 0 ? ctx_ld : Rv;
   hipLaunchKernelGGL(pv_combine_kernel, dim3(H * ((Rv + 63) / 64)), dim3(64 * CB_WAVES), 0, s, c);
   PALU_LAUNCH_CHECK();
   return PALU_OK;
@@ -1151,7 +1148,7 @@ static int pv_qr_plan(int G, int L, int Rv, int cw, int* nsl_o, int* ncw_o, int*
 }
 static int pv_qr_launch(const void* scores, int64_t ss_h, const void* mask, const void* rows, int64_t sc_g, int64_t sc_l,
                         const void* meta, int64_t sm_g, int64_t sm_l, void* ctx, void* probs, int64_t sp_h,
-                        void* workspace, int H, int G, int L, int Rv, int bits, float sqrt_d, hipStream_t s) {
+                        void* workspace, int H, int G, int L, int Rv, int bits, float sqrt_d, hipStream_t s, int ctx_ld = 0) {
   static int qr_enabled = -1, qr16_enabled = -1;
   if (qr_enabled < 0) {
     const char* e = getenv("PALU_PVQ_DIRECT");
@@ -1230,7 +1227,7 @@ static int pv_qr_launch(const void* scores, int64_t ss_h, const void* mask, cons
 #undef PALU_PVQR
 #undef PALU_PVQR2
   PALU_LAUNCH_CHECK();
-  int rcq = palu_pv_combine_launch(ws, ctx, H, G, Rv, ns, s);
+  int rcq = palu_pv_combine_launch(ws, ctx, H, G, Rv, ns, s, ctx_ld);
   if (rcq) return rcq;
   if (probs) {
     int bx = (L + 255) / 256;
@@ -1245,6 +1242,7 @@ static int pv_qr_launch(const void* scores, int64_t ss_h, const void* mask, cons
 extern "C" int palu_softmax_pv_f16(const void* scores, int64_t ss_h, const void* mask, const void* v, int64_t sv_g,
                                    int64_t sv_l, void* ctx, void* probs, int64_t sp_h, void* workspace, int H, int G,
                                    int L, int Rv, float sqrt_d, palu_stream_t stream) {
+  const int ctx_ld = 0;   // context rows are Rv apart
   PALU_REQUIRE(H > 0 && G > 0 && H % G == 0 && L > 0 && Rv > 0, PALU_ERR_ARG, "softmax_pv: bad shape");
   PALU_REQUIRE(scores && v && ctx && workspace, PALU_ERR_ARG, "softmax_pv: null pointer");
   const int gs = H / G;
@@ -1287,7 +1285,7 @@ extern "C" int palu_softmax_pv_f16(const void* scores, int64_t ss_h, const void*
   CombineParams c;
   c.part = p.part; c.ml = p.ml; c.ctx = (h16*)ctx; c.stats = stats;
   c.G = G; c.gs = gs; c.Rv = Rv; c.nsplit = ns;
-  c.ctx_ld = g_ctx_ld ? g_ctx_ld : Rv;
+  c.ctx_ld = ctx_ld > 0 ? ctx_ld : Rv;
   hipLaunchKernelGGL(pv_combine_kernel, dim3(H * ((Rv + 63) / 64)), dim3(64 * CB_WAVES), 0, s, c);
   PALU_LAUNCH_CHECK();
   if (probs) {
@@ -1300,10 +1298,24 @@ extern "C" int palu_softmax_pv_f16(const void* scores, int64_t ss_h, const void*
   return PALU_OK;
 }
 
+// ctx_ld: elements between the context rows of consecutive heads (0 = Rv; palu_softmax_pv_qg writes column groups in place)
+static int softmax_pv_q_impl(const void* scores, int64_t ss_h, const void* mask, const void* codes, int64_t sc_g,
+                             int64_t sc_l, const void* meta, int64_t sm_g, int64_t sm_l, void* ctx, void* probs,
+                             int64_t sp_h, void* workspace, int H, int G, int L, int Rv, int bits, float sqrt_d,
+                             palu_stream_t stream, int ctx_ld);
+
 extern "C" int palu_softmax_pv_q(const void* scores, int64_t ss_h, const void* mask, const void* codes, int64_t sc_g,
                                  int64_t sc_l, const void* meta, int64_t sm_g, int64_t sm_l, void* ctx, void* probs,
                                  int64_t sp_h, void* workspace, int H, int G, int L, int Rv, int bits, float sqrt_d,
                                  palu_stream_t stream) {
+  return softmax_pv_q_impl(scores, ss_h, mask, codes, sc_g, sc_l, meta, sm_g, sm_l, ctx, probs, sp_h, workspace, H, G, L, Rv,
+                           bits, sqrt_d, stream, 0);
+}
+
+static int softmax_pv_q_impl(const void* scores, int64_t ss_h, const void* mask, const void* codes, int64_t sc_g,
+                             int64_t sc_l, const void* meta, int64_t sm_g, int64_t sm_l, void* ctx, void* probs,
+                             int64_t sp_h, void* workspace, int H, int G, int L, int Rv, int bits, float sqrt_d,
+                             palu_stream_t stream, int ctx_ld) {
   PALU_REQUIRE(H > 0 && G > 0 && H % G == 0 && L > 0 && Rv > 0, PALU_ERR_ARG, "softmax_pv_q: bad shape");
   PALU_REQUIRE(scores && codes && meta && ctx && workspace, PALU_ERR_ARG, "softmax_pv_q: null pointer");
   PALU_REQUIRE(bits == 3 || bits == 4, PALU_ERR_UNSUPPORTED, "softmax_pv_q: bits must be 3 or 4");
@@ -1319,7 +1331,7 @@ extern "C" int palu_softmax_pv_q(const void* scores, int64_t ss_h, const void* m
   // register-direct matrix-core kernel first (pv_partial_qr_kernel); the VALU kernel below takes what it does not
   {
     const int rcq = pv_qr_launch(scores, ss_h, mask, codes, sc_g, sc_l, meta, sm_g, sm_l, ctx, probs, sp_h, workspace, H, G, L,
-                                 Rv, bits, sqrt_d, s);
+                                 Rv, bits, sqrt_d, s, ctx_ld);
     if (rcq != PV_QR_NOT_TAKEN) return rcq;
   }
   const int ns = (L + rps - 1) / rps;
@@ -1362,7 +1374,7 @@ extern "C" int palu_softmax_pv_q(const void* scores, int64_t ss_h, const void* m
   CombineParams c;
   c.part = p.part; c.ml = p.ml; c.ctx = (h16*)ctx; c.stats = stats;
   c.G = G; c.gs = gs; c.Rv = Rv; c.nsplit = ns;
-  c.ctx_ld = g_ctx_ld ? g_ctx_ld : Rv;
+  c.ctx_ld = ctx_ld > 0 ? ctx_ld : Rv;
   hipLaunchKernelGGL(pv_combine_kernel, dim3(H * ((Rv + 63) / 64)), dim3(64 * CB_WAVES), 0, s, c);
   PALU_LAUNCH_CHECK();
   if (probs) {
@@ -1394,11 +1406,9 @@ extern "C" int palu_softmax_pv_qg(const void* scores, int64_t ss_h, const void* 
   const int ng = Rv / group_size;
   const int gbytes = group_size * bits / 8;
   int rc = PALU_OK;
-  g_ctx_ld = Rv;
   for (int q = 0; q < ng && rc == PALU_OK; ++q)
-    rc = palu_softmax_pv_q(scores, ss_h, mask, (const char*)codes + (size_t)q * gbytes, sc_g, sc_l, (const h16*)meta + 2 * q,
+    rc = softmax_pv_q_impl(scores, ss_h, mask, (const char*)codes + (size_t)q * gbytes, sc_g, sc_l, (const h16*)meta + 2 * q,
                            sm_g, sm_l, (h16*)ctx + (size_t)q * group_size, q == 0 ? probs : nullptr, sp_h, workspace, H, G, L,
-                           group_size, bits, sqrt_d, stream);
-  g_ctx_ld = 0;
+                           group_size, bits, sqrt_d, stream, Rv);
   return rc;
 }

@@ -346,7 +346,11 @@ def test_softmax_pv_full_size_c2_properties():
 
 
 @pytest.mark.parametrize("M,N,K,R", [(1000, 1024, 4096, 128), (63, 4096, 4096, 512), (129, 768, 512, 96), (4096, 3072, 4096, 384),
-                                     (1, 256, 4096, 32)])
+                                     (1, 256, 4096, 32),
+                                     # the 256x256 LDS-DMA kernel (M >= 512, N >= 256, K >= 512): ragged token tiles, a half-used
+                                     # column tile, more token tiles than one round of the 8 XCDs, a single k-tile pair
+                                     (600, 384, 512, 96), (777, 1280, 1024, 160), (2304 + 17, 512, 4096, 128), (512, 256, 512, 256),
+                                     (8192, 1024, 4096, 256)])
 def test_lowrank_project_gemm(M, N, K, R):
     """Prefill down-projection (MFMA GEMM) vs fp64, written into the [G, L, R] cache layout at a row offset."""
     lib = _lib()
