@@ -212,6 +212,7 @@ extern "C" int palu_abx_rope_shared_f16(const void* a, int64_t sa_h, int64_t sa_
   p.out = (h16*)out; p.so_h = so_h; p.out_bytes = (unsigned)ob;
   p.inv_freq = inv_freq;
   const int nwg = abx_fill_params(p, pl, H, G, L, R, pos0);
+  p.prio_mode = abx_prio_mode(true);
   hipStream_t s = (hipStream_t)stream;
 #define PALU_ABX_SH(NKS) (pl.nmb == 2 ? launch_abx_shared<NKS, 2>(p, nwg, s) : launch_abx_shared<NKS, 1>(p, nwg, s))
   switch (R) {

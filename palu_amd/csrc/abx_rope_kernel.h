@@ -1094,13 +1094,21 @@ inline bool abx_plan(int H, int G, int R, AbxPlan* pl) {
   return true;
 }
 
-inline int abx_prio_mode() {
-  static int m = -1;
-  if (m < 0) {
+// Wave priorities inside a workgroup (PALU_ABX_PRIO_MODE overrides): 0 none, 1 waves 4-7 raised for the whole kernel,
+// 2 waves 4-7 raised for the first half of every tile (both waves of a SIMD then finish a tile together; worth 1-2 % on
+// the packed score kernels, nothing at C2).  The shared-B kernel runs WITHOUT priorities: with mode 2 its first launch in
+// a fresh process returned, in 20-30 % of the processes, one wave's partial scores of the last 16 rows of a workgroup's
+// last tile wrong (lanes 16-31 / 48-63 of the drain's q-dot); 0 of 98 cold processes with modes 0 / 1, and the per-head
+// and packed kernels are deterministic under mode 2 (12 of 12 each).  Not understood -- the MFMA -> v_permlane32_swap
+// distance in the drain is 12 wait states, and tools/ubench_mfma_hazard.hip shows 6 are enough with and without a
+// second wave on the matrix pipe -- so the toggling is simply not used there (profiles/r03_shared_b_cold_start.txt).
+inline int abx_prio_mode(bool shared = false) {
+  static int m = -2;
+  if (m == -2) {
     const char* e = getenv("PALU_ABX_PRIO_MODE");
-    m = e ? atoi(e) : 2;
+    m = e ? atoi(e) : -1;
   }
-  return m;
+  return m >= 0 ? m : (shared ? 0 : 2);
 }
 
 // fills the launch-independent part of the parameters; returns the number of workgroups

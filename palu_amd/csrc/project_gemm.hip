@@ -119,17 +119,21 @@ __global__ __launch_bounds__(PG_THREADS, 2) void project_gemm_kernel(PgParams p)
 // per wave per k-tile with a scalar offset.  Two LDS buffers (2 x 64 KB), tile kt+1 in flight under the MFMAs of tile kt,
 // `s_waitcnt vmcnt(0)` + barrier per k-tile.  Workgroup -> tile: the 8 XCDs each take every 8th token tile and run
 // its column tiles back to back, so the X rows of a token tile are fetched into ONE L2.
-constexpr int PL_BM = 256, PL_BN = 256, PL_THREADS = 512;
+constexpr int PL_BM = 256, PL_THREADS = 512;   // column tile: 128 * NI (NI = 2: 256 x 256; NI = 1: 256 x 128 for grids that would not fill the chip)
 
+template <int NI>
 __global__ __launch_bounds__(PL_THREADS, 1) void project_gemm_256_kernel(PgParams p, int ntn, int ntm) {
-  extern __shared__ __attribute__((aligned(1024))) char smem_l[];   // [buf][X | VT][256 rows][64 halfs] = 128 KB
+  extern __shared__ __attribute__((aligned(1024))) char smem_l[];   // [buf][X 256 rows | VT 128 NI rows][64 halfs] = 2 x (32 + 16 NI) KB
+  constexpr int PL_BN = 128 * NI;
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wv >> 2, wn = wv & 3;
   const int b = blockIdx.x, j = b >> 3;
   const int mt = (j / ntn) * 8 + (b & 7), nt = j % ntn;
   if (mt >= ntm) return;
   const int m0 = mt * PL_BM, n0 = nt * PL_BN;
-  constexpr int TILE = PL_BM * PG_BK * 2;   // 32 KB per operand tile
+  constexpr int TILE = PL_BM * PG_BK * 2;   // 32 KB: X tile
+  constexpr int WTILE = PL_BN * PG_BK * 2;  // VT tile
+  constexpr int BUF = TILE + WTILE;
 
   auto make_rsrc = [](const void* base) {
     u32x4 r;
@@ -143,12 +147,12 @@ __global__ __launch_bounds__(PL_THREADS, 1) void project_gemm_256_kernel(PgParam
   const u32x4 xrs = make_rsrc(p.x + (int64_t)m0 * p.ldx), wrs = make_rsrc(p.w + (int64_t)n0 * p.ldw);
   // piece pi = wv + 8 i holds tile rows 8 pi + lane/8; chunk position lane%8 holds source chunk pos ^ key(row)
   const int prow = lane >> 3, key = (4 * (wv & 1) + (lane >> 4)) & 7, csrc = (lane & 7) ^ key;
-  unsigned xvo[4], wvo[4];
+  unsigned xvo[4], wvo[2 * NI];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int row = 8 * (wv + 8 * i) + prow;
     xvo[i] = (unsigned)(min(row, p.M - 1 - m0) * (int)p.ldx * 2 + csrc * 16);
-    wvo[i] = (unsigned)(min(row, p.N - 1 - n0) * (int)p.ldw * 2 + csrc * 16);
+    if (i < 2 * NI) wvo[i] = (unsigned)(min(row, p.N - 1 - n0) * (int)p.ldw * 2 + csrc * 16);
   }
   const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>(smem_l);
   auto dma = [&](unsigned dst, unsigned voff, const u32x4& rs, unsigned soff) {
@@ -162,17 +166,17 @@ __global__ __launch_bounds__(PL_THREADS, 1) void project_gemm_256_kernel(PgParam
   };
   auto stage = [&](int kt, int buf) {
     const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)kt * (PG_BK * 2));
-    const unsigned d = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * 2 * TILE + wv * 1024));
+    const unsigned d = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * BUF + wv * 1024));
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       dma(d + i * 8192, xvo[i], xrs, soff);
-      dma(d + TILE + i * 8192, wvo[i], wrs, soff);
+      if (i < 2 * NI) dma(d + TILE + i * 8192, wvo[i], wrs, soff);
     }
   };
 
-  f32x16 acc[2][4];   // [latent-column tile][token tile]
+  f32x16 acc[NI][4];   // [latent-column tile][token tile]
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
@@ -183,24 +187,24 @@ __global__ __launch_bounds__(PL_THREADS, 1) void project_gemm_256_kernel(PgParam
   // fragment addresses: row * 128 + ((2 ks + kb) ^ key(row)) * 16; rows of a wave's tiles differ by multiples of 32,
   // so the key is the lane's own and the k-step only flips bits 5..6 of the chunk
   const int fkey = (fr >> 1) & 7;
-  const unsigned xrd = (unsigned)((wm * 128 + fr) * 128), wrd = (unsigned)((wn * 64 + fr) * 128);
+  const unsigned xrd = (unsigned)((wm * 128 + fr) * 128), wrd = (unsigned)((wn * 32 * NI + fr) * 128);
   stage(0, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
-    const char* xs = smem_l + (kt & 1) * 2 * TILE;
+    const char* xs = smem_l + (kt & 1) * BUF;
     const char* ws = xs + TILE;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const unsigned co = (unsigned)(((2 * ks + kb) ^ fkey) * 16);
-      h16x8 fx[4], fw[2];
+      h16x8 fx[4], fw[NI];
 #pragma unroll
       for (int t = 0; t < 4; ++t) fx[t] = *reinterpret_cast<const h16x8*>(xs + xrd + t * 4096 + co);
 #pragma unroll
-      for (int t = 0; t < 2; ++t) fw[t] = *reinterpret_cast<const h16x8*>(ws + wrd + t * 4096 + co);
+      for (int t = 0; t < NI; ++t) fw[t] = *reinterpret_cast<const h16x8*>(ws + wrd + t * 4096 + co);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i], fx[jj], acc[i][jj], 0, 0, 0);
     }
@@ -210,10 +214,10 @@ __global__ __launch_bounds__(PL_THREADS, 1) void project_gemm_256_kernel(PgParam
   // C^T tiles: lane column (lane & 31) = token, rows = latent columns (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): a lane
   // holds 4 consecutive latent columns of one token (N % R == 0 and R % 4 == 0: never across a group boundary)
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int n = n0 + wn * 64 + i * 32 + 8 * q + 4 * kb;
+      const int n = n0 + wn * 32 * NI + i * 32 + 8 * q + 4 * kb;
       if (n >= p.N) continue;
       const int g = n / p.R;
       h16* col = p.out + (int64_t)g * p.so_g + (n - g * p.R) + (int64_t)p.row0 * p.so_l;
@@ -246,12 +250,18 @@ extern "C" int palu_lowrank_project_gemm(const void* x, int64_t ldx, const void*
   // large shapes: the 256x256 LDS-DMA kernel (tile offsets are 32-bit there: 256 rows of either operand < 2 GiB)
   const bool large = M >= 512 && N >= 256 && K >= 512 && 256 * ldx * 2 < (int64_t(1) << 31) && 256 * ldw * 2 < (int64_t(1) << 31);
   if (large) {
-    const int ntm = (M + PL_BM - 1) / PL_BM, ntn = (N + PL_BN - 1) / PL_BN;
-    const int smem = 2 * 2 * PL_BM * PG_BK * 2;
-    PALU_REQUIRE(palu_func_max_lds((const void*)project_gemm_256_kernel, smem) == 0, PALU_ERR_LAUNCH,
-                 "project_gemm: cannot reserve %d bytes of LDS", smem);
-    hipLaunchKernelGGL(project_gemm_256_kernel, dim3(((ntm + 7) / 8) * 8 * ntn), dim3(PL_THREADS), smem, (hipStream_t)stream,
-                       p, ntn, ntm);
+    // 256 x 256 tiles unless they leave CUs without a workgroup (8192 x 1024: 128 tiles), then 256 x 128
+    // (measured: 8192 x 1024 857 vs 686 TFLOP/s; 8192 x 3072 -- 384 wide tiles -- 807 wide vs 732 narrow)
+    const int ntm = (M + PL_BM - 1) / PL_BM;
+    const int cus = palu_num_cus();
+    const bool wide = (int64_t)ntm * ((N + 255) / 256) >= cus;
+    const int bn = wide ? 256 : 128, ntn = (N + bn - 1) / bn;
+    const int smem = 2 * (PL_BM + bn) * PG_BK * 2;
+    const void* fn = wide ? (const void*)project_gemm_256_kernel<2> : (const void*)project_gemm_256_kernel<1>;
+    PALU_REQUIRE(palu_func_max_lds(fn, smem) == 0, PALU_ERR_LAUNCH, "project_gemm: cannot reserve %d bytes of LDS", smem);
+    const dim3 grid(((ntm + 7) / 8) * 8 * ntn), block(PL_THREADS);
+    if (wide) hipLaunchKernelGGL(project_gemm_256_kernel<2>, grid, block, smem, (hipStream_t)stream, p, ntn, ntm);
+    else hipLaunchKernelGGL(project_gemm_256_kernel<1>, grid, block, smem, (hipStream_t)stream, p, ntn, ntm);
   } else {
     dim3 grid((M + PG_BM - 1) / PG_BM, (N + PG_BN - 1) / PG_BN);
     hipLaunchKernelGGL(project_gemm_kernel, grid, dim3(PG_THREADS), 0, (hipStream_t)stream, p);

@@ -286,3 +286,38 @@ def test_abx_random_shapes_and_strides():
             exact = oracle.abx_scores_f64(a, b, xz)[:, :, off:]
             scale = exact.abs().max().item()
             assert (got.cpu().double() - ref.double()).abs().max().item() / scale <= 1e-3, (it, gs, G, R, L, off)
+
+
+_COLD_START = r"""
+import numpy as np, torch, sys
+from palu_amd.kernel.abx_rope import abx
+H, gs, R, L = 32, 4, 128, int(sys.argv[1])
+G = H // gs
+rng = np.random.default_rng(H + R + L)
+a = torch.from_numpy(rng.standard_normal((H, 1, 128)).astype(np.float16)).cuda()
+bg = torch.from_numpy((rng.standard_normal((G, 1, R, 128)) / np.sqrt(R)).astype(np.float16))
+b = bg.expand(G, gs, R, 128).reshape(H, R, 128).contiguous().cuda()
+x = torch.from_numpy(rng.standard_normal((G, L, R)).astype(np.float16)).cuda()
+first = abx(a, b, x); torch.cuda.synchronize()
+second = abx(a, b, x); torch.cuda.synchronize()
+sys.exit(0 if torch.equal(first, second) else 3)
+"""
+
+
+def test_abx_shared_b_cold_start():
+    """The first launch of the shared-B kernel in a fresh process must equal every later one.  Regression test of
+    profiles/r03_shared_b_cold_start.txt: with the dynamic wave priorities the kernel used to run with, 20-30 % of cold
+    first launches had 16 wrong rows in one workgroup (98 of 98 fresh processes are right without them)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("PALU_ABX_PRIO_MODE", None)
+    bad = []
+    for i in range(6):
+        L = 65537 if i % 2 == 0 else 65536
+        r = subprocess.run([sys.executable, "-c", _COLD_START, str(L)], env=env, cwd=root, timeout=300)
+        assert r.returncode in (0, 3), r.returncode
+        if r.returncode == 3:
+            bad.append((i, L))
+    assert not bad, bad

@@ -350,7 +350,9 @@ def test_softmax_pv_full_size_c2_properties():
                                      # the 256x256 LDS-DMA kernel (M >= 512, N >= 256, K >= 512): ragged token tiles, a half-used
                                      # column tile, more token tiles than one round of the 8 XCDs, a single k-tile pair
                                      (600, 384, 512, 96), (777, 1280, 1024, 160), (2304 + 17, 512, 4096, 128), (512, 256, 512, 256),
-                                     (8192, 1024, 4096, 256)])
+                                     (8192, 1024, 4096, 256),
+                                     # enough tiles for the 256-column form (>= 1 per CU), ragged in both directions
+                                     (8192 + 5, 2048 + 128, 512, 128)])
 def test_lowrank_project_gemm(M, N, K, R):
     """Prefill down-projection (MFMA GEMM) vs fp64, written into the [G, L, R] cache layout at a row offset."""
     lib = _lib()
