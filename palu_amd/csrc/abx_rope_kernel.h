@@ -1099,7 +1099,7 @@ inline bool abx_plan(int H, int G, int R, AbxPlan* pl) {
 // the packed score kernels, nothing at C2).  The shared-B kernel runs WITHOUT priorities: with mode 2 its first launch in
 // a fresh process returned, in 20-30 % of the processes, one wave's partial scores of the last 16 rows of a workgroup's
 // last tile wrong (lanes 16-31 / 48-63 of the drain's q-dot); 0 of 98 cold processes with modes 0 / 1, and the per-head
-// and packed kernels are deterministic under mode 2 (12 of 12 each).  Not understood -- the MFMA -> v_permlane32_swap
+// and packed kernels are deterministic under mode 2 (72 of 72 and 48 of 48 fresh processes).  Not understood -- the MFMA -> v_permlane32_swap
 // distance in the drain is 12 wait states, and tools/ubench_mfma_hazard.hip shows 6 are enough with and without a
 // second wave on the matrix pipe -- so the toggling is simply not used there (profiles/r03_shared_b_cold_start.txt).
 inline int abx_prio_mode(bool shared = false) {
