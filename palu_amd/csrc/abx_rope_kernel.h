@@ -948,6 +948,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) sd[e] = 0.f;
       sd = __builtin_amdgcn_mfma_f32_32x32x16_f16(qa, krb, sd, 0, 0, 0);
+      // drain only (once per workgroup): slack between the last q-dot and its v_permlane32_swap.  Belt and braces for the
+      // cold-start flake of profiles/r03_shared_b_cold_start.txt (60 of 60 fresh processes right with it even under the
+      // priority mode that provoked it); the steady state keeps hipcc's own padding.
+      if (KIND == 3) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" : "+v"(sd));
 #pragma unroll
       for (int mb = 0; mb < NMB; ++mb) {
         auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sd[2 * mb]), __float_as_uint(sd[2 * mb + 1]), false, false);
