@@ -1011,7 +1011,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope_kernel(AbxParams p) {
       __syncthreads();
     }
     stamp();  // 6+2*tt: leave barrier
-    if (p.prio_mode == 2 && young) __builtin_amdgcn_s_setprio(1);  // young half leads the first half tile
+    // young half leads the first half tile -- but never on a workgroup's LAST tile: raising the priority there is what
+    // provoked the shared-B kernel's cold-start flake (20 of 30 fresh processes right with it, 30 of 30 without the raise
+    // on the last tile, 30 of 30 with s_nop in place of both s_setprio; profiles/r03_shared_b_cold_start.txt)
+    if (p.prio_mode == 2 && young && tt + 1 < ntile) __builtin_amdgcn_s_setprio(1);
     // one straight-line region per block: MFMAs of block b+1, RoPE epilogue of block b, staging of tile
     // tt+2 into the ring, cross-wave reduction + store of tile tt-2
     if (TIMING && (p.exp_flags & 1) && young) continue;   // experiment: one computing wave per SIMD
