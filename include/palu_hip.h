@@ -74,6 +74,25 @@ int palu_abx_rope_f16(const void* a, int64_t sa_h, int64_t sa_d,
  * scratch of palu_abx_scratch_bytes(H, G, L, R) bytes (16-byte aligned; 0 for R <= 128): partial scores are accumulated
  * in fp32 and rounded once.  Without scratch (palu_abx_rope_f16, or scratch = 0) such ranks take the slower chunked kernel.
  * Ranks below 128 other than 32 / 64 (e.g. 96) always run the 128-column kernel with the missing columns masked. */
+/* Low-band RoPE coefficient table of the two-band score kernel (csrc/abx_rope2_kernel.h).  With 4 heads per latent group
+ * and R in {32, 64, 128} the abx entry points (fp16 and packed latents, and the decode steps built on them) run a kernel
+ * that treats the 32 low-frequency RoPE pairs of a 128-position tile as a degree-7 polynomial in the in-tile position:
+ * a quarter of the reconstruction GEMM and of the per-position rotation work disappears.  It needs, per 128-position
+ * tile, the fp16 coefficients (psi_i/psi_max)^k cos/sin(phi_i + k pi/2) of the tile's centre angle -- a function of the
+ * positions and frequencies only (like the cos/sin cache of kernel/pytorch_reference.py:3-9), built once:
+ *   table = palu_rope_table_bytes(npos) bytes, 16-byte aligned, filled by palu_rope_table_build for the positions
+ *   [pos_first, pos_first + npos), pos_first % 128 == 0;
+ *   palu_rope_table_register ties it to the DEVICE POINTER the caller passes as `inv_freq` (the registry key; the table
+ *   must stay alive while registered; inv_freq_32 = the host value of inv_freq[32], which bounds the band's angles).
+ * A launch takes the two-band kernel when a registered table covers its positions, pos0 % 128 == 0, pos0 + L <= 2^18 and
+ * inv_freq[32] * (pos0 + L) < 2048 rad (the band uses the exact angle l*f; the oracle's fp32 rounding of l*f is <= 2^-14 rad
+ * there); otherwise, or with PALU_ABX_TWO_BAND=0 in the environment, it runs the one-band kernel -- same results within
+ * the oracle's own fp16 rounding.  palu_abx_two_band_selected reports the decision for a launch. */
+size_t palu_rope_table_bytes(int npos);
+int palu_rope_table_build(const float* inv_freq, int pos_first, int npos, void* table, palu_stream_t stream);
+int palu_rope_table_register(const float* inv_freq, const void* table, int pos_first, int npos, float inv_freq_32);
+int palu_rope_table_unregister(const float* inv_freq);
+int palu_abx_two_band_selected(const float* inv_freq, int H, int G, int L, int R, int pos0);
 size_t palu_abx_scratch_bytes(int H, int G, int L, int R);
 int palu_abx_rope_ws_f16(const void* a, int64_t sa_h, int64_t sa_d, const void* bfrag,
                          const void* x, int64_t sx_g, int64_t sx_l, void* out, int64_t so_h,

@@ -7,4 +7,4 @@ Only the hot path named in BASELINE.json lives here:
                      (kernel/abx_rope.py::abx, kernel/palu_attention.py::LlamaPaluAttention)
 There is no CPU fallback: every op raises if the HIP library cannot be loaded.
 """
-__version__ = "0.1.0"
+__version__ = "0.4.0"

@@ -4,6 +4,8 @@
 
 namespace {
 
+inline size_t abx_frag1_bytes(int G, const AbxPlan& pl) { return (size_t)G * pl.hb * 8 * pl.nmb * pl.nks_tot * 64 * sizeof(u32x4); }
+
 template <int NKS, int NMB, bool FOLD>
 int launch_abx_fast(const AbxParams& p, int nwg, hipStream_t stream) {
   // positions beyond 2^18: the second-order angle correction (abx_rope_kernel.h, ORDER2)
@@ -54,7 +56,8 @@ extern "C" int palu_abx_set_fold(int enable) {
 extern "C" size_t palu_abx_bfrag_bytes(int H, int G, int R) {
   AbxPlan pl;
   if (!abx_plan(H, G, R, &pl)) return 0;
-  return (size_t)G * pl.hb * 8 * pl.nmb * pl.nks_tot * 64 * sizeof(u32x4);
+  // [fragments of abx_rope_kernel | fragments of the two-band kernel (gs = 4, R in {32, 64, 128}; abx_rope2_kernel.h)]
+  return abx_frag1_bytes(G, pl) + palu_abx2_frag_bytes(H, G, R);
 }
 
 extern "C" int palu_abx_prepare_b(const void* b, int64_t sb_h, int64_t sb_r, int64_t sb_d, int H, int G, int R,
@@ -69,7 +72,7 @@ extern "C" int palu_abx_prepare_b(const void* b, int64_t sb_h, int64_t sb_r, int
   hipLaunchKernelGGL(abx_prepare_b_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
                      (const h16*)b, sb_h, sb_r, sb_d, H, G, R, pl.nmb, pl.hb, pl.nks_tot, (u32x4*)bfrag, total);
   PALU_LAUNCH_CHECK();
-  return PALU_OK;
+  return palu_abx2_prepare_b(b, sb_h, sb_r, sb_d, H, G, R, (char*)bfrag + abx_frag1_bytes(G, pl), (hipStream_t)stream);
 }
 
 extern "C" size_t palu_abx_scratch_bytes(int H, int G, int L, int R) {
@@ -150,6 +153,12 @@ extern "C" int palu_abx_rope_ws_f16(const void* a, int64_t sa_h, int64_t sa_d, c
     return PALU_OK;
   }
   if (pl.chunked) return pl.nmb == 2 ? launch_abx_generic<2>(p, nwg, s) : launch_abx_generic<1>(p, nwg, s);
+  if (fold && palu_abx2_frag_bytes(H, G, R)) {
+    // gs = 4 at a fast rank: the two-band kernel when a coefficient table covers the positions (abx_rope2.hip)
+    p.bfrag2 = (const u32x4*)((const char*)bfrag + abx_frag1_bytes(G, pl));
+    const int rc = palu_abx2_try_launch(&p, nwg, 0, s);
+    if (rc != PALU_ABX2_SKIP) return rc;
+  }
 #define PALU_ABX_DISPATCH(NKS)                                                                       \
   (fold ? (pl.nmb == 2 ? launch_abx_fast<NKS, 2, true>(p, nwg, s) : launch_abx_fast<NKS, 1, true>(p, nwg, s)) \
         : (pl.nmb == 2 ? launch_abx_fast<NKS, 2, false>(p, nwg, s) : launch_abx_fast<NKS, 1, false>(p, nwg, s)))

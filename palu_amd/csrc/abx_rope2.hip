@@ -1,0 +1,135 @@
+// Host side of the two-band score kernel (abx_rope2_kernel.h): fragment preparation, the low-band RoPE coefficient
+// table and its registry, and the launch decision.  The kernel computes what abx_rope_kernel computes (the reference's
+// `_abx_fwd`, kernel/abx_rope.py:79-111); the entry points of abx_rope.hip / abx_rope_q.hip select it when they can.
+#include <mutex>
+#include <vector>
+
+#include "abx_rope2_kernel.h"
+
+namespace {
+
+struct RopeTable {
+  const float* inv_freq;   // device pointer the callers pass as `inv_freq`: the registry key
+  const u32x4* tab;
+  int tile_first, ntiles;  // 128-position tiles covered: [tile_first, tile_first + ntiles)
+  float f_low;             // inv_freq[32] as the host computed it: bounds the low band's angles
+};
+std::mutex g_tab_mutex;
+std::vector<RopeTable> g_tabs;
+
+int two_band_enabled() {     // PALU_ABX_TWO_BAND=0 keeps every launch on abx_rope_kernel (A/B measurements)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("PALU_ABX_TWO_BAND");
+    v = e ? (atoi(e) != 0) : 1;
+  }
+  return v;
+}
+
+template <int NKS, int QBITS>
+int launch2(const AbxParams& p, int nwg, hipStream_t stream) {
+  return launch_kernel(abx_rope2_kernel<NKS, QBITS>, abx2_smem(NKS), p, nwg, stream);
+}
+
+}  // namespace
+
+size_t palu_abx2_frag_bytes(int H, int G, int R) {
+  if (G <= 0 || H != 4 * G || !(R == 32 || R == 64 || R == 128)) return 0;
+  return abx2_frag_u32x4(G, R / 16) * sizeof(u32x4);
+}
+
+// fragments of the two-band kernel, written behind the abx_rope_kernel fragments by palu_abx_prepare_b
+int palu_abx2_prepare_b(const void* b, int64_t sb_h, int64_t sb_r, int64_t sb_d, int H, int G, int R, void* frag2,
+                        hipStream_t stream) {
+  if (!palu_abx2_frag_bytes(H, G, R)) return PALU_OK;
+  const int nks = R / 16;
+  const int64_t n_hi = (int64_t)G * 8 * nks * 64;
+  const int64_t total = (int64_t)abx2_frag_u32x4(G, nks);
+  hipLaunchKernelGGL(abx2_prepare_b_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const h16*)b, sb_h,
+                     sb_r, sb_d, G, R, nks, (u32x4*)frag2, n_hi, total);
+  PALU_LAUNCH_CHECK();
+  return PALU_OK;
+}
+
+extern "C" size_t palu_rope_table_bytes(int npos) {
+  if (npos <= 0) return 0;
+  return (size_t)((npos + TL - 1) / TL) * 2 * 64 * sizeof(u32x4);
+}
+
+extern "C" int palu_rope_table_build(const float* inv_freq, int pos_first, int npos, void* table, palu_stream_t stream) {
+  PALU_REQUIRE(inv_freq && table, PALU_ERR_ARG, "rope_table_build: null pointer");
+  PALU_REQUIRE(pos_first >= 0 && pos_first % TL == 0 && npos > 0, PALU_ERR_ARG,
+               "rope_table_build: pos_first must be a multiple of %d and npos > 0 (got %d, %d)", TL, pos_first, npos);
+  PALU_REQUIRE(((uintptr_t)table & 15) == 0, PALU_ERR_ARG, "rope_table_build: table must be 16-byte aligned");
+  const int ntiles = (npos + TL - 1) / TL;
+  const int64_t total = (int64_t)ntiles * 128;
+  hipLaunchKernelGGL(abx2_rope_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, inv_freq,
+                     pos_first / TL, ntiles, (u32x4*)table);
+  PALU_LAUNCH_CHECK();
+  return PALU_OK;
+}
+
+extern "C" int palu_rope_table_register(const float* inv_freq, const void* table, int pos_first, int npos, float inv_freq_32) {
+  PALU_REQUIRE(inv_freq && table && pos_first >= 0 && pos_first % TL == 0 && npos > 0, PALU_ERR_ARG,
+               "rope_table_register: bad arguments");
+  PALU_REQUIRE(inv_freq_32 > 0.f, PALU_ERR_ARG, "rope_table_register: inv_freq[32] must be positive");
+  std::lock_guard<std::mutex> lk(g_tab_mutex);
+  for (auto& t : g_tabs)
+    if (t.inv_freq == inv_freq) {
+      t = RopeTable{inv_freq, (const u32x4*)table, pos_first / TL, (npos + TL - 1) / TL, inv_freq_32};
+      return PALU_OK;
+    }
+  g_tabs.push_back(RopeTable{inv_freq, (const u32x4*)table, pos_first / TL, (npos + TL - 1) / TL, inv_freq_32});
+  return PALU_OK;
+}
+
+extern "C" int palu_rope_table_unregister(const float* inv_freq) {
+  std::lock_guard<std::mutex> lk(g_tab_mutex);
+  for (size_t i = 0; i < g_tabs.size(); ++i)
+    if (g_tabs[i].inv_freq == inv_freq) {
+      g_tabs.erase(g_tabs.begin() + (long)i);
+      return PALU_OK;
+    }
+  return PALU_OK;
+}
+
+// 1 when a launch with these positions would take the two-band kernel (introspection for tests and the bench)
+extern "C" int palu_abx_two_band_selected(const float* inv_freq, int H, int G, int L, int R, int pos0) {
+  if (!two_band_enabled() || !palu_abx2_frag_bytes(H, G, R) || L <= 0 || pos0 < 0 || pos0 % TL) return 0;
+  if ((int64_t)pos0 + L > 262144) return 0;
+  std::lock_guard<std::mutex> lk(g_tab_mutex);
+  for (const auto& t : g_tabs)
+    if (t.inv_freq == inv_freq) {
+      const int first = pos0 / TL, last = (pos0 + L + TL - 1) / TL;
+      return first >= t.tile_first && last <= t.tile_first + t.ntiles && t.f_low * (float)(pos0 + L) < 2048.0f;
+    }
+  return 0;
+}
+
+int palu_abx2_try_launch(const void* params, int nwg, int bits, hipStream_t stream) {
+  AbxParams p = *reinterpret_cast<const AbxParams*>(params);
+  if (!p.bfrag2 || p.ncols != 0 || p.acc || p.ks0 != 0 || p.qgroup != 0 || p.HB != 1 || p.gs != 4) return PALU_ABX2_SKIP;
+  if (!palu_abx_two_band_selected(p.inv_freq, p.H, p.G, p.L, p.R, p.pos0)) return PALU_ABX2_SKIP;
+  {
+    std::lock_guard<std::mutex> lk(g_tab_mutex);
+    const RopeTable* t = nullptr;
+    for (const auto& e : g_tabs)
+      if (e.inv_freq == p.inv_freq) t = &e;
+    if (!t) return PALU_ABX2_SKIP;
+    p.rope_tab = t->tab;
+    p.tab_tile0 = p.pos0 / TL - t->tile_first;
+  }
+  if (bits == 0) {
+    switch (p.R) {
+      case 32: return launch2<2, 0>(p, nwg, stream);
+      case 64: return launch2<4, 0>(p, nwg, stream);
+      default: return launch2<8, 0>(p, nwg, stream);
+    }
+  }
+  if (bits == 3) return p.R == 128 ? launch2<8, 3>(p, nwg, stream) : PALU_ABX2_SKIP;
+  switch (p.R) {
+    case 32: return launch2<2, 4>(p, nwg, stream);
+    case 64: return launch2<4, 4>(p, nwg, stream);
+    default: return launch2<8, 4>(p, nwg, stream);
+  }
+}

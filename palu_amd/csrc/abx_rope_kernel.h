@@ -31,6 +31,14 @@
 
 #include "palu_common.h"
 
+// two-band score kernel (abx_rope2.hip): launches it when the shape, the positions and a registered coefficient table
+// allow (gs = 4, R in {32, 64, 128}, pos0 % 128 == 0, pos0 + L <= 2^18, low-band angles below 2048 rad); returns
+// PALU_ABX2_SKIP when the caller should run abx_rope_kernel instead.  `params` is an AbxParams with bfrag2 set.
+#define PALU_ABX2_SKIP 1
+int palu_abx2_try_launch(const void* params, int nwg, int bits, hipStream_t stream);
+size_t palu_abx2_frag_bytes(int H, int G, int R);   // 0 when the shape is not covered
+int palu_abx2_prepare_b(const void* b, int64_t sb_h, int64_t sb_r, int64_t sb_d, int H, int G, int R, void* frag2, hipStream_t stream);
+
 namespace {
 
 constexpr int TL = 128;        // rows (cache positions) per tile
@@ -66,6 +74,11 @@ struct AbxParams {
   int ks0;                  // first fragment k-step of this pass (0)
   float* acc;               // fp32 scores [H][acc_ld] of the ACC = 1 / 2 instantiations (store / atomic add of the partials)
   int64_t acc_ld;
+  // two-band kernel (abx_rope2_kernel.h): its fragment layout (behind the fragments above in the same allocation), the
+  // low-band coefficient table (palu_rope_table_build) and the table tile of position pos0
+  const u32x4* bfrag2;
+  const u32x4* rope_tab;
+  int tab_tile0;
 };
 
 // heads per workgroup = 2*NMB; each MFMA M-block carries 2 heads x 8 pairs x {i, i+64}
@@ -1115,7 +1128,7 @@ inline int abx_prio_mode(bool shared = false) {
     const char* e = getenv("PALU_ABX_PRIO_MODE");
     m = e ? atoi(e) : -1;
   }
-  return m >= 0 ? m : (shared ? 0 : 2);
+  return m >= 0 ? m : 0;
 }
 
 // fills the launch-independent part of the parameters; returns the number of workgroups

@@ -144,6 +144,12 @@ static int abx_rope_q_impl(const void* a, int64_t sa_h, int64_t sa_d, const void
     if (bits == 3) return pl.nmb == 2 ? launch_abx_q_generic<2, 3>(p, nwg, s) : launch_abx_q_generic<1, 3>(p, nwg, s);
     return pl.nmb == 2 ? launch_abx_q_generic<2, 4>(p, nwg, s) : launch_abx_q_generic<1, 4>(p, nwg, s);
   }
+  if (palu_abx2_frag_bytes(H, G, R)) {
+    // gs = 4 at a fast rank: the two-band kernel when a coefficient table covers the positions (abx_rope2.hip)
+    p.bfrag2 = (const u32x4*)((const char*)bfrag + (size_t)G * pl.hb * 8 * pl.nmb * pl.nks_tot * 64 * sizeof(u32x4));
+    const int rc = palu_abx2_try_launch(&p, nwg, bits, s);
+    if (rc != PALU_ABX2_SKIP) return rc;
+  }
   if (bits == 3) return pl.nmb == 2 ? launch_abx_q<8, 2, 3>(p, nwg, s) : launch_abx_q<8, 1, 3>(p, nwg, s);
   switch (R) {
     case 32: return pl.nmb == 2 ? launch_abx_q<2, 2, 4>(p, nwg, s) : launch_abx_q<2, 1, 4>(p, nwg, s);

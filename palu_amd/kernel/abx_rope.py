@@ -26,10 +26,30 @@ def rope_inv_freq(device, head_dim: int = 128, theta: float = 10000.0) -> torch.
     key = (str(device), head_dim, float(theta))
     t = _inv_freq_cache.get(key)
     if t is None:
-        t = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
-        t = t.to(device)
+        host = 1.0 / (theta ** (torch.arange(0, head_dim, 2, dtype=torch.int64).float() / head_dim))
+        t = host.to(device)
         _inv_freq_cache[key] = t
+        if head_dim == 128 and torch.device(device).type == "cuda":
+            _register_rope_table(t, host)
     return t
+
+
+ROPE_TABLE_POSITIONS = 1 << 18      # what the two-band score kernel covers (csrc/abx_rope2.hip); 4 MB per (device, theta)
+_rope_tables = {}
+
+
+def _register_rope_table(inv: torch.Tensor, host: torch.Tensor) -> None:
+    """Low-band RoPE coefficients of the two-band score kernel for positions [0, 2^18): a function of the frequencies
+    only, built once per (device, theta) next to the inverse-frequency table and registered under its device pointer
+    (include/palu_hip.h: palu_rope_table_build / _register).  Launches that pass this `inv` then select that kernel
+    when their shape and positions allow."""
+    with _lib.on_device(inv):
+        tab = torch.empty(_lib.lib.palu_rope_table_bytes(ROPE_TABLE_POSITIONS), dtype=torch.uint8, device=inv.device)
+        _lib.check(_lib.lib.palu_rope_table_build(inv.data_ptr(), 0, ROPE_TABLE_POSITIONS, tab.data_ptr(),
+                                                  _lib.current_stream()), "palu_rope_table_build")
+        _lib.check(_lib.lib.palu_rope_table_register(inv.data_ptr(), tab.data_ptr(), 0, ROPE_TABLE_POSITIONS,
+                                                     float(host[32])), "palu_rope_table_register")
+    _rope_tables[inv.data_ptr()] = tab          # keeps the table alive as long as the cached frequencies
 
 
 def set_fold(enable: bool) -> bool:
