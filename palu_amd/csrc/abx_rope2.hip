@@ -106,8 +106,13 @@ extern "C" int palu_abx_two_band_selected(const float* inv_freq, int H, int G, i
   return 0;
 }
 
+static unsigned long long* g_abx2_dbg = nullptr;
+// debug: device buffer of >= 176 KB that workgroup 0 of the next two-band launches dumps its first W image into (0 = off)
+extern "C" void palu_abx2_debug_buffer(void* ptr) { g_abx2_dbg = (unsigned long long*)ptr; }
+
 int palu_abx2_try_launch(const void* params, int nwg, int bits, hipStream_t stream) {
   AbxParams p = *reinterpret_cast<const AbxParams*>(params);
+  p.dbg = g_abx2_dbg;
   if (!p.bfrag2 || p.ncols != 0 || p.acc || p.ks0 != 0 || p.qgroup != 0 || p.HB != 1 || p.gs != 4) return PALU_ABX2_SKIP;
   if (!palu_abx_two_band_selected(p.inv_freq, p.H, p.G, p.L, p.R, p.pos0)) return PALU_ABX2_SKIP;
   {

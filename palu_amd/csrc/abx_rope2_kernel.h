@@ -116,7 +116,7 @@ __global__ void abx2_rope_table_kernel(const float* __restrict__ inv_freq, int t
   out[idx] = *reinterpret_cast<u32x4*>(&v);
 }
 
-constexpr int ABX2_RED_STRIDE = 4 * 4 * TL;   // floats per partial-sum slot: [4 wave pairs][4 heads][TL]
+constexpr int ABX2_RED_STRIDE = 8 * 4 * TL;   // floats per partial-sum slot: [8 waves][4 heads][TL]
 constexpr int abx2_smem(int nks) { return 3 * TL * 32 * nks + 3 * ABX2_RED_STRIDE * (int)sizeof(float) + 2 * nks * 1024; }
 
 typedef __attribute__((address_space(3))) float lds_f32;
@@ -240,10 +240,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
     const h16 v = p.a[(int64_t)(g * 4 + hh) * p.sa_h + (int64_t)d * p.sa_d];
     *(__attribute__((address_space(3))) h16*)(uintptr_t)(qbuf + (unsigned)(((hh * 64 + (d & 63)) * 2 + (d >> 6)) * 2)) = v;
   }
-  // partial-sum slots start at zero (the waves of a SIMD pair ADD into them)
-#pragma unroll
-  for (int k = 0; k < 3 * ABX2_RED_STRIDE * 4 / 16 / NTHREADS; ++k)
-    *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(red_base + (unsigned)((tid + NTHREADS * k) * 16)) = u32x4{0u, 0u, 0u, 0u};
 
   if (QBITS == 0) {
     dma_tile(0, 0);
@@ -351,11 +347,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
         u32x4 res;
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
-          const h16x2 cp = __builtin_bit_cast(h16x2, qq[e4]);            // (q_i, q_{i+64})
+          // (element -> scalar -> bit_cast: hipcc 7.2 folds __builtin_bit_cast(h16x2, vec[e4]) to element 0 for every e4)
+          const unsigned qe = qq[e4], oe = own[e4];
+          const h16x2 cp = __builtin_bit_cast(h16x2, qe);                 // (q_i, q_{i+64})
           h16x2 cq;
           cq[0] = cp[1];
           cq[1] = -cp[0];                                                  // (q_{i+64}, -q_i)
-          const h16x2 bb = __builtin_bit_cast(h16x2, own[e4]);
+          const h16x2 bb = __builtin_bit_cast(h16x2, oe);
           float r0 = __builtin_amdgcn_fdot2(bb, cp, 0.f, false);
           float r1 = __builtin_amdgcn_fdot2(bb, cq, 0.f, false);
           h16x2 r2;
@@ -389,20 +387,27 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
     }
   };
   if (s1_wave) stage1(cf0, 0);
+  if (p.dbg && blockIdx.x == 0) {
+    // debug dump (tools/diag_two_band.py dump): W image of the first tile, this lane's folded low fragments and coefficients
+    __syncthreads();
+    u32x4* d = reinterpret_cast<u32x4*>(p.dbg);
+    d[tid] = *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(w_base + (unsigned)(tid * 16));   // 8 KB (NKS = 8)
+    for (int hh = 0; hh < 4; ++hh)
+      for (int cs = 0; cs < 2; ++cs) d[512 + (hh * 2 + cs) * 512 + tid] = __builtin_bit_cast(u32x4, lowf[hh][cs]);
+    for (int cs = 0; cs < 2; ++cs) d[512 + 8 * 512 + cs * 512 + tid] = __builtin_bit_cast(u32x4, cf0[cs]);
+  }
 
   // scores leave through a buffer store (invalid lanes get an out-of-range offset the hardware drops)
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
 
-  // cross-wave reduction of tile tt (partial sums in slot rslot: 4 wave pairs) and the fp16 store; the slot is handed back
-  // zeroed (exchange) for its next tile
+  // cross-wave reduction of tile tt (partial sums of the 8 waves in slot rslot) and the fp16 store
+  // (measured: LDS float atomics -- the two waves of a SIMD adding into one word -- cost 50 us per launch at C2)
   auto reduce_store = [&](int tt, int rslot) {
     const int hh = tid >> 7, pos = tid & 127;
     const unsigned r = red_base + (unsigned)((rslot * ABX2_RED_STRIDE + hh * TL + pos) * sizeof(float));
     float s = 0.f;
 #pragma unroll
-    for (int ww = 0; ww < 4; ++ww)
-      s += __hip_atomic_exchange((lds_f32*)(uintptr_t)(r + (unsigned)(ww * 4 * TL * sizeof(float))), 0.f, __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int ww = 0; ww < 8; ++ww) s += *(lds_f32*)(uintptr_t)(r + (unsigned)(ww * 4 * TL * sizeof(float)));
     const int l = (tile0 + tt) * TL + pos;
     const bool ok = tt >= 0 && l < p.L;
     const unsigned off = ok ? (unsigned)(((int64_t)(g * 4 + hh) * p.so_h + l) * 2) : 0xFFFFFFF0u;
@@ -420,8 +425,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
   auto read_frag = [&](int i, int blk) {
     return *(const __attribute__((address_space(3))) h16x8*)(uintptr_t)(fa[i] + (unsigned)(blk * 32 * Geo::RB));
   };
-  // partial sums: after the half swap lane (n, hi) holds head 2 mb + hi of position n; wave pair w & 3
-  const unsigned red_lane = red_base + (unsigned)((((w & 3) * 4 + hi) * TL + n) * sizeof(float));
+  // partial sums: after the half swap lane (n, hi) holds head 2 mb + hi of position n
+  const unsigned red_lane = red_base + (unsigned)(((w * 4 + hi) * TL + n) * sizeof(float));
   // stage-2 A operand of this lane: W image row m = n, k-slot half hi, the wave's first k-step koff
   const unsigned w_rd = w_base + (unsigned)(((koff * 2 + hi) * 32 + n) * 16);
 
@@ -527,10 +532,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
       auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(part[2 * mb]), __float_as_uint(part[2 * mb + 1]), false, false);
-      const float v = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
-      // the two waves of a pair add into a zeroed word: 0 + a + b is the same number in either order
-      __hip_atomic_fetch_add((lds_f32*)(uintptr_t)(rdst + (unsigned)(mb * 2 * TL * sizeof(float))), v, __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_WORKGROUP);
+      *(lds_f32*)(uintptr_t)(rdst + (unsigned)(mb * 2 * TL * sizeof(float))) = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
     if (KIND == 0 && QBITS != 0) {
       store_q(sslot);
@@ -561,9 +563,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
   auto main_loop = [&](auto s_c) {
     constexpr int S = decltype(s_c)::value;       // this wave's stage-2 block
     // S2M = (block == S), S2E = (block whose epilogue runs == S)
+#ifdef PALU_ABX2_EXP_NOS2
+#define ABX2_REGION(KIND, LASTT, BLK, ACN, ERSLOT, EBLK, ACP, STT, SSLOT, ND, WRD)                                          \
+  region(KIND{}, LASTT{}, std::false_type{}, std::false_type{}, ACN, BLK, ERSLOT, EBLK, ACP, STT, SSLOT, ND, WRD)
+#else
 #define ABX2_REGION(KIND, LASTT, BLK, ACN, ERSLOT, EBLK, ACP, STT, SSLOT, ND, WRD)                                          \
   region(KIND{}, LASTT{}, std::integral_constant<bool, (BLK) == S>{}, std::integral_constant<bool, (EBLK) == S>{}, ACN, BLK, \
          ERSLOT, EBLK, ACP, STT, SSLOT, ND, WRD)
+#endif
     const int nmain = tail_nb < 4 ? ntile - 1 : ntile;
     for (int tt = 0; tt < nmain; ++tt) {
       if (tt > 0) {
@@ -575,9 +582,13 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
       const unsigned wrd = w_rd + (unsigned)((tt & 1) * WB);
       ABX2_REGION(K0, NotLast, 0, accA, s_prv, 3, accB, min(tt + 2, ntile - 1), s_prv, 0u, wrd);
       ABX2_REGION(K1, NotLast, 1, accB, s_cur, 0, accA, tt - 2, s_nxt, 0u, wrd);
+#ifndef PALU_ABX2_EXP_NOS1
       if (early_s1 && s1_wave && tt + 1 < ntile) stage1(cfC, (tt + 1) & 1);
+#endif
       ABX2_REGION(K2, NotLast, 2, accA, s_cur, 1, accB, 0, 0, 0u, wrd);
+#ifndef PALU_ABX2_EXP_NOS1
       if (!early_s1 && s1_wave && tt + 1 < ntile) stage1(cfC, (tt + 1) & 1);
+#endif
       ABX2_REGION(K2, Last, 3, accB, s_cur, 2, accA, 0, 0, nd, wrd);
       cfC[0] = cfN[0];
       cfC[1] = cfN[1];
