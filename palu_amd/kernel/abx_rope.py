@@ -10,6 +10,7 @@ safe under torch.cuda.graph capture once the B fragments are cached (first call 
 """
 from __future__ import annotations
 
+import contextlib
 import weakref
 
 import torch
@@ -49,7 +50,22 @@ def _register_rope_table(inv: torch.Tensor, host: torch.Tensor) -> None:
                                                   _lib.current_stream()), "palu_rope_table_build")
         _lib.check(_lib.lib.palu_rope_table_register(inv.data_ptr(), tab.data_ptr(), 0, ROPE_TABLE_POSITIONS,
                                                      float(host[32])), "palu_rope_table_register")
-    _rope_tables[inv.data_ptr()] = tab          # keeps the table alive as long as the cached frequencies
+    _rope_tables[inv.data_ptr()] = (tab, float(host[32]))   # keeps the table alive as long as the cached frequencies
+
+
+@contextlib.contextmanager
+def one_band():
+    """Run the enclosed launches on the one-band score kernel (csrc/abx_rope_kernel.h) by taking the coefficient tables out
+    of the registry for the duration -- for A/B measurements and for tests that compare scores bit for bit with the fused
+    attention core, which carries the one-band pipeline.  Not thread-safe (process-wide registry)."""
+    for ptr in _rope_tables:
+        _lib.lib.palu_rope_table_unregister(ptr)
+    try:
+        yield
+    finally:
+        for ptr, (tab, f32_) in _rope_tables.items():
+            _lib.check(_lib.lib.palu_rope_table_register(ptr, tab.data_ptr(), 0, ROPE_TABLE_POSITIONS, f32_),
+                       "palu_rope_table_register")
 
 
 def set_fold(enable: bool) -> bool:

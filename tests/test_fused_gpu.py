@@ -83,7 +83,7 @@ def test_fused_attn_vs_oracle(H, G, Rk, Rv, L):
 
 def two_kernel_attn(q, b, k, v, L, pos0=0):
     """the two-kernel HIP path (abx -> softmax.PV) on the same device tensors -> (ctx [H,Rv], raw fp16 scores [H,L])"""
-    from palu_amd.kernel.abx_rope import prepare_b, rope_inv_freq
+    from palu_amd.kernel.abx_rope import one_band, prepare_b, rope_inv_freq
     lib = _lib()
     H, Rk, _ = b.shape
     G, Rv = k.shape[0], v.shape[2]
@@ -93,9 +93,11 @@ def two_kernel_attn(q, b, k, v, L, pos0=0):
     ws = torch.empty(lib.lib.palu_pv_workspace_bytes(H, G, L, Rv), dtype=torch.uint8, device=DEV)
     ctx2 = torch.empty(H, Rv, dtype=torch.float16, device=DEV)
     s = torch.cuda.current_stream().cuda_stream
-    lib.check(lib.lib.palu_abx_rope_f16(q.data_ptr(), q.stride(0), 1, frag.data_ptr(), k.data_ptr(), k.stride(0),
-                                        k.stride(1), scores.data_ptr(), scores.stride(0), H, G, L, Rk, D,
-                                        inv.data_ptr(), pos0, s), "abx")
+    # the fused core carries the ONE-band score pipeline: its scores are compared bit for bit with that kernel's
+    with one_band():
+        lib.check(lib.lib.palu_abx_rope_f16(q.data_ptr(), q.stride(0), 1, frag.data_ptr(), k.data_ptr(), k.stride(0),
+                                            k.stride(1), scores.data_ptr(), scores.stride(0), H, G, L, Rk, D,
+                                            inv.data_ptr(), pos0, s), "abx")
     lib.check(lib.lib.palu_softmax_pv_f16(scores.data_ptr(), scores.stride(0), 0, v.data_ptr(), v.stride(0),
                                           v.stride(1), ctx2.data_ptr(), 0, 0, ws.data_ptr(), H, G, L, Rv,
                                           math.sqrt(D), s), "pv")

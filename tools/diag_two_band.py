@@ -25,7 +25,7 @@ print("device:", props.name, "CUs", props.multi_processor_count, "shared/block",
 
 def set_two_band(on: bool):
     if on:
-        tab = _rope_tables[inv.data_ptr()]
+        tab = _rope_tables[inv.data_ptr()][0]
         _lib.check(_lib.lib.palu_rope_table_register(inv.data_ptr(), tab.data_ptr(), 0, ROPE_TABLE_POSITIONS, float(inv_host[32])), "reg")
     else:
         _lib.lib.palu_rope_table_unregister(inv.data_ptr())
