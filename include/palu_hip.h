@@ -86,7 +86,7 @@ int palu_abx_rope_f16(const void* a, int64_t sa_h, int64_t sa_d,
  *   must stay alive while registered; inv_freq_32 = the host value of inv_freq[32], which bounds the band's angles).
  * A launch takes the two-band kernel when a registered table covers its positions, pos0 % 128 == 0, pos0 + L <= 2^18 and
  * inv_freq[32] * (pos0 + L) < 2048 rad (the band uses the exact angle l*f; the oracle's fp32 rounding of l*f is <= 2^-14 rad
- * there); otherwise, or with PALU_ABX_TWO_BAND=0 in the environment, it runs the one-band kernel -- same results within
+ * there) and 64 * inv_freq[32] <= 0.7 rad (the polynomial's remainder: theta >= ~8400 at head_dim 128); otherwise, or with PALU_ABX_TWO_BAND=0 in the environment, it runs the one-band kernel -- same results within
  * the oracle's own fp16 rounding.  palu_abx_two_band_selected reports the decision for a launch. */
 size_t palu_rope_table_bytes(int npos);
 int palu_rope_table_build(const float* inv_freq, int pos_first, int npos, void* table, palu_stream_t stream);

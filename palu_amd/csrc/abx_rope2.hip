@@ -101,7 +101,10 @@ extern "C" int palu_abx_two_band_selected(const float* inv_freq, int H, int G, i
   for (const auto& t : g_tabs)
     if (t.inv_freq == inv_freq) {
       const int first = pos0 / TL, last = (pos0 + L + TL - 1) / TL;
-      return first >= t.tile_first && last <= t.tile_first + t.ntiles && t.f_low * (float)(pos0 + L) < 2048.0f;
+      // psi_max = 64 f_32 <= 0.7 rad keeps the degree-7 Taylor remainder below 0.7^8 / 8! = 1.4e-6 (theta >= ~8400 at D = 128);
+      // f_32 (pos0 + L) < 2048 rad keeps the oracle's fp32 rounding of the band's angles below 2^-14 rad
+      return first >= t.tile_first && last <= t.tile_first + t.ntiles && 64.0f * t.f_low <= 0.7f &&
+             t.f_low * (float)(pos0 + L) < 2048.0f;
     }
   return 0;
 }

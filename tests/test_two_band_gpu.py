@@ -1,0 +1,191 @@
+"""GPU parity of the two-band score kernel (csrc/abx_rope2_kernel.h) -- the kernel `abx` runs for 4 heads per latent group
+at R in {32, 64, 128} -- against the CPU oracle (`torch_abx`, kernel/abx_rope.py:152-171), against the one-band kernel on
+the same inputs, band by band, and the rules that select it.  Criteria: SURVEY.md 8(c) P2."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import oracle
+
+D = 128
+
+
+def _mods():
+    from palu_amd import _lib
+    from palu_amd.kernel import abx_rope
+    return _lib, abx_rope
+
+
+def _inputs(H, G, R, L, seed, band="all", scale_b=None):
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((H, 1, D)).astype(np.float16)
+    if band == "high":                     # only the components of RoPE pairs 0..31 (d in 0..31 and 64..95)
+        a[:, :, 32:64] = 0
+        a[:, :, 96:128] = 0
+    elif band == "low":                    # only pairs 32..63
+        a[:, :, 0:32] = 0
+        a[:, :, 64:96] = 0
+    b = (rng.standard_normal((H, R, D)) * (R ** -0.5 if scale_b is None else scale_b)).astype(np.float16)
+    x = rng.standard_normal((G, L, R)).astype(np.float16)
+    return torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(x)
+
+
+def _p2(got, a, b, x, theta=10000.0):
+    exact = oracle.abx_scores_f64(a, b, x, theta)
+    ref16 = oracle.abx_scores(a, b, x, theta)
+    scale = exact.abs().max().item()
+    got = got.detach().cpu().double()
+    err_vs_oracle = (got - ref16.double()).abs().max().item() / scale
+    err_mine = (got - exact).abs().max().item() / scale
+    err_oracle = (ref16.double() - exact).abs().max().item() / scale
+    assert err_vs_oracle <= 1e-3, (err_vs_oracle, err_mine, err_oracle)
+    assert err_mine <= max(1.5 * err_oracle, 2.0 ** -10), (err_mine, err_oracle)
+    rms_mine = ((got - exact) ** 2).mean().sqrt().item()
+    rms_oracle = ((ref16.double() - exact) ** 2).mean().sqrt().item()
+    assert rms_mine <= 1.25 * rms_oracle, (rms_mine, rms_oracle)       # the kernel's error stays at the oracle's own level
+    return err_mine, err_oracle
+
+
+def test_selection_rules():
+    _lib, ar = _mods()
+    dev = torch.device("cuda:0")
+    inv = ar.rope_inv_freq(dev)
+    sel = lambda H, G, L, R, pos0: _lib.lib.palu_abx_two_band_selected(inv.data_ptr(), H, G, L, R, pos0)
+    assert sel(32, 8, 65537, 128, 0) == 1 and sel(32, 8, 131073, 64, 0) == 1 and sel(4, 1, 100, 32, 256) == 1
+    assert sel(32, 8, 1000, 128, 64) == 0              # tiles must start at multiples of 128
+    assert sel(16, 8, 1000, 128, 0) == 0               # 2 heads per group
+    assert sel(32, 8, 1000, 96, 0) == 0                # rank outside {32, 64, 128}
+    assert sel(32, 8, 262145, 128, 0) == 0             # positions beyond the table / 2^18
+    assert sel(32, 8, 204800, 128, 0) == 0             # inv_freq[32] * L >= 2048 rad (0.01 * 204800)
+    assert sel(32, 8, 204000, 128, 0) == 1
+    with ar.one_band():
+        assert sel(32, 8, 65537, 128, 0) == 0
+    assert sel(32, 8, 65537, 128, 0) == 1
+    inv_small_theta = ar.rope_inv_freq(dev, 128, 1000.0)            # psi_max = 64 * 1000^-0.5 = 2.0 rad: polynomial too short
+    assert _lib.lib.palu_abx_two_band_selected(inv_small_theta.data_ptr(), 32, 8, 1000, 128, 0) == 0
+    inv_llama3 = ar.rope_inv_freq(dev, 128, 500000.0)
+    assert _lib.lib.palu_abx_two_band_selected(inv_llama3.data_ptr(), 32, 8, 65537, 128, 0) == 1
+
+
+@pytest.mark.parametrize("band", ["high", "low", "all"])
+@pytest.mark.parametrize("R,L", [(128, 1000), (64, 517), (32, 300)])
+def test_bands_in_isolation_vs_oracle(band, R, L):
+    """A query with only high-band (or only low-band) components exercises one half of the kernel alone."""
+    _lib, ar = _mods()
+    a, b, x = _inputs(32, 8, R, L, seed=R + L, band=band)
+    got = ar.abx(a.cuda(), b.cuda(), x.cuda())
+    _p2(got, a, b, x)
+
+
+@pytest.mark.parametrize("H,G,R,L", [(32, 8, 128, 1), (32, 8, 128, 33), (32, 8, 128, 128), (32, 8, 128, 129), (32, 8, 128, 255),
+                                     (32, 8, 128, 4096 + 97), (4, 1, 128, 8191), (32, 8, 64, 2113), (32, 8, 32, 2048),
+                                     (8, 2, 64, 5000)])
+def test_two_band_and_one_band_agree(H, G, R, L):
+    _lib, ar = _mods()
+    a, b, x = _inputs(H, G, R, L, seed=7 * L + R)
+    ac, bc, xc = a.cuda(), b.cuda(), x.cuda()
+    inv = ar.rope_inv_freq(xc.device)
+    assert _lib.lib.palu_abx_two_band_selected(inv.data_ptr(), H, G, L, R, 0) == 1
+    two = ar.abx(ac, bc, xc)
+    with ar.one_band():
+        one = ar.abx(ac, bc, xc)
+    _p2(two, a, b, x)
+    _p2(one, a, b, x)
+    scale = float(one.float().abs().max())
+    assert float((two.float() - one.float()).abs().max()) <= 1e-3 * scale
+
+
+def test_randn_scale_inputs_full_size_c2():
+    """randn-scale weights (abx_rope.py:200-202) at the full config-2 size: both kernels against an fp64 evaluation on the
+    GPU (oracle.abx_scores_f64 restated with torch.cuda fp64), error no worse than 1.25x the one-band kernel's."""
+    _lib, ar = _mods()
+    H, G, R, L = 32, 8, 128, 65537
+    g = torch.Generator().manual_seed(5)
+    a = torch.randn(H, 1, D, generator=g).half().cuda()
+    b = torch.randn(H, R, D, generator=g).half().cuda()
+    x = torch.randn(G, L, R, generator=g).half().cuda()
+    inv = ar.rope_inv_freq(x.device)
+    two = ar.abx(a, b, x).reshape(H, L).double()
+    with ar.one_band():
+        one = ar.abx(a, b, x).reshape(H, L).double()
+    e2 = e1 = 0.0
+    mx = 0.0
+    worst = 0.0
+    for l0 in range(0, L, 8192):
+        l1 = min(L, l0 + 8192)
+        keys = torch.matmul(x[:, None, l0:l1].double(), b.double().reshape(G, 4, R, D))
+        ang = torch.outer(torch.arange(l0, l1, device=x.device, dtype=torch.int64).to(torch.float32), inv).double()
+        c, s = ang.cos(), ang.sin()
+        k1, k2 = keys[..., :64], keys[..., 64:]
+        rot = torch.cat((k1 * c - k2 * s, k2 * c + k1 * s), dim=-1)
+        ref = torch.einsum("ghd,ghld->ghl", a.double().reshape(G, 4, D), rot).reshape(H, l1 - l0)
+        e2 += float(((two[:, l0:l1] - ref) ** 2).sum())
+        e1 += float(((one[:, l0:l1] - ref) ** 2).sum())
+        mx = max(mx, float(ref.abs().max()))
+        worst = max(worst, float((two[:, l0:l1] - ref).abs().max()))
+    assert worst <= 1e-3 * mx, (worst, mx)
+    assert e2 <= 1.25 ** 2 * e1, (e2, e1)
+
+
+@pytest.mark.parametrize("bits,R,L", [(4, 128, 1000), (4, 64, 4097), (4, 32, 777), (3, 128, 4193)])
+def test_packed_latents_score_like_their_dequantised_rows(bits, R, L):
+    """3/4-bit latents through the two-band kernel: bit-identical scores to the fp16 two-band kernel on quantize_tensor(x)
+    (same LDS tile image, same MFMA stream), and P2 against the oracle on those rows."""
+    _lib, ar = _mods()
+    from palu_amd.kernel import quant as pq
+    H, G = 32, 8
+    a, b, x = _inputs(H, G, R, L, seed=bits * 1000 + L)
+    ac, bc, xc = a.cuda(), b.cuda(), x.cuda()
+    codes, meta = pq.quantize_pack(xc, bits)
+    xdq = pq.unpack_dequant(codes, meta, bits, R)
+    inv = ar.rope_inv_freq(xc.device)
+    frag = ar.prepare_b(bc, G)
+    out = torch.empty(H, 1, L, dtype=torch.float16, device=xc.device)
+    _lib.check(_lib.lib.palu_abx_rope_q(ac.data_ptr(), ac.stride(0), ac.stride(2), frag.data_ptr(), codes.data_ptr(),
+                                        codes.stride(0), codes.stride(1), meta.data_ptr(), meta.stride(0), meta.stride(1),
+                                        out.data_ptr(), out.stride(0), H, G, L, R, D, bits, inv.data_ptr(), 0,
+                                        torch.cuda.current_stream().cuda_stream), "abx_q")
+    ref = ar.abx(ac, bc, xdq)
+    assert torch.equal(out, ref)
+    _p2(out, a, b, xdq.cpu())
+
+
+def test_pos_offset_in_whole_tiles_and_other_theta():
+    """pos_offset a multiple of 128 indexes the coefficient table by absolute tile (split-L ranks, chunked callers); a
+    Llama-3 style theta = 5e5 builds its own table."""
+    _lib, ar = _mods()
+    H, G, R, L = 32, 8, 128, 1500
+    a, b, x = _inputs(H, G, R, L, seed=3)
+    ac, bc, xc = a.cuda(), b.cuda(), x.cuda()
+    full = ar.abx(ac, bc, xc)
+    part = ar.abx(ac, bc, xc[:, 384:].contiguous(), pos_offset=384)
+    scale = float(full.float().abs().max())
+    assert float((part.float() - full[:, :, 384:].float()).abs().max()) <= 5e-4 * scale
+    got = ar.abx(ac, bc, xc, theta=500000.0)
+    _p2(got, a, b, x, theta=500000.0)
+
+
+@pytest.mark.parametrize("two_band", [1, 0])
+@pytest.mark.parametrize("kind", ["perhead", "q3", "q4", "fused_c5", "fused_c2"])
+def test_cold_start_first_launch_is_deterministic(kind, two_band):
+    """the first launch of every score kernel of the family in a FRESH process equals its second and
+    third (the shared-B kernel's cold-start flake is guarded in test_abx_gpu.py); 8 processes per kernel kind, with the
+    two-band kernel (the default for these shapes) and with the one-band kernel (PALU_ABX_TWO_BAND=0)."""
+    import os
+    import subprocess
+    import sys
+    if kind.startswith("fused") and not two_band:
+        pytest.skip("the fused core has one score pipeline")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root, PALU_ABX_TWO_BAND=str(two_band))
+    env.pop("PALU_ABX_PRIO_MODE", None)
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tools", "diag_cold_start.py"), kind], env=env, cwd=root,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for _ in range(4)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tools", "diag_cold_start.py"), kind], env=env, cwd=root,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for _ in range(4)]
+    outs += [p.communicate(timeout=600)[0] for p in procs]
+    for o in outs:
+        assert "first!=second: 0  second!=third: 0" in o, o
