@@ -478,7 +478,11 @@ def main():
         if dist is not None:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         walls, evs = t[0].tolist(), t[1].tolist()
+        sev = sorted(evs)
         ab[name] = {"device_us": round(_median(evs) * 1e3 / args.steps, 2), "device_us_min": round(min(evs) * 1e3 / args.steps, 2),
+                    # p20 / p80 over the repetitions (the quantiles kernel/abx_rope.py:198-223 reports)
+                    "device_us_p20": round(sev[int(0.2 * (len(sev) - 1) + 0.5)] * 1e3 / args.steps, 2),
+                    "device_us_p80": round(sev[int(0.8 * (len(sev) - 1) + 0.5)] * 1e3 / args.steps, 2),
                     "host_wall_us": round(_median(walls) * 1e3 / args.steps, 2),
                     "host_wall_us_min": round(min(walls) * 1e3 / args.steps, 2)}
     best = min(ab, key=lambda k_: ab[k_]["device_us"])
@@ -563,6 +567,7 @@ def main():
                                  "launch_ab" % REPS},
             "launch_ab": ab,
             "host_wall_us": ab[best]["host_wall_us"],
+            "p20_us": ab[best]["device_us_p20"], "p80_us": ab[best]["device_us_p80"],
             "collective_us": None if coll_us is None else round(coll_us, 2),
             "step_algorithmic_bytes": step_b,
             "step_hbm_GBps": round(step_b / us_step * 1e-3, 1),
@@ -582,7 +587,17 @@ def main():
                                "unit": "GB/s", "frac": kern[dom]["hbm_frac"], "traffic": traffic,
                                "traffic_source": tsrc if traffic is not None else None}
             ab, af = alg["abx"]
-            rec["roofline_abx"] = {"kernel": "abx_rope", "bound": "mfma", "achieved": kern["abx"]["tflops"],
+            # the same launch on the one-band kernel (coefficient tables out of the registry), same box, same loop
+            from palu_amd.kernel.abx_rope import one_band
+            two_band = bool(lib.palu_abx_two_band_selected(inv.data_ptr(), H, G, L, Rk, 0))
+            with one_band():
+                _, kms1 = time_loop(k_abx, n, 10, torch.cuda.synchronize, reps=5)
+            rec["roofline_abx"] = {"kernel": "abx_rope2_kernel (two-band)" if two_band else "abx_rope_kernel (one-band)",
+                                   "one_band_kernel_us": round(kms1 * 1e3 / n, 2),
+                                   "flops_note": "achieved = ALGORITHMIC flops (2*H*L*R*D + 5*H*L*D, SURVEY 8(d)) / time; the "
+                                                 "two-band kernel executes 320 of every 512 MFMAs of that count (low RoPE band "
+                                                 "as a per-tile polynomial, DESIGN 4.1)",
+                                   "bound": "mfma", "achieved": kern["abx"]["tflops"],
                                    "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                                    "frac": round(kern["abx"]["tflops"] / MFMA_PEAK_TFLOPS, 4),
                                    "hbm_achieved_GBps": kern["abx"]["hbm_GBps"], "hbm_frac": kern["abx"]["hbm_frac"],
