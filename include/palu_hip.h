@@ -175,6 +175,9 @@ int palu_decode_attn_mask_f16(const void* q, int64_t sq_h, int64_t sq_d, const v
  *   (replaces DynamicCache.update's torch.cat at :193).  q_out: [H*D] fp16.
  */
 int palu_gemv_f16(const void* W, int64_t ldw, const void* x, void* y, int N, int K, palu_stream_t stream);
+/* y = W x + bias, bias [N] fp16 added to the fp32 accumulator before the rounding (or NULL): o_proj of a model built with
+ * config.attention_bias (kernel/palu_attention.py:145). */
+int palu_gemv_bias_f16(const void* W, int64_t ldw, const void* x, const void* bias, void* y, int N, int K, palu_stream_t stream);
 /* Same product, fp32 accumulators written out unrounded (y: [N] fp32): the per-rank partial of a column-sharded o_proj
  * (kernel/palu_attention.py:254-257): W = this rank's [hidden, H/N*Rv] column block (ldw = H*Rv),
  * x = its context slice; the ranks all-reduce the partials and round to fp16 once. */
@@ -184,6 +187,14 @@ int palu_decode_qkv_f16(const void* wq, int64_t ldq, const void* vtk, int64_t ld
                         void* k_cache, int64_t sk_g, int64_t sk_l, void* v_cache, int64_t sv_g, int64_t sv_l,
                         const float* inv_freq, int H, int D, int hidden, int G, int Rk, int Rv,
                         int pos, int row, palu_stream_t stream);
+/* The same with q_proj.bias ([H*D] fp16 or NULL), added before the rotation.  VT has no bias (kernel/palu_attention.py:33)
+ * and the decode branch never applies the biases of U (:207-219), so with config.attention_bias q and o_proj are the two
+ * biased products of a decode step (palu_gemv_bias_f16 is the other). */
+int palu_decode_qkv_bias_f16(const void* wq, int64_t ldq, const void* q_bias, const void* vtk, int64_t ldk,
+                             const void* vtv, int64_t ldv, const void* x, void* q_out, void* k_cache,
+                             int64_t sk_g, int64_t sk_l, void* v_cache, int64_t sv_g, int64_t sv_l,
+                             const float* inv_freq, int H, int D, int hidden, int G, int Rk, int Rv, int pos,
+                             int row, palu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Whole decode step (5 launches on `stream`): qkv+RoPE+append -> abx -> softmax.PV -> o_proj.

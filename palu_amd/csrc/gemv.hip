@@ -61,10 +61,12 @@ static __device__ __forceinline__ void stage_x(const h16* __restrict__ x, h16* x
   __syncthreads();
 }
 
+// bias (optional, nn.Linear(bias=True): kernel/palu_attention.py:142-145 with config.attention_bias): added to the fp32
+// accumulator before the one rounding, as a GEMM epilogue would
 template <typename OUT>
 __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const h16* __restrict__ W, int64_t ldw,
                                                           const h16* __restrict__ x, OUT* __restrict__ y, int N,
-                                                          int K) {
+                                                          int K, const h16* __restrict__ bias) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   h16* xs = reinterpret_cast<h16*>(smem_raw);
   stage_x(x, xs, K, threadIdx.x);
@@ -76,6 +78,10 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const h16* __restrict_
   float y0, y1;
   row_pair_dot(W + (int64_t)n0 * ldw, W + (int64_t)n1 * ldw, xs, K, lane, &y0, &y1);
   if (lane == 0) {
+    if (bias) {
+      y0 += (float)bias[n0];
+      y1 += (float)bias[n1];
+    }
     y[n0] = (OUT)y0;
     if (n0 + 1 < N) y[n0 + 1] = (OUT)y1;
   }
@@ -90,6 +96,7 @@ struct QkvParams {
   const float* inv_freq;
   int H, D, K, rank_k, rank_v, Rk, Rv;
   int pos, row;
+  const h16* q_bias;          // optional [H*D]: q_proj.bias, added before the rotation
 };
 
 // cos/sin of the oracle's fp32-rounded angle fl32(pos * f)  (kernel/pytorch_reference.py:5-6)
@@ -126,6 +133,11 @@ __global__ __launch_bounds__(GV_THREADS) void decode_qkv_kernel(QkvParams p) {
     row_pair_dot(r0, r0 + (int64_t)half * p.ldq, xs, p.K, lane, &y0, &y1);
     if (lane == 0) {
       float c, s;
+      if (p.q_bias) {
+        // HF adds the bias inside the fp16 linear (one rounding of W x + b) and rotates the fp16 result
+        y0 += (float)p.q_bias[h * p.D + i];
+        y1 += (float)p.q_bias[h * p.D + i + half];
+      }
       rope_cs(p.pos, p.inv_freq[i], &c, &s);
       p.q_out[h * p.D + i] = (h16)(y0 * c - y1 * s);
       p.q_out[h * p.D + i + half] = (h16)(y1 * c + y0 * s);
@@ -154,6 +166,12 @@ __global__ __launch_bounds__(GV_THREADS) void decode_qkv_kernel(QkvParams p) {
 }  // namespace
 
 extern "C" int palu_gemv_f16(const void* W, int64_t ldw, const void* x, void* y, int N, int K, palu_stream_t stream) {
+  return palu_gemv_bias_f16(W, ldw, x, nullptr, y, N, K, stream);
+}
+
+// y = W x + bias (bias [N] fp16 or null): o_proj of a model with attention_bias (kernel/palu_attention.py:145)
+extern "C" int palu_gemv_bias_f16(const void* W, int64_t ldw, const void* x, const void* bias, void* y, int N, int K,
+                                  palu_stream_t stream) {
   PALU_REQUIRE(W && x && y && N > 0 && K > 0, PALU_ERR_ARG, "gemv: bad arguments");
   PALU_REQUIRE(K % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)W & 15) == 0 && ((uintptr_t)x & 15) == 0, PALU_ERR_ARG,
                "gemv: K, ldw must be multiples of 8 and W, x 16-byte aligned");
@@ -161,7 +179,7 @@ extern "C" int palu_gemv_f16(const void* W, int64_t ldw, const void* x, void* y,
   const int pairs = (N + 1) / 2;
   const int blocks = (pairs + GV_THREADS / 64 - 1) / (GV_THREADS / 64);
   hipLaunchKernelGGL(gemv_kernel<h16>, dim3(blocks), dim3(GV_THREADS), (size_t)K * 2, (hipStream_t)stream, (const h16*)W,
-                     ldw, (const h16*)x, (h16*)y, N, K);
+                     ldw, (const h16*)x, (h16*)y, N, K, (const h16*)bias);
   PALU_LAUNCH_CHECK();
   return PALU_OK;
 }
@@ -177,7 +195,7 @@ extern "C" int palu_gemv_f16_acc32(const void* W, int64_t ldw, const void* x, fl
   const int pairs = (N + 1) / 2;
   const int blocks = (pairs + GV_THREADS / 64 - 1) / (GV_THREADS / 64);
   hipLaunchKernelGGL(gemv_kernel<float>, dim3(blocks), dim3(GV_THREADS), (size_t)K * 2, (hipStream_t)stream,
-                     (const h16*)W, ldw, (const h16*)x, y, N, K);
+                     (const h16*)W, ldw, (const h16*)x, y, N, K, (const h16*)nullptr);
   PALU_LAUNCH_CHECK();
   return PALU_OK;
 }
@@ -186,6 +204,18 @@ extern "C" int palu_decode_qkv_f16(const void* wq, int64_t ldq, const void* vtk,
                                    int64_t ldv, const void* x, void* q_out, void* k_cache, int64_t sk_g, int64_t sk_l,
                                    void* v_cache, int64_t sv_g, int64_t sv_l, const float* inv_freq, int H, int D,
                                    int hidden, int G, int Rk, int Rv, int pos, int row, palu_stream_t stream) {
+  return palu_decode_qkv_bias_f16(wq, ldq, nullptr, vtk, ldk, vtv, ldv, x, q_out, k_cache, sk_g, sk_l, v_cache, sv_g, sv_l,
+                                  inv_freq, H, D, hidden, G, Rk, Rv, pos, row, stream);
+}
+
+// the same with q_proj.bias ([H*D] fp16 or null).  The latent projections VT have no bias (kernel/palu_attention.py:33),
+// and the decode branch never applies the biases of U (:207-219 reads the latents only), so q and o_proj are the two
+// places config.attention_bias reaches in a decode step.
+extern "C" int palu_decode_qkv_bias_f16(const void* wq, int64_t ldq, const void* q_bias, const void* vtk, int64_t ldk,
+                                        const void* vtv, int64_t ldv, const void* x, void* q_out, void* k_cache,
+                                        int64_t sk_g, int64_t sk_l, void* v_cache, int64_t sv_g, int64_t sv_l,
+                                        const float* inv_freq, int H, int D, int hidden, int G, int Rk, int Rv, int pos,
+                                        int row, palu_stream_t stream) {
   PALU_REQUIRE(wq && vtk && vtv && x && q_out && k_cache && v_cache && inv_freq, PALU_ERR_ARG, "decode_qkv: null pointer");
   PALU_REQUIRE(H > 0 && G > 0 && D > 0 && D % 2 == 0 && Rk % 2 == 0 && Rv % 2 == 0 && hidden % 8 == 0 && pos >= 0 &&
                    row >= 0,
@@ -203,6 +233,7 @@ extern "C" int palu_decode_qkv_f16(const void* wq, int64_t ldq, const void* vtk,
   p.inv_freq = inv_freq;
   p.H = H; p.D = D; p.K = hidden; p.rank_k = G * Rk; p.rank_v = G * Rv; p.Rk = Rk; p.Rv = Rv;
   p.pos = pos; p.row = row;
+  p.q_bias = (const h16*)q_bias;
   const int pairs = H * D / 2 + p.rank_k / 2 + p.rank_v / 2;
   const int blocks = (pairs + GV_THREADS / 64 - 1) / (GV_THREADS / 64);
   hipLaunchKernelGGL(decode_qkv_kernel, dim3(blocks), dim3(GV_THREADS), (size_t)hidden * 2, (hipStream_t)stream, p);

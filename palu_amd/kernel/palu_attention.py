@@ -197,6 +197,25 @@ class QuantLatentCache:
         c, m = quantize_pack(x.reshape(*x.shape[:-1], R // gsz, gsz), self.n_bits)
         return c.reshape(*x.shape[:-1], -1), m.reshape(*x.shape[:-1], -1)
 
+    def append_rows(self, key_states: torch.Tensor, value_states: torch.Tensor, layer_idx: int) -> None:
+        """quantise + pack `[1, G, t, R]` latent rows behind the cached ones (what `update` does, without handing back a
+        dequantised copy of the whole cache)."""
+        if key_states.dim() != 4 or value_states.dim() != 4:
+            raise ValueError("QuantLatentCache expects [bsz, groups, seq, rank] tensors")
+        _, G, t, Rk = key_states.shape
+        Rv = value_states.shape[3]
+        self._ensure_layer(layer_idx)
+        n = self._len[layer_idx]
+        self.reserve(layer_idx, n + t + self._headroom, G, Rk, Rv, key_states.device)
+        st = self._store[layer_idx]
+        kc, km = self._quantize(key_states)
+        vc, vm = self._quantize(value_states)
+        st["kc"][:, :, n:n + t].copy_(kc)
+        st["km"][:, :, n:n + t].copy_(km)
+        st["vc"][:, :, n:n + t].copy_(vc)
+        st["vm"][:, :, n:n + t].copy_(vm)
+        self._len[layer_idx] = n + t
+
     def update(self, key_states: torch.Tensor, value_states: torch.Tensor, layer_idx: int, cache_kwargs=None):
         from .quant import quantize_pack
         if key_states.dim() != 4 or value_states.dim() != 4:
@@ -493,8 +512,8 @@ class LlamaPaluAttention(nn.Module):
 
     def _decode_fused(self, hidden_states, attention_mask, pos, cache: "LatentCache", output_attentions):
         """q_len == 1, U_v folded into o_proj: the whole step in the HIP library."""
-        if self.q_proj.bias is not None:
-            raise NotImplementedError("attention_bias=True is not supported by the HIP decode step")
+        if self.q_proj.bias is not None or self.o_proj.bias is not None:
+            return self._decode_biased(hidden_states, attention_mask, pos, cache, output_attentions)
         dev = hidden_states.device
         li = self.layer_idx
         n = cache.get_seq_length(li)
@@ -539,10 +558,83 @@ class LlamaPaluAttention(nn.Module):
         cache.advance(li, 1)
         return out, probs
 
+    def _decode_biased(self, hidden_states, attention_mask, pos, cache, output_attentions):
+        """config.attention_bias (kernel/palu_attention.py:142-145): the same HIP kernels, launched one by one, with
+        q_proj.bias inside the qkv kernel (before the rotation) and o_proj.bias inside the last GEMV.  The latent
+        projections have no bias (:33) and the decode branch never applies U's (:207-219)."""
+        dev, dt = hidden_states.device, hidden_states.dtype
+        li = self.layer_idx
+        n = cache.get_seq_length(li)
+        H, G, D, Rk, Rv = self.num_heads, self.num_groups, self.head_dim, self.group_rank_k, self.group_rank_v
+        packed = isinstance(cache, QuantLatentCache)
+        L = n + 1
+        S = _lib.current_stream
+        inv = rope_inv_freq(dev, D, self.rope_theta)
+        frag = prepare_b(self.k_proj.B, G)
+        x = hidden_states.reshape(-1).contiguous()
+        wq, vtk, vtv, wo = self.q_proj.weight, self.k_proj.VT.weight, self.v_proj.VT.weight, self.o_proj.weight
+        qb = 0 if self.q_proj.bias is None else self.q_proj.bias.data_ptr()
+        ob = 0 if self.o_proj.bias is None else self.o_proj.bias.data_ptr()
+        q = torch.empty(H * D, dtype=dt, device=dev)
+        scores = torch.empty((H, (L + 15) // 8 * 8), dtype=dt, device=dev)
+        ctx = torch.empty(H * Rv, dtype=dt, device=dev)
+        pvws = torch.empty(_lib.lib.palu_pv_workspace_bytes(H, G, L, Rv), dtype=torch.uint8, device=dev)
+        out = torch.empty((1, 1, self.hidden_size), dtype=dt, device=dev)
+        probs = torch.empty((1, H, 1, L), dtype=dt, device=dev) if output_attentions else None
+        mask_ptr = 0
+        if attention_mask is not None:
+            attention_mask = additive_mask(attention_mask, dt).reshape(-1).contiguous()
+            mask_ptr = attention_mask.data_ptr()
+        if not packed:
+            if cache.capacity(li) < L:
+                cache.reserve(li, L + cache._headroom, torch.empty((1, G, 0, Rk), dtype=dt, device=dev),
+                              torch.empty((1, G, 0, Rv), dtype=dt, device=dev))
+            kbuf, vbuf = cache.buffers(li)
+            _lib.check(_lib.lib.palu_decode_qkv_bias_f16(
+                wq.data_ptr(), wq.stride(0), qb, vtk.data_ptr(), vtk.stride(0), vtv.data_ptr(), vtv.stride(0), x.data_ptr(),
+                q.data_ptr(), kbuf.data_ptr(), kbuf.stride(1), kbuf.stride(2), vbuf.data_ptr(), vbuf.stride(1), vbuf.stride(2),
+                inv.data_ptr(), H, D, self.hidden_size, G, Rk, Rv, int(pos), n, S()), "palu_decode_qkv_bias_f16")
+            cache.advance(li, 1)
+            nscr = _lib.lib.palu_abx_scratch_bytes(H, G, L, Rk)
+            scr = torch.empty(nscr, dtype=torch.uint8, device=dev) if nscr else None
+            _lib.check(_lib.lib.palu_abx_rope_ws_f16(q.data_ptr(), D, 1, frag.data_ptr(), kbuf.data_ptr(), kbuf.stride(1),
+                                                     kbuf.stride(2), scores.data_ptr(), scores.stride(0), H, G, L, Rk, D,
+                                                     inv.data_ptr(), 0, 0 if scr is None else scr.data_ptr(), S()),
+                       "palu_abx_rope_ws_f16")
+            _lib.check(_lib.lib.palu_softmax_pv_f16(scores.data_ptr(), scores.stride(0), mask_ptr, vbuf.data_ptr(),
+                                                    vbuf.stride(1), vbuf.stride(2), ctx.data_ptr(),
+                                                    0 if probs is None else probs.data_ptr(),
+                                                    0 if probs is None else probs.stride(1), pvws.data_ptr(), H, G, L, Rv,
+                                                    math.sqrt(D), S()), "palu_softmax_pv_f16")
+        else:
+            knew = torch.empty((1, G, 1, Rk), dtype=dt, device=dev)
+            vnew = torch.empty((1, G, 1, Rv), dtype=dt, device=dev)
+            _lib.check(_lib.lib.palu_decode_qkv_bias_f16(
+                wq.data_ptr(), wq.stride(0), qb, vtk.data_ptr(), vtk.stride(0), vtv.data_ptr(), vtv.stride(0), x.data_ptr(),
+                q.data_ptr(), knew.data_ptr(), Rk, 0, vnew.data_ptr(), Rv, 0, inv.data_ptr(), H, D, self.hidden_size, G, Rk, Rv,
+                int(pos), 0, S()), "palu_decode_qkv_bias_f16")
+            cache.append_rows(knew, vnew, li)                     # quantise + pack the new rows in place
+            st = cache.buffers(li)
+            kc, km, vc, vm = st["kc"], st["km"], st["vc"], st["vm"]
+            nscr = _lib.lib.palu_abx_scratch_bytes(H, G, L, Rk)
+            scr = torch.empty(nscr, dtype=torch.uint8, device=dev) if nscr else None
+            _lib.check(_lib.lib.palu_abx_rope_qg(q.data_ptr(), D, 1, frag.data_ptr(), kc.data_ptr(), kc.stride(1), kc.stride(2),
+                                                 km.data_ptr(), km.stride(1), km.stride(2), scores.data_ptr(), scores.stride(0),
+                                                 H, G, L, Rk, D, cache.n_bits, cache.group_size, inv.data_ptr(), 0,
+                                                 0 if scr is None else scr.data_ptr(), S()), "palu_abx_rope_qg")
+            _lib.check(_lib.lib.palu_softmax_pv_qg(scores.data_ptr(), scores.stride(0), mask_ptr, vc.data_ptr(), vc.stride(1),
+                                                   vc.stride(2), vm.data_ptr(), vm.stride(1), vm.stride(2), ctx.data_ptr(),
+                                                   0 if probs is None else probs.data_ptr(),
+                                                   0 if probs is None else probs.stride(1), pvws.data_ptr(), H, G, L, Rv,
+                                                   cache.n_bits, cache.group_size, math.sqrt(D), S()), "palu_softmax_pv_qg")
+        _lib.check(_lib.lib.palu_gemv_bias_f16(wo.data_ptr(), wo.stride(0), ctx.data_ptr(), ob, out.data_ptr(),
+                                               self.hidden_size, H * Rv, S()), "palu_gemv_bias_f16")
+        return out, probs
+
     def _decode_fused_q(self, hidden_states, attention_mask, pos, cache: "QuantLatentCache", output_attentions):
         """q_len == 1 on a packed 3/4-bit cache: palu_decode_step_q."""
-        if self.q_proj.bias is not None:
-            raise NotImplementedError("attention_bias=True is not supported by the HIP decode step")
+        if self.q_proj.bias is not None or self.o_proj.bias is not None:
+            return self._decode_biased(hidden_states, attention_mask, pos, cache, output_attentions)
         dev = hidden_states.device
         li = self.layer_idx
         n = cache.get_seq_length(li)

@@ -2,13 +2,18 @@
 """Kernel micro-benchmark for the fused abx_rope score kernel -- same CLI as the reference's
 run_latency_kernel.py (:5-13) / kernel/abx_rope.py::run_benchmark (:173-228), without Triton:
 warm-up 25, 100 timed reps, median/p20/p80 in microseconds (abx_rope.py:198-223), randn fp16
-inputs (:200-204).  Providers: `WX` (uncompressed q.K^T, torch.matmul), `ours` (HIP abx).
+inputs (:200-204).  Providers, as in the reference (:180-181, :208-221): `WX` (uncompressed q.K^T, torch.matmul),
+`torch` (the reference's own PyTorch path `torch_abx`, :152-171 -- reconstruct K with a batched matmul through
+hipBLASLt, fp32 RoPE, fp16 q.K^T -- restated on the GPU) and `ours` (HIP abx).  Results are printed and, like
+`bench_low_rank.run(save_path='results/')` (:227-228), written to results/low-rank-rank-<R>-group-<G>.csv.
 Adds achieved HBM GB/s and MFMA TFLOP/s from the algorithmic bytes/flops of SURVEY.md 8(d).
 """
 from __future__ import annotations
 
 import argparse
+import csv
 import json
+import os
 
 import torch
 
@@ -51,6 +56,22 @@ def do_bench_total(fn, warmup=25, rep=100):
     return s.elapsed_time(e) * 1e3 / rep
 
 
+def torch_provider(a, b, x, theta=10000.0):
+    """The reference's PyTorch path for the same scores (kernel/abx_rope.py:152-171 `torch_abx`, with the rotary tables of
+    kernel/pytorch_reference.py:3-21) as stock torch ops on the GPU: K = x @ B per group (fp16 batched matmul), RoPE in
+    fp32 at positions 0..L-1, one rounding to fp16, q @ K^T."""
+    H, R, D = b.shape
+    G, L, _ = x.shape
+    keys = torch.matmul(x[:, None], b.reshape(G, H // G, R, D)).reshape(H, L, D)
+    inv = 1.0 / (theta ** (torch.arange(0, D, 2, dtype=torch.int64, device=x.device).float() / D))
+    ang = torch.outer(torch.arange(L, device=x.device, dtype=torch.int64).float(), inv)
+    ang = torch.cat((ang, ang), dim=-1)
+    cos, sin = ang.cos(), ang.sin()
+    rot = torch.cat((-keys[..., D // 2:], keys[..., :D // 2]), dim=-1)
+    keys = (keys * cos + rot * sin).to(torch.float16)
+    return torch.matmul(a, keys.transpose(-1, -2))
+
+
 def abx_algorithmic(H, G, L, R, D=128):
     nbytes = 2 * G * L * R + 2 * H * R * D + 2 * H * D + 2 * H * L
     flops = 2 * H * L * R * D + 5 * H * L * D
@@ -67,6 +88,8 @@ def main():
     ap.add_argument("--flush_mb", type=int, default=0, help="write this many MiB between reps to defeat the 256 MiB Infinity Cache")
     ap.add_argument("--no_fold", action="store_true", help="keep q in fp32 instead of folding it into B (slower, exact)")
     ap.add_argument("--json", action="store_true")
+    ap.add_argument("--save_path", default="results/", help="directory of the CSV (abx_rope.py:227-228); '' = no file")
+    ap.add_argument("--no_torch_provider", action="store_true", help="skip the PyTorch provider (6 GB of temporaries at 262144)")
     args = ap.parse_args()
 
     from palu_amd.kernel.abx_rope import abx, set_fold
@@ -90,16 +113,30 @@ def main():
         ours = do_bench(lambda: abx(A, B, X, out=out_buf), flush_mb=args.flush_mb)
         ours_total = do_bench_total(lambda: abx(A, B, X, out=out_buf))
         wx = do_bench(lambda: torch.matmul(org_A, org_X.transpose(-1, -2)), flush_mb=args.flush_mb)
+        tch = (float("nan"),) * 3
+        if not args.no_torch_provider:
+            tch = do_bench(lambda: torch_provider(A, B, X), warmup=5, rep=20, flush_mb=args.flush_mb)
         nbytes, flops = abx_algorithmic(H, G, L, R, D)
-        row = {"seq_len": L, "ours_us": ours[0], "ours_p20": ours[1], "ours_p80": ours[2], "WX_us": wx[0],
+        row = {"seq_len": L, "ours_us": ours[0], "ours_p20": ours[1], "ours_p80": ours[2], "WX_us": wx[0], "torch_us": tch[0],
                "hbm_GBps": nbytes / ours[0] * 1e-3, "hbm_frac": nbytes / ours[0] * 1e-3 / 8000.0,
                "mfma_TFLOPs": flops / ours[0] * 1e-6, "mfma_frac": flops / ours[0] * 1e-6 / 2500.0}
         rows.append(row)
         row["ours_back_to_back_us"] = ours_total
         print(f"L={L:7d}  ours {ours[0]:9.1f} us (p20 {ours[1]:.1f}, p80 {ours[2]:.1f}; {ours_total:.1f} us/call back-to-back)   WX {wx[0]:9.1f} us   "
+              f"torch {tch[0]:9.1f} us   "
               f"{row['hbm_GBps']:7.0f} GB/s ({100 * row['hbm_frac']:.1f}% of 8 TB/s)   "
               f"{row['mfma_TFLOPs']:6.0f} TF ({100 * row['mfma_frac']:.1f}% of 2.5 PF)")
         del X, org_X
+    if args.save_path:
+        os.makedirs(args.save_path, exist_ok=True)
+        fn = os.path.join(args.save_path, f"low-rank-rank-{args.total_rank}-group-{G}.csv")
+        with open(fn, "w", newline="") as f:
+            wr = csv.writer(f)
+            wr.writerow(["seq_len", "WX", "Torch", "Ours", "Ours_p20", "Ours_p80", "hbm_GBps", "mfma_TFLOPs"])
+            for r in rows:
+                wr.writerow([r["seq_len"], f"{r['WX_us']:.3f}", f"{r['torch_us']:.3f}", f"{r['ours_us']:.3f}",
+                             f"{r['ours_p20']:.3f}", f"{r['ours_p80']:.3f}", f"{r['hbm_GBps']:.1f}", f"{r['mfma_TFLOPs']:.1f}"])
+        print("saved", fn)
     if args.json:
         print(json.dumps(rows))
 

@@ -599,3 +599,59 @@ def test_decode_step_with_shared_b_goes_through_the_shared_kernel(with_probs):
     torch.testing.assert_close(out.cpu().reshape(-1), ref_out, rtol=1e-3, atol=1e-3)
     if with_probs:
         torch.testing.assert_close(probs.cpu().reshape(H, L + 1), ref_p, rtol=1e-3, atol=1e-3)
+
+
+@pytest.mark.parametrize("bits", [16, 4])
+def test_decode_step_with_attention_bias(bits):
+    """config.attention_bias = True (kernel/palu_attention.py:142-145): q_proj.bias inside the qkv kernel, o_proj.bias inside
+    the last GEMV, fp16 and packed caches.  Oracle: the same decode step on weights augmented by one bias column and a
+    token augmented by a constant 1 (fp16 matmul with fp32 accumulation: W x + b rounded once), o_proj.bias added last."""
+    from palu_amd.kernel.palu_attention import LatentCache, LlamaPaluAttention, QuantLatentCache, build_b
+    tag, seed, hidden, H, D, gs, rank_k, rank_v, L, _ = gi.STEP_CASES[0]
+    w, k_lat, v_lat, tok, _ = gi.step_inputs(seed, hidden, H, D, gs, rank_k, rank_v, L, False)
+
+    class Cfg:
+        pass
+    cfg = Cfg()
+    cfg.hidden_size, cfg.num_attention_heads, cfg.attention_bias = hidden, H, True
+    cfg.group_size, cfg.num_groups, cfg.total_rank_k, cfg.total_rank_v = gs, H // gs, rank_k, rank_v
+    m = LlamaPaluAttention(cfg, 0)
+    g = torch.Generator().manual_seed(3)
+    qb = (torch.randn(H * D, generator=g) * 0.5).half()
+    ob = (torch.randn(hidden, generator=g) * 0.02).half()
+    with torch.no_grad():
+        m.q_proj.weight.copy_(w["wq"])
+        m.q_proj.bias.copy_(qb)
+        m.k_proj.VT.weight.copy_(w["vt_k"])
+        m.v_proj.VT.weight.copy_(w["vt_v"])
+        m.o_proj.weight.copy_(w["wo"])
+        m.o_proj.bias.copy_(ob)
+    m.k_proj.B = nn.Parameter(build_b(w["u_k"], gs, D))
+    m = m.eval().to(DEV, torch.float16)
+    if bits == 16:
+        cache = LatentCache()
+        cache.update(k_lat.unsqueeze(0).to(DEV), v_lat.unsqueeze(0).to(DEV), 0)
+        k_ref, v_ref, lb = k_lat, v_lat, None
+    else:
+        cache = QuantLatentCache(bits)
+        cache.update(k_lat.unsqueeze(0).to(DEV), v_lat.unsqueeze(0).to(DEV), 0)
+        k_ref = oracle.quantize_rows(k_lat.reshape(-1, k_lat.shape[-1]), bits)[0].reshape(k_lat.shape)
+        v_ref = oracle.quantize_rows(v_lat.reshape(-1, v_lat.shape[-1]), bits)[0].reshape(v_lat.shape)
+        lb = bits
+    with torch.no_grad():
+        out, probs, _ = m(tok.reshape(1, 1, hidden).to(DEV), position_ids=torch.arange(L, L + 1), past_key_value=cache,
+                          output_attentions=True)
+    assert cache.get_seq_length(0) == L + 1
+    pad = 8
+    tok_a = torch.cat((tok.reshape(-1), torch.ones(1, dtype=tok.dtype), torch.zeros(pad - 1, dtype=tok.dtype)))
+    aug = lambda wt, b=None: torch.cat((wt.half(), (torch.zeros(wt.shape[0], 1) if b is None else b.reshape(-1, 1)).half(),
+                                        torch.zeros(wt.shape[0], pad - 1).half()), dim=1)
+    wd = {"wq": aug(w["wq"], qb), "vt_k": aug(w["vt_k"]), "vt_v": aug(w["vt_v"]),
+          "b": oracle.build_b_from_u(w["u_k"], gs, D).half(), "wo": w["wo"].half()}
+    kw = {} if lb is None else {"latent_bits": lb}
+    o2, p2, _, _ = oracle.decode_step(tok_a, L, wd, k_ref, v_ref, **kw)
+    o2 = (o2.float() + ob.float())
+    torch.testing.assert_close(probs.cpu().reshape(H, L + 1).float(), p2.float(), rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(out.cpu().reshape(-1).float(), o2, rtol=1e-3, atol=1e-3)
+    # the bias really took part
+    assert (qb.abs().max() > 0.1) and float((out.cpu().reshape(-1).float() - (o2 - ob.float())).abs().max()) > 1e-2

@@ -53,7 +53,15 @@ def test_attention_harness_head_parallel_leg_under_torchrun():
     assert j["gpus"] == 1 and j["cache_graph"] is True and j["latency_us"] > 0
 
 
-def test_kernel_harness():
+def test_kernel_harness(tmp_path):
+    """the three providers of kernel/abx_rope.py:180-221 (WX, Torch, Ours) and the CSV of :227-228"""
+    import csv
+    import json
     out = _run([sys.executable, "run_latency_kernel.py", "--total_rank", "1024", "--group_size", "4", "--target_seq_lens", "4096",
-                "--json"])
+                "--json", "--save_path", str(tmp_path)])
     assert "4096" in out
+    rows = json.loads([l for l in out.splitlines() if l.startswith("[")][-1])
+    assert rows[0]["torch_us"] > rows[0]["ours_us"] > 0 and rows[0]["WX_us"] > 0
+    with open(tmp_path / "low-rank-rank-1024-group-8.csv") as f:
+        got = list(csv.reader(f))
+    assert got[0][:4] == ["seq_len", "WX", "Torch", "Ours"] and got[1][0] == "4096"
