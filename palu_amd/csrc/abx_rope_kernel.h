@@ -1125,7 +1125,7 @@ inline bool abx_plan(int H, int G, int R, AbxPlan* pl) {
 inline int abx_prio_mode(bool shared = false) {
   static int m = -2;
   if (m == -2) {
-    const char* e = getenv("PALU_ABX_PRIO_MODE");
+    const char* e = palu_exp_env("PALU_ABX_PRIO_MODE");
     m = e ? atoi(e) : -1;
   }
   return m >= 0 ? m : 0;
@@ -1140,14 +1140,14 @@ inline int abx_fill_params(AbxParams& p, const AbxPlan& pl, int H, int G, int L,
   p.prio_mode = abx_prio_mode();
   static int exp_flags = -1;        // PALU_ABX_EXP: experiment flags (4 = angle correction on every wave); read once
   if (exp_flags < 0) {
-    const char* e = getenv("PALU_ABX_EXP");
+    const char* e = palu_exp_env("PALU_ABX_EXP");
     exp_flags = e ? atoi(e) : 0;
   }
   p.exp_flags = exp_flags;
   const int ngb = G * pl.hb;
   static int cu_cap = -1;           // PALU_ABX_CUS: experiments that leave part of the GPU to another kernel
   if (cu_cap < 0) {
-    const char* e = getenv("PALU_ABX_CUS");
+    const char* e = palu_exp_env("PALU_ABX_CUS");
     cu_cap = e ? atoi(e) : 0;
   }
   const int cus = (cu_cap > 0 && cu_cap < palu_num_cus()) ? cu_cap : palu_num_cus();

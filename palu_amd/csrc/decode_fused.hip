@@ -33,7 +33,7 @@ bool fused_col_plan(int Rv, int* nts, int* ntl) {
 int g_fused_exp = -1;
 int fused_exp_flags() {
   if (g_fused_exp < 0) {
-    const char* e = getenv("PALU_FUSED_EXP");
+    const char* e = palu_exp_env("PALU_FUSED_EXP");
     g_fused_exp = e ? atoi(e) : 0;
   }
   return g_fused_exp;
@@ -42,7 +42,7 @@ int fused_exp_flags() {
 int fused_prio_mode() {   // 0 none, 2 score-block alternation (abx_rope_kernel.h), 3 (default) priority to the side work
   static int m = -1;
   if (m < 0) {
-    const char* e = getenv("PALU_FUSED_PRIO");
+    const char* e = palu_exp_env("PALU_FUSED_PRIO");
     m = e ? atoi(e) : 3;
   }
   return m;

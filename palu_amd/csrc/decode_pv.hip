@@ -996,7 +996,7 @@ __global__ void probs_kernel(const h16* scores, int64_t ss_h, const h16* mask, c
 int pv_wgs_per_cu() {
   static int per_cu = 0;
   if (per_cu == 0) {
-    const char* e = getenv("PALU_PV_WGS_PER_CU");
+    const char* e = palu_exp_env("PALU_PV_WGS_PER_CU");
     per_cu = e ? atoi(e) : 4;
     if (per_cu < 1) per_cu = 1;
   }
@@ -1031,7 +1031,7 @@ float pv_exact_rcp(float d) {
 int pv_qr_wgs() {
   static int wgs = 0;
   if (wgs == 0) {
-    const char* e = getenv("PALU_PVQ_WGS");
+    const char* e = palu_exp_env("PALU_PVQ_WGS");
     wgs = e ? atoi(e) : 1;
     if (wgs < 1) wgs = 1;
   }
@@ -1186,7 +1186,7 @@ static int pv_qr_launch(const void* scores, int64_t ss_h, const void* mask, cons
     if (ex < 0) {
       // PALU_PVQ_TIMELINE_DUMP=<bytes the caller added behind the workspace>: every wave dumps 5 wall-clock stamps there
       // (tools/time_pvq.py).  The explicit size keeps an accidental setting from writing past a normal workspace.
-      const char* e = getenv("PALU_PVQ_TIMELINE_DUMP");
+      const char* e = palu_exp_env("PALU_PVQ_TIMELINE_DUMP");
       ex = (e && atoll(e) >= (long long)G * ns * 8 * 5 * 8) ? 8 : 0;
     }
     p.exp_flags = ex;
@@ -1196,7 +1196,7 @@ static int pv_qr_launch(const void* scores, int64_t ss_h, const void* mask, cons
   {
     static int prio = -1;
     if (prio < 0) {
-      const char* e = getenv("PALU_PVQ_PRIO");
+      const char* e = palu_exp_env("PALU_PVQ_PRIO");
       prio = e ? atoi(e) : 1;
     }
     p.qr_prio = prio;

@@ -16,6 +16,20 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define PALU_WAVE 64
 
+// Experiment knobs (wave priorities, workgroups per CU, timeline dumps, ...) are read from the environment only in a build
+// with -DPALU_EXPERIMENTS (PALU_EXTRA_CFLAGS=-DPALU_EXPERIMENTS python -m palu_amd.build --force); the shipped library runs
+// the measured defaults.  The kernel-selection switches that tests and A/B runs use stay: PALU_ABX_TWO_BAND, PALU_FUSED_ATTN,
+// PALU_PVQ_DIRECT, PALU_PV_DIRECT.
+#include <stdlib.h>
+static inline const char* palu_exp_env(const char* name) {
+#ifdef PALU_EXPERIMENTS
+  return getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
+}
+
 // Set by every entry point on failure; read with palu_last_error().
 void palu_set_error(const char* fmt, ...);
 

@@ -599,7 +599,7 @@ extern "C" int palu_prefill_attn_f16(const void* q, int64_t sq_h, int64_t sq_t, 
   {
     static int force = -2;                       // PALU_PREFILL_HEAD_MAJOR = 0 / 1 overrides the size rule
     if (force == -2) {
-      const char* e = getenv("PALU_PREFILL_HEAD_MAJOR");
+      const char* e = palu_exp_env("PALU_PREFILL_HEAD_MAJOR");
       force = e ? atoi(e) : -1;
     }
     p.head_major = force >= 0 ? force : ((int64_t)p.nqt * H <= 2048 ? 1 : 2);
@@ -608,7 +608,7 @@ extern "C" int palu_prefill_attn_f16(const void* q, int64_t sq_h, int64_t sq_t, 
   hipStream_t s = (hipStream_t)stream;
   static int use_pair = -1;
   if (use_pair < 0) {
-    const char* e = getenv("PALU_PREFILL_PAIR");
+    const char* e = palu_exp_env("PALU_PREFILL_PAIR");
     use_pair = e ? atoi(e) : 1;
   }
   if (use_pair && Rv % 64 == 0 && Rv <= 384) {          // two waves per 32 queries, each half of the latent columns
