@@ -280,7 +280,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
       cf[cs] = *reinterpret_cast<h16x8*>(&v);
     }
   };
-  h16x8 cf0[2], cfC[2], cfN[2];
+  h16x8 cf0[2], cfC[2];
   load_coef(0, cf0);
   load_coef(1, cfC);
 
@@ -438,12 +438,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
   //      the PREVIOUS block (accumulators acP -> partial sums of block eblk in slot erslot), one chunk of 4 VALU operations
   //      per MFMA gap.  S2M: this wave also runs stage 2 of block blk (its NS2 k-steps); S2E: the previous block was this
   //      wave's stage-2 block, its 16 FMAs join the epilogue.
-  auto region = [&](auto kind_c, auto last_c, auto s2m_c, auto s2e_c, f32x16& acN, int blk, int erslot, int eblk,
-                    const f32x16& acP, int stt, int sslot, unsigned nd, unsigned wrd) {
+  auto region = [&](auto kind_c, auto last_c, auto s2m_c, auto s2e_c, auto s1_c, f32x16& acN, int blk, int erslot, int eblk,
+                    const f32x16& acP, int stt, int sslot, unsigned nd, unsigned wrd, int wnext) {
     constexpr int KIND = decltype(kind_c)::value;
     constexpr bool LAST = decltype(last_c)::value;
     constexpr bool S2M = decltype(s2m_c)::value;
     constexpr bool S2E = decltype(s2e_c)::value;
+    constexpr bool S1 = decltype(s1_c)::value;      // stage 1 of the NEXT tile rides in this region's MFMA gaps
+    constexpr int S1PG = 8 / NKS;                   // stage-1 MFMAs per gap (8 per tile and wave)
+    f32x4 wa[4];
+    if (S1) {
+#pragma unroll
+      for (int h4 = 0; h4 < 4; ++h4) wa[h4] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     constexpr int GAPS = NKS;
     constexpr int NC = 8 + (S2E ? 4 : 0);
     constexpr int CPG = (NC + GAPS - 1) / GAPS;
@@ -501,6 +508,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
           accS2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfr[ks], xf[ks % XD], accS2, 0, 0, 0);
           asm volatile("" : "+v"(accS2));
         }
+        if (S1) {
+#pragma unroll
+          for (int i = 0; i < S1PG; ++i) {
+            const int m = ks * S1PG + i;            // (head, c-step) = (m >> 1, m & 1)
+            wa[m >> 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lowf[m >> 1][m & 1], cfC[m & 1], wa[m >> 1], 0, 0, 0);
+            asm volatile("" : "+v"(wa[m >> 1]));
+          }
+        }
       }
 #pragma unroll
       for (int q = 0; q < CPG; ++q)
@@ -539,6 +554,19 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
       load_q(min(stt + 1, ntile - 1));
     }
     if (KIND == 1) reduce_store(stt, sslot);
+    if (S1) {
+      // W image of the next tile: lane (k, q) holds W_h[k][16 w + 4 q + j] (waves beyond the rank's r-blocks computed on
+      // r-block 0 and store nothing)
+      if (s1_wave && (lane & 15) < ABX2_K) {
+#pragma unroll
+        for (int h4 = 0; h4 < 4; ++h4) {
+          h16x4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (h16)wa[h4][j];
+          *(__attribute__((address_space(3))) h16x4*)(uintptr_t)(w_st + (unsigned)(wnext * WB + h4 * 8 * 16)) = o;
+        }
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
   };
 
@@ -558,40 +586,41 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
   using NotLast = std::false_type;
   using Last = std::true_type;
   int s_cur = 0, s_nxt = 1, s_prv = 2;
-  const bool early_s1 = w < 4;                    // the two waves of a SIMD run stage 1 at different points of a tile
 
   auto main_loop = [&](auto s_c) {
     constexpr int S = decltype(s_c)::value;       // this wave's stage-2 block
     // S2M = (block == S), S2E = (block whose epilogue runs == S)
-#ifdef PALU_ABX2_EXP_NOS2
+    // stage 1 of the next tile rides in region (S + 2) & 3: neither this wave's stage-2 region nor the one after it, so its
+    // 16 accumulator registers can be the (then dead) stage-2 accumulators
 #define ABX2_REGION(KIND, LASTT, BLK, ACN, ERSLOT, EBLK, ACP, STT, SSLOT, ND, WRD)                                          \
-  region(KIND{}, LASTT{}, std::false_type{}, std::false_type{}, ACN, BLK, ERSLOT, EBLK, ACP, STT, SSLOT, ND, WRD)
-#else
-#define ABX2_REGION(KIND, LASTT, BLK, ACN, ERSLOT, EBLK, ACP, STT, SSLOT, ND, WRD)                                          \
-  region(KIND{}, LASTT{}, std::integral_constant<bool, (BLK) == S>{}, std::integral_constant<bool, (EBLK) == S>{}, ACN, BLK, \
-         ERSLOT, EBLK, ACP, STT, SSLOT, ND, WRD)
-#endif
+  region(KIND{}, LASTT{}, std::integral_constant<bool, (BLK) == S>{}, std::integral_constant<bool, (EBLK) == S>{},          \
+         std::integral_constant<bool, (BLK) == ((S + 2) & 3)>{}, ACN, BLK, ERSLOT, EBLK, ACP, STT, SSLOT, ND, WRD, wnext)
+#define ABX2_REGION_T(KIND, LASTT, BLK, ACN, ERSLOT, EBLK, ACP, STT, SSLOT, ND, WRD)                                        \
+  region(KIND{}, LASTT{}, std::integral_constant<bool, (BLK) == S>{}, std::integral_constant<bool, (EBLK) == S>{},          \
+         std::false_type{}, ACN, BLK, ERSLOT, EBLK, ACP, STT, SSLOT, ND, WRD, 0)
     const int nmain = tail_nb < 4 ? ntile - 1 : ntile;
     for (int tt = 0; tt < nmain; ++tt) {
       if (tt > 0) {
         dma_wait();
         __syncthreads();
       }
-      load_coef(tt + 2, cfN);                     // stage 1 of tile tt + 2 runs during tile tt + 1
+      // the coefficient fragments requested during the previous tile have landed (vmcnt(0) above): make hipcc place its
+      // own wait for them HERE and not in front of the stage-1 MFMAs, where it would also wait for this tile's DMA pieces
+      asm volatile("" : "+v"(cfC[0]), "+v"(cfC[1]));
       const unsigned nd = (unsigned)((s_nxt - s_cur) * Geo::TILE_BYTES);
       const unsigned wrd = w_rd + (unsigned)((tt & 1) * WB);
+      const int wnext = (tt + 1) & 1;             // (a stage 1 past the last tile writes an image nobody reads)
+      // the coefficients of tile tt + 2 (its stage 1 runs during tile tt + 1) are requested as soon as this tile's stage 1
+      // has consumed the current ones: a whole tile and a barrier's vmcnt(0) ahead of their use
+      constexpr int R1 = (S + 2) & 3;
       ABX2_REGION(K0, NotLast, 0, accA, s_prv, 3, accB, min(tt + 2, ntile - 1), s_prv, 0u, wrd);
+      if (R1 == 0) load_coef(tt + 2, cfC);
       ABX2_REGION(K1, NotLast, 1, accB, s_cur, 0, accA, tt - 2, s_nxt, 0u, wrd);
-#ifndef PALU_ABX2_EXP_NOS1
-      if (early_s1 && s1_wave && tt + 1 < ntile) stage1(cfC, (tt + 1) & 1);
-#endif
+      if (R1 == 1) load_coef(tt + 2, cfC);
       ABX2_REGION(K2, NotLast, 2, accA, s_cur, 1, accB, 0, 0, 0u, wrd);
-#ifndef PALU_ABX2_EXP_NOS1
-      if (!early_s1 && s1_wave && tt + 1 < ntile) stage1(cfC, (tt + 1) & 1);
-#endif
+      if (R1 == 2) load_coef(tt + 2, cfC);
       ABX2_REGION(K2, Last, 3, accB, s_cur, 2, accA, 0, 0, nd, wrd);
-      cfC[0] = cfN[0];
-      cfC[1] = cfN[1];
+      if (R1 == 3) load_coef(tt + 2, cfC);
       const int t3 = s_prv;
       s_prv = s_cur;
       s_cur = s_nxt;
@@ -606,10 +635,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
         __syncthreads();
       }
       const unsigned wrd = w_rd + (unsigned)((tt & 1) * WB);
-      ABX2_REGION(K2, NotLast, 0, accA, s_prv, 3, accB, 0, 0, 0u, wrd);
-      if (tail_nb >= 2) ABX2_REGION(K1, NotLast, 1, accB, s_cur, 0, accA, tt - 2, s_nxt, 0u, wrd);
+      ABX2_REGION_T(K2, NotLast, 0, accA, s_prv, 3, accB, 0, 0, 0u, wrd);
+      if (tail_nb >= 2) ABX2_REGION_T(K1, NotLast, 1, accB, s_cur, 0, accA, tt - 2, s_nxt, 0u, wrd);
       else reduce_store(tt - 2, s_nxt);
-      if (tail_nb == 3) ABX2_REGION(K2, NotLast, 2, accA, s_cur, 1, accB, 0, 0, 0u, wrd);
+      if (tail_nb == 3) ABX2_REGION_T(K2, NotLast, 2, accA, s_cur, 1, accB, 0, 0, 0u, wrd);
       if (tail_nb != 2) accB = accA;
       drain_slot = s_cur;
       drain_blk = tail_nb - 1;
@@ -619,9 +648,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
       s_nxt = t3;
     }
     // drain: epilogue of the very last block (with this wave's stage-2 terms if that block is S)
-    if (drain_blk == S) region(K3{}, NotLast{}, std::false_type{}, std::true_type{}, accA, 0, drain_slot, drain_blk, accB, 0, 0, 0u, 0u);
-    else region(K3{}, NotLast{}, std::false_type{}, std::false_type{}, accA, 0, drain_slot, drain_blk, accB, 0, 0, 0u, 0u);
+    if (drain_blk == S) region(K3{}, NotLast{}, std::false_type{}, std::true_type{}, std::false_type{}, accA, 0, drain_slot, drain_blk, accB, 0, 0, 0u, 0u, 0);
+    else region(K3{}, NotLast{}, std::false_type{}, std::false_type{}, std::false_type{}, accA, 0, drain_slot, drain_blk, accB, 0, 0, 0u, 0u, 0);
 #undef ABX2_REGION
+#undef ABX2_REGION_T
   };
   switch (w & 3) {
     case 0: main_loop(std::integral_constant<int, 0>{}); break;
