@@ -400,6 +400,7 @@ def main():
                     help="N > 1: all-gather + replicated o_proj, or column-sharded o_proj + all-reduce of the [hidden] partials")
     ap.add_argument("--no_graph", action="store_true", help="launch the step directly instead of replaying a captured hipGraph")
     ap.add_argument("--no_extra_configs", action="store_true", help="skip the config 3/4/5 sub-records")
+    ap.add_argument("--no_model32", action="store_true", help="skip the whole-model (32-layer) decode sub-record")
     ap.add_argument("--cpu_sample_len", type=int, default=0, help="positions used for the CPU baseline (0 = full)")
     args = ap.parse_args()
 
@@ -640,6 +641,20 @@ def main():
                 sub["C5_per_gpu_slice"] = bench_c5_slice(max(50, args.steps // 2), dev)
             except Exception as e:                          # noqa: BLE001
                 sub["C5_per_gpu_slice"] = {"error": repr(e)[:200]}
+            if not args.no_model32:
+                # the whole 32-layer model decoding through the latent caches (tools/bench_model.py)
+                try:
+                    torch.cuda.empty_cache()
+                    sys.path.insert(0, os.path.join(ROOT, "tools"))
+                    import bench_model
+                    m32 = bench_model.run(32, rank_k, rank_v, 4, Lp, 16, reps=15, dev=str(dev))
+                    m32["attention_share"] = ("32 x the single-layer decode step above = %.2f ms of the %.2f ms per token "
+                                              "(the rest: RMSNorm / MLP / lm_head through torch)"
+                                              % (32 * us_step * 1e-3, m32.get("graph_ms_per_token", m32["eager_ms_per_token"])))
+                    sub["model32"] = m32
+                except Exception as e:                      # noqa: BLE001
+                    sub["model32"] = {"error": repr(e)[:200]}
+                torch.cuda.empty_cache()
             rec["configs"] = sub
         print(json.dumps(rec), flush=True)
     if dist is not None:

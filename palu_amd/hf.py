@@ -95,8 +95,12 @@ class PaluAttentionHF(nn.Module):
         if q_len == 1:
             # one token attends to the whole cache.  The mask (if any) is passed through as it is: testing it for "all
             # zeros" would be a device-to-host sync per layer and token, and is illegal under graph capture; an all-zero
-            # mask only selects the masked softmax kernel, it changes no result
-            pass
+            # mask only selects the masked softmax kernel, it changes no result.
+            # The token's position is the row its latents are appended at (cache rows ARE absolute positions,
+            # kernel/abx_rope.py:114-150: key position = row index), so the module derives it from the cache length: reading
+            # it out of the device tensor transformers hands over would be a host sync per layer and token (and raises
+            # inside a graph capture).
+            position_ids = None
         elif attention_mask is None:
             is_causal = True               # the model is causal; without a mask tensor the module would apply none (:229)
         else:

@@ -845,7 +845,7 @@ class LlamaPaluAttention(nn.Module):
                 f"Attention mask should be of size {(bsz, 1, q_len, kv_seq_len)}, but is {attention_mask.size()}")
 
         fused_o = self.o_proj.in_features == self.fused_hidden_dim_o
-        hip_step_ok = self.q_proj.bias is None and self.head_dim == 128 and self._hip_step_shapes_ok(past_key_value)
+        hip_step_ok = self.head_dim == 128 and self._hip_step_shapes_ok(past_key_value)      # (biases: _decode_biased)
         if (q_len == 1 and bsz == 1 and isinstance(past_key_value, (LatentCache, QuantLatentCache)) and fused_o
                 and hip_step_ok and hidden_states.is_cuda and hidden_states.dtype == torch.float16
                 and hasattr(self.k_proj, "B")):
