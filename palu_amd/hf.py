@@ -87,11 +87,32 @@ class PaluAttentionHF(nn.Module):
         cache = past_key_values.latent if isinstance(past_key_values, PaluCacheHF) else past_key_values
         q_len = hidden_states.shape[1]
         is_causal = None
-        if attention_mask is not None and attention_mask.dtype == torch.bool:
-            # transformers 5.x (sdpa / create_causal_mask) hands over BOOLEAN masks, True = attend: the module speaks the
-            # reference's additive convention (kernel/palu_attention.py:229-234), so convert first -- a bool mask cast to
-            # fp16 would add +1 to attended positions and mask nothing
-            attention_mask = additive_mask(attention_mask, hidden_states.dtype)
+        orig = attention_mask
+        # One conversion + one "is this the plain causal mask" decision per FORWARD PASS, not per layer: the memo lives on
+        # the cache object and is keyed on the IDENTITY of the mask tensor transformers hands to every layer, which it holds
+        # a reference to (a key made of data_ptr / shape / version could be inherited by a different mask that
+        # the caching allocator placed at the freed address).
+        memo = getattr(past_key_values, "_mask_memo", None)
+        if orig is not None and memo is not None and memo[0] is orig:
+            attention_mask, is_causal = memo[1], memo[2]
+        else:
+            if attention_mask is not None and attention_mask.dtype == torch.bool:
+                # transformers 5.x (sdpa / create_causal_mask) hands over BOOLEAN masks, True = attend: the module speaks the
+                # reference's additive convention (kernel/palu_attention.py:229-234), so convert first -- a bool mask cast
+                # to fp16 would add +1 to attended positions and mask nothing
+                attention_mask = additive_mask(attention_mask, hidden_states.dtype)
+            if q_len > 1 and attention_mask is not None:
+                # a mask tensor may carry padding: decide whether it is the plain causal one (flash kernel) or not (general
+                # path).  The test syncs; a mask whose width is not past + q_len is left to the module's own shape check.
+                past = cache.get_seq_length(self.layer_idx) if cache is not None else 0
+                is_causal = (attention_mask.shape[0] == 1 and attention_mask.shape[-1] == past + q_len
+                             and attention_mask.shape[-2] == q_len
+                             and bool(self.inner._mask_is_causal(attention_mask, q_len, past)))
+            if orig is not None and past_key_values is not None:
+                try:
+                    past_key_values._mask_memo = (orig, attention_mask, is_causal)
+                except AttributeError:
+                    pass
         if q_len == 1:
             # one token attends to the whole cache.  The mask (if any) is passed through as it is: testing it for "all
             # zeros" would be a device-to-host sync per layer and token, and is illegal under graph capture; an all-zero
@@ -101,23 +122,9 @@ class PaluAttentionHF(nn.Module):
             # it out of the device tensor transformers hands over would be a host sync per layer and token (and raises
             # inside a graph capture).
             position_ids = None
+            is_causal = None
         elif attention_mask is None:
             is_causal = True               # the model is causal; without a mask tensor the module would apply none (:229)
-        else:
-            # a mask tensor may carry padding: let the module decide whether it is the plain causal one (flash kernel)
-            # or not (general path).  The test syncs, so it is done once per forward pass, not once per layer.
-            memo = getattr(past_key_values, "_mask_memo", None)
-            key = (attention_mask.data_ptr(), tuple(attention_mask.shape), attention_mask._version)
-            if memo is not None and memo[0] == key:
-                is_causal = memo[1]
-            else:
-                past = cache.get_seq_length(self.layer_idx) if cache is not None else 0
-                is_causal = bool(self.inner._mask_is_causal(attention_mask, q_len, past)) if attention_mask.shape[0] == 1 else False
-                if past_key_values is not None:
-                    try:
-                        past_key_values._mask_memo = (key, is_causal)
-                    except AttributeError:
-                        pass
         out, weights, _ = self.inner(hidden_states, attention_mask=attention_mask, position_ids=position_ids,
                                      past_key_value=cache, output_attentions=bool(kwargs.get("output_attentions", False)),
                                      is_causal=is_causal)

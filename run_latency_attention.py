@@ -62,6 +62,15 @@ class _DenseAttention(nn.Module):
         self.k_proj = nn.Linear(d, d, bias=False)
         self.v_proj = nn.Linear(d, d, bias=False)
         self.o_proj = nn.Linear(d, d, bias=False)
+        self._inv_freq = {}          # per device: the fp32 inverse frequencies, built once (no host work inside a step)
+
+    def _inv(self, device):
+        t = self._inv_freq.get(device)
+        if t is None:
+            D = self.head_dim
+            t = (1.0 / (self.rope_theta ** (torch.arange(0, D, 2, dtype=torch.int64).float() / D))).to(device)
+            self._inv_freq[device] = t
+        return t
 
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None,
                 output_attentions=False, **kwargs):
@@ -72,9 +81,11 @@ class _DenseAttention(nn.Module):
         v = self.v_proj(hidden_states).view(bsz, q_len, H, D).transpose(1, 2)
         past = 0 if past_key_value is None else past_key_value.get_usable_length(q_len, self.layer_idx)
         if position_ids is None:
-            position_ids = torch.arange(past, past + q_len)
-        inv = 1.0 / (self.rope_theta ** (torch.arange(0, D, 2, dtype=torch.int64).float() / D))
-        ang = torch.outer(position_ids.reshape(-1).float(), inv).to(hidden_states.device)
+            position_ids = torch.arange(past, past + q_len, device=hidden_states.device)
+        # angles on the device from a cached table: no CPU arithmetic and no blocking pageable copy per step (ADVICE r3;
+        # such a copy is also illegal inside a graph capture).  Callers hand over device-resident position_ids.
+        ang = torch.outer(position_ids.reshape(-1).to(hidden_states.device, non_blocking=True).float(),
+                          self._inv(hidden_states.device))
         emb = torch.cat((ang, ang), dim=-1)
         cos, sin = emb.cos().to(q.dtype), emb.sin().to(q.dtype)
 
@@ -157,6 +168,10 @@ def profile_tpot(model, cache_size_k, cache_size_v, cache_type=torch.float16, ba
             past_key_value.advance(0, t)
     del cache_k, cache_v
     position_ids = torch.arange(prompt_len, prompt_len + 1)
+    if isinstance(model, _DenseAttention):
+        # the dense leg builds its rotary angles on the device: hand the position over once, outside the timed / captured
+        # region (the Palu module reads it on the host: a CPU tensor costs it nothing)
+        position_ids = position_ids.to(device)
     input_token = torch.randn((batch_size, 1, hidden_dim), dtype=torch.float16, device=device)
 
     s = torch.cuda.Stream()

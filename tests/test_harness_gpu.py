@@ -30,6 +30,8 @@ def test_attention_harness_palu_and_dense_legs():
     base = [sys.executable, "run_latency_attention.py", "--prompt_len", "4096", "--repeats", "10", "--json"]
     palu = _run(base + ["--palu", "--fast_init", "--rank_k", "1024", "--rank_v", "3072", "--group_size", "4", "--cache_graph"])
     dense = _run(base)
+    dense_graph = _run(base + ["--cache_graph"])        # the dense leg must survive a graph capture too
+    assert LINE.search(dense_graph)
     for out in (palu, dense):
         m = LINE.search(out)
         assert m and int(m.group(1)) == 4096 and float(m.group(2)) > 0
