@@ -398,6 +398,10 @@ def main():
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--oproj", choices=("replicated", "sharded"), default="sharded",
                     help="N > 1: all-gather + replicated o_proj, or column-sharded o_proj + all-reduce of the [hidden] partials")
+    ap.add_argument("--exchange", choices=("rccl", "p2p"), default="rccl",
+                    help="N > 1: the step's one collective through RCCL (torch.distributed) or through the one-shot "
+                         "peer-to-peer exchange kernel over hipIpc buffers (csrc/exchange.hip); the other one is timed alone "
+                         "and reported beside it")
     ap.add_argument("--no_graph", action="store_true", help="launch the step directly instead of replaying a captured hipGraph")
     ap.add_argument("--no_extra_configs", action="store_true", help="skip the config 3/4/5 sub-records")
     ap.add_argument("--no_model32", action="store_true", help="skip the whole-model (32-layer) decode sub-record")
@@ -439,7 +443,18 @@ def main():
     k_cache = torch.randn(Gl, cap, Rk, device=dev, dtype=torch.float16)       # run_latency_attention.py:62-63
     v_cache = torch.randn(Gl, cap, Rv, device=dev, dtype=torch.float16)
     hidden = torch.randn(HIDDEN, device=dev, dtype=torch.float16)             # :70
-    dec = hp.HeadParallelDecoder(plan, w, k_cache, v_cache, HIDDEN)
+    p2p = None
+    if world > 1:
+        try:
+            p2p = hp.IpcExchange(rank, world, max(HIDDEN * 4, plan.heads_local * Rv * 2), dev)
+        except Exception as e:                                  # noqa: BLE001 -- e.g. IPC not available between these devices
+            print("bench.py[rank %d]: peer-to-peer exchange unavailable (%s)" % (rank, repr(e)[:200]), file=sys.stderr)
+        if args.exchange == "p2p":
+            okt = torch.tensor([1 if p2p is not None else 0], device=dev)
+            dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+            if not int(okt.item()):
+                raise SystemExit("--exchange p2p: the exchange could not be set up on every rank")
+    dec = hp.HeadParallelDecoder(plan, w, k_cache, v_cache, HIDDEN, exchange=p2p if args.exchange == "p2p" else None)
 
     def sync():
         torch.cuda.synchronize()
@@ -500,6 +515,31 @@ def main():
         tc = torch.tensor([sorted(ts)[len(ts) // 2]], device=dev)
         dist.all_reduce(tc, op=dist.ReduceOp.MAX)
         coll_us = float(tc.item())
+        # the other exchange on the step's message, alone: 200 back-to-back collectives between events (max over ranks)
+        other_us, other_name = None, ("p2p" if args.exchange == "rccl" else "rccl")
+        other = p2p if args.exchange == "rccl" else hp.DistExchange(None)
+        okt = torch.tensor([1 if other is not None else 0], device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if int(okt.item()):
+            if dec.oproj_sharded:
+                buf = torch.zeros(HIDDEN, dtype=torch.float32, device=dev)
+                coll = lambda: other.all_reduce_sum_(buf)
+            else:
+                src = torch.zeros(plan.heads_local * Rv, dtype=torch.float16, device=dev)
+                dst = torch.empty(H * Rv, dtype=torch.float16, device=dev)
+                coll = lambda: other.all_gather_into(dst, src)
+            for _ in range(20):
+                coll()
+            sync()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(200):
+                coll()
+            e1.record()
+            torch.cuda.synchronize()
+            to = torch.tensor([e0.elapsed_time(e1) * 1e3 / 200], device=dev)
+            dist.all_reduce(to, op=dist.ReduceOp.MAX)
+            other_us = float(to.item())
 
     rec = None
     if rank == 0:
@@ -556,7 +596,7 @@ def main():
                                    "geometry as built by run_latency_attention.py (LlamaConfig() defaults): "
                                    "H=32 D=128 hidden=4096 gs=4 G=8 rank_k=%d rank_v=%d prompt_len=%d fp16 latents batch=1"
                                    % (rank_k, rank_v, Lp),
-                       "parallelism": ("head-group x%d + RCCL %s" % (world, "all-gather, replicated o_proj" if args.oproj == "replicated"
+                       "parallelism": ("head-group x%d + %s %s" % (world, "RCCL" if args.exchange == "rccl" else "one-shot P2P exchange", "all-gather, replicated o_proj" if args.oproj == "replicated"
                                                                        else "column-sharded o_proj + all-reduce of [hidden] fp32"))
                        if world > 1 else "single GPU",
                        "kernels_per_step": 5 if world == 1 else 6,
@@ -570,6 +610,11 @@ def main():
             "host_wall_us": ab[best]["host_wall_us"],
             "p20_us": ab[best]["device_us_p20"], "p80_us": ab[best]["device_us_p80"],
             "collective_us": None if coll_us is None else round(coll_us, 2),
+            "collective": None if world == 1 else {
+                "in_step": args.exchange, "in_step_us": round(coll_us, 2), "alone_back_to_back": other_name,
+                "alone_back_to_back_us": None if other_us is None else round(other_us, 2),
+                "message": ("all-reduce of [hidden] fp32 (16 KiB)" if dec.oproj_sharded else
+                            "all-gather of [H/N * Rv] fp16 slices (%d B per rank)" % (plan.heads_local * Rv * 2))},
             "step_algorithmic_bytes": step_b,
             "step_hbm_GBps": round(step_b / us_step * 1e-3, 1),
             "step_hbm_frac": round(step_b / us_step * 1e-3 / HBM_PEAK_GBPS, 4),

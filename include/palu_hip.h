@@ -359,6 +359,32 @@ int palu_prefill_attn_f16(const void* q, int64_t sq_h, int64_t sq_t, const void*
                           int D, int Tq, int Tk, int Rv, int past, int causal, float scale,
                           palu_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * One-shot peer-to-peer exchange for the head-group-parallel decode step (the reference is single-GPU and
+ * has no collective).  The step's one collective moves 3 KiB (all-gather of a rank's context slice) or 16 KiB (all-reduce
+ * of the [hidden] fp32 partials) per rank: one kernel per rank writes its slice straight into every peer's exchange
+ * buffer, raises a flag there, waits for the peers' flags in its own buffer (bounded spin) and copies / sums the slots.
+ * Setup (allocates, synchronises -- NOT part of a step): every rank allocates a buffer of palu_exchange_bytes(nranks,
+ * slot_bytes), exports a handle (palu_exchange_handle_bytes() host bytes) that the other ranks import (hipIpc*; within one
+ * process the pointer itself is used), and uploads the n base pointers, own included and in rank order, as a device array.
+ * Steps (capturable, no allocation, no host sync): palu_exchange_allgather (out [nranks][bytes]) /
+ * palu_exchange_allreduce_f32 (out [bytes], the fp32 sum in rank order: identical on every rank).  Every rank must issue the
+ * same sequence of exchanges on a buffer.  palu_exchange_status reads the buffer's control words after a synchronisation:
+ * exchanges done and the epoch of a wait that timed out (0 = none; a peer that never arrives becomes an error, not a hang).
+ */
+size_t palu_exchange_bytes(int nranks, size_t slot_bytes);
+int palu_exchange_alloc(size_t bytes, void** ptr);
+int palu_exchange_free(void* ptr);
+size_t palu_exchange_handle_bytes(void);
+int palu_exchange_export(void* ptr, void* handle_out_host);
+int palu_exchange_import(const void* handle_host, void** ptr_out);
+int palu_exchange_close(void* imported_ptr);
+int palu_exchange_allgather(const void* src, size_t bytes, const void* peers_dev, int rank, int nranks, size_t slot_bytes,
+                            void* out, palu_stream_t stream);
+int palu_exchange_allreduce_f32(const void* src, size_t bytes, const void* peers_dev, int rank, int nranks,
+                                size_t slot_bytes, void* out, palu_stream_t stream);
+int palu_exchange_status(const void* buffer, unsigned* epoch_host, unsigned* error_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,6 +91,16 @@ SIGNATURES = {
     "palu_pack_codes": (i32, [vp, vp, i64, i32, vp]),
     "palu_unpack_codes": (i32, [vp, vp, i64, i32, vp]),
     "palu_hadamard_transform": (i32, [vp, vp, i64, i32, f32, i32, vp]),
+    "palu_exchange_bytes": (sz, [i32, sz]),
+    "palu_exchange_alloc": (i32, [sz, C.POINTER(C.c_void_p)]),
+    "palu_exchange_free": (i32, [vp]),
+    "palu_exchange_handle_bytes": (sz, []),
+    "palu_exchange_export": (i32, [vp, vp]),
+    "palu_exchange_import": (i32, [vp, C.POINTER(C.c_void_p)]),
+    "palu_exchange_close": (i32, [vp]),
+    "palu_exchange_allgather": (i32, [vp, sz, vp, i32, i32, sz, vp, vp]),
+    "palu_exchange_allreduce_f32": (i32, [vp, sz, vp, i32, i32, sz, vp, vp]),
+    "palu_exchange_status": (i32, [vp, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
     "palu_decode_workspace_bytes": (sz, [i32, i32, i32, i32, i32]),
     "palu_decode_attend_f16": (i32, [vp, vp, i64, vp, i64, vp, i64, vp, vp, i64, i64, vp, i64, i64, vp, vp, vp, vp,
                                      i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),

@@ -131,6 +131,87 @@ class DistExchange:
         dist.all_gather_into_tensor(out, t, group=self.group)
 
 
+class IpcExchange:
+    """The step's collective as ONE kernel per rank writing straight into every peer's buffer (csrc/exchange.hip,
+    include/palu_hip.h: palu_exchange_*): no ring, no host involvement, capturable.  For the 3 KiB / 16 KiB messages of the
+    head-parallel step a collective library's small-message latency is the cost; this is the one-shot alternative over
+    the same xGMI links.  Setup exchanges hipIpc handles through `group` (any torch.distributed backend: only
+    `all_gather_object` is used) -- or takes the peers' pointers directly when all ranks live in one process (`peers=`).
+
+    slot_bytes: the largest message (bytes) this exchange will carry, rounded up to 16."""
+
+    def __init__(self, rank: int, world: int, slot_bytes: int, device, group=None, peers=None):
+        import ctypes as C
+        from .. import _lib
+        self._lib, self.rank, self.world = _lib, rank, world
+        self.slot = (int(slot_bytes) + 15) // 16 * 16
+        self.device = torch.device(device)
+        self._imported = []
+        with torch.cuda.device(self.device):
+            nbytes = _lib.lib.palu_exchange_bytes(world, self.slot)
+            if not nbytes:
+                raise ValueError(f"IpcExchange: unsupported world {world} / slot {self.slot}")
+            ptr = C.c_void_p()
+            _lib.check(_lib.lib.palu_exchange_alloc(nbytes, C.byref(ptr)), "palu_exchange_alloc")
+            self.buffer = ptr.value
+            if peers is None:
+                import torch.distributed as dist
+                hb = _lib.lib.palu_exchange_handle_bytes()
+                h = C.create_string_buffer(hb)
+                _lib.check(_lib.lib.palu_exchange_export(self.buffer, h), "palu_exchange_export")
+                handles = [None] * world
+                dist.all_gather_object(handles, bytes(h.raw), group=group)
+                peers = []
+                for r in range(world):
+                    if r == rank:
+                        peers.append(self.buffer)
+                        continue
+                    q = C.c_void_p()
+                    _lib.check(_lib.lib.palu_exchange_import(C.create_string_buffer(handles[r], hb), C.byref(q)),
+                               "palu_exchange_import")
+                    self._imported.append(q.value)
+                    peers.append(q.value)
+            else:
+                peers = list(peers)
+                peers[rank] = self.buffer
+            self.peers = torch.tensor(peers, dtype=torch.int64, device=self.device)
+
+    def set_peers(self, peers) -> None:
+        """single-process use: fill in the other ranks' buffer pointers once every rank has allocated"""
+        self.peers = torch.tensor(list(peers), dtype=torch.int64, device=self.device)
+
+    def all_gather_into(self, out: torch.Tensor, t: torch.Tensor) -> None:
+        nb = t.numel() * t.element_size()
+        assert out.numel() * out.element_size() == nb * self.world and t.is_contiguous() and out.is_contiguous()
+        self._lib.check(self._lib.lib.palu_exchange_allgather(t.data_ptr(), nb, self.peers.data_ptr(), self.rank, self.world,
+                                                             self.slot, out.data_ptr(), self._lib.current_stream(self.device)),
+                        "palu_exchange_allgather")
+
+    def all_reduce_sum_(self, t: torch.Tensor) -> None:
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        nb = t.numel() * 4
+        self._lib.check(self._lib.lib.palu_exchange_allreduce_f32(t.data_ptr(), nb, self.peers.data_ptr(), self.rank,
+                                                                 self.world, self.slot, t.data_ptr(),
+                                                                 self._lib.current_stream(self.device)),
+                        "palu_exchange_allreduce_f32")
+
+    def status(self):
+        """(exchanges done, epoch of a timed-out wait or 0) -- synchronises"""
+        import ctypes as C
+        e, err = C.c_uint(), C.c_uint()
+        torch.cuda.synchronize(self.device)
+        self._lib.check(self._lib.lib.palu_exchange_status(self.buffer, C.byref(e), C.byref(err)), "palu_exchange_status")
+        return e.value, err.value
+
+    def close(self) -> None:
+        for q in self._imported:
+            self._lib.lib.palu_exchange_close(q)
+        self._imported = []
+        if self.buffer:
+            self._lib.lib.palu_exchange_free(self.buffer)
+            self.buffer = None
+
+
 class LocalExchange:
     """In-process stand-in for the collective: several ranks' decoders living on ONE device and stepped on one stream
     (tests, tools/hp_two_ranks_one_gpu.py).  Plain device ops, so a captured graph contains the exchange.  Protocol: every

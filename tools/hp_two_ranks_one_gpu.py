@@ -35,7 +35,7 @@ def build(world, rank, dev):
     return hp.HeadParallelDecoder(plan, w, kc.contiguous(), vc.contiguous(), HIDDEN), hidden
 
 
-def worker(rank, world, port, q, oproj):
+def worker(rank, world, port, q, oproj, p2p=False):
     global OPROJ
     OPROJ = oproj
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -43,6 +43,37 @@ def worker(rank, world, port, q, oproj):
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     dec, hidden = build(world, rank, dev)
+    if p2p:
+        # the step's collective as the one-shot peer-to-peer exchange kernel (csrc/exchange.hip) between the two PROCESSES:
+        # eager step, then the same step captured into one hipGraph (kernels + exchange) and replayed
+        from palu_amd.kernel import head_parallel as hp
+        ex = hp.IpcExchange(rank, world, max(HIDDEN * 4, dec.plan.heads_local * dec.plan.rank_v * 2), dev)
+        dec.exchange = ex
+        out = dec.step(hidden, LP, LP).float().cpu()
+        torch.cuda.synchronize()
+        dist.barrier()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            dec.step(hidden, LP, LP)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        dist.barrier()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            o2 = dec.step(hidden, LP, LP)
+        for _ in range(3):
+            g.replay()
+            torch.cuda.synchronize()
+            dist.barrier()
+        rep = o2.float().cpu()
+        done, err = ex.status()
+        if rank == 0:
+            q.put((out, rep, err))
+        dist.barrier()
+        ex.close()
+        dist.destroy_process_group()
+        return
     # gloo moves host tensors: wrap the one collective
     orig = dist.all_gather_into_tensor
 
@@ -67,14 +98,14 @@ def worker(rank, world, port, q, oproj):
     dist.destroy_process_group()
 
 
-def run_world2(oproj):
+def run_world2(oproj, p2p=False):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=worker, args=(r, 2, port, q, oproj)) for r in range(2)]
+    procs = [ctx.Process(target=worker, args=(r, 2, port, q, oproj, p2p)) for r in range(2)]
     for p in procs:
         p.start()
     sharded = q.get(timeout=300)
@@ -92,6 +123,11 @@ def main():
         err = (sharded - ref).abs().max().item()
         print(f"world 2 on one GPU ({oproj} o_proj) vs unsharded: max|diff| = {err:.3e} (scale {ref.abs().max().item():.3e})")
         ok &= err <= 1e-3 * max(1.0, ref.abs().max().item())
+        eager, replay, terr = run_world2(oproj, p2p=True)
+        e1, e2 = (eager - ref).abs().max().item(), (replay - ref).abs().max().item()
+        print(f"world 2 on one GPU ({oproj} o_proj), one-shot P2P exchange between the processes: eager max|diff| = {e1:.3e}, "
+              f"graph replay {e2:.3e}, timeout word {terr}")
+        ok &= max(e1, e2) <= 1e-3 * max(1.0, ref.abs().max().item()) and terr == 0
     sys.exit(0 if ok else 1)
 
 
