@@ -358,6 +358,73 @@ def bench_shared_b(rank_k, rank_v, Lp, steps, dev):
                                        "hbm_frac": round(ab_b / kus * 1e-3 / HBM_PEAK_GBPS, 4)}}}
 
 
+def bench_prefill(rank_k, rank_v, T, dev):
+    """the prompt pass of ONE attention module (LlamaPaluAttention.forward, q_len = T, empty cache) through
+    the flash-style prefill kernel -- ms and peak transient memory (above weights, input, output and the cache) for the
+    one-launch form (K~ of every head, V^T of every group, every context row at once: the default up to 6 GiB of transients)
+    and the bounded-workspace form (query chunks x latent groups), fp16 and packed 4-bit caches."""
+    from torch import nn
+    from palu_amd.kernel.palu_attention import LatentCache, LlamaPaluAttention, QuantLatentCache, build_b
+
+    class Cfg:
+        pass
+    cfg = Cfg()
+    cfg.hidden_size, cfg.num_attention_heads, cfg.attention_bias = HIDDEN, H, False
+    cfg.group_size, cfg.num_groups, cfg.total_rank_k, cfg.total_rank_v = GS, G, rank_k, rank_v
+    torch.manual_seed(0)
+    with torch.device(dev):
+        m = LlamaPaluAttention(cfg, 0).half()
+        with torch.no_grad():
+            for lin in (m.q_proj, m.k_proj.VT, m.v_proj.VT, m.o_proj):
+                lin.weight.normal_(0.0, 0.02)
+            for u in m.k_proj.U_list:
+                u.weight.normal_(0.0, (rank_k // G) ** -0.5)
+        m.k_proj.B = nn.Parameter(build_b([u.weight for u in m.k_proj.U_list], GS, D))
+    m = m.eval().prepare_decode()
+    x = torch.randn(1, T, HIDDEN, device=dev, dtype=torch.float16)
+    rec = {"workload": "prompt pass of one attention module, %d tokens, rank_k=%d rank_v=%d gs=%d, causal" % (T, rank_k, rank_v, GS)}
+    for tag, bits, budget in (("fp16_cache", 16, None), ("fp16_cache_bounded_workspace", 16, 0), ("packed_4bit_cache", 4, None),
+                              ("packed_4bit_cache_bounded_workspace", 4, 0)):
+        mk = (lambda: LatentCache(capacity=T + 512)) if bits >= 16 else (lambda: QuantLatentCache(bits, capacity=T + 512))
+        if budget is not None:
+            m.PREFILL_WORKSPACE_BUDGET = budget
+        try:
+            with torch.no_grad():
+                def fresh():
+                    c = mk()
+                    if bits >= 16:
+                        c.reserve(0, T + 512, torch.empty((1, G, 0, rank_k // G), dtype=torch.float16, device=dev),
+                                  torch.empty((1, G, 0, rank_v // G), dtype=torch.float16, device=dev))
+                    else:
+                        c.reserve(0, T + 512, G, rank_k // G, rank_v // G, x.device)
+                    return c
+                c = fresh()
+                out, _, _ = m(x, past_key_value=c, is_causal=True)      # untimed: the caching allocator gets its blocks
+                del out, c
+                ts, extra = [], 0
+                for _ in range(2):
+                    c = fresh()
+                    torch.cuda.synchronize()
+                    torch.cuda.reset_peak_memory_stats()
+                    base = torch.cuda.memory_allocated()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    out, _, _ = m(x, past_key_value=c, is_causal=True)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    extra = torch.cuda.max_memory_allocated() - base - out.numel() * 2
+                    ts.append(e0.elapsed_time(e1))
+                    del out, c
+                ms = min(ts)
+                rec[tag] = {"ms": round(ms, 2), "transient_MiB": round(extra / 2 ** 20, 1),
+                            "causal_TFLOPs": round((2.0 * H * T * T / 2 * (D + rank_v // G)) / (ms * 1e-3) * 1e-12, 1)}
+        finally:
+            if budget is not None:
+                del m.PREFILL_WORKSPACE_BUDGET
+        torch.cuda.empty_cache()
+    return rec
+
+
 def bench_c5_slice(steps, dev):
     """BASELINE config 5, what ONE of the 8 GPUs runs per step: its latent group (G=1, H=4) of the rank 1024/3072 model at
     prompt_len 256k -- qkv for its heads, attention core (the fused single-kernel path is selected for G=1), no o_proj
@@ -686,6 +753,11 @@ def main():
                 sub["C5_per_gpu_slice"] = bench_c5_slice(max(50, args.steps // 2), dev)
             except Exception as e:                          # noqa: BLE001
                 sub["C5_per_gpu_slice"] = {"error": repr(e)[:200]}
+            try:
+                sub["prefill_64k"] = bench_prefill(rank_k, rank_v, Lp, dev)
+            except Exception as e:                          # noqa: BLE001
+                sub["prefill_64k"] = {"error": repr(e)[:200]}
+            torch.cuda.empty_cache()
             if not args.no_model32:
                 # the whole 32-layer model decoding through the latent caches (tools/bench_model.py)
                 try:

@@ -704,65 +704,139 @@ class LlamaPaluAttention(nn.Module):
         above = j > i
         return bool(((m <= -1e4) == above).all()) and bool((m.masked_fill(above, 0) == 0).all())
 
+    # bytes of transient prefill workspace above which the prompt pass runs in query chunks x latent groups.  Below it: one
+    # kernel launch for all heads and queries, the fastest form (a 64k-token prompt at the config-2 ranks needs 2.9 GiB of
+    # transients that way -- 1 % of this GPU's HBM -- and runs 1.9x faster than in 128-workgroup slices).  Both are class
+    # attributes: a deployment that is short of memory lowers the budget.
+    PREFILL_WORKSPACE_BUDGET = 6 << 30
+    PREFILL_QUERY_CHUNK = 8192
+
     def _prefill_flash(self, hidden_states, pos, cache, causal: bool):
         """Prompt branch (:196-257) on the flash-style HIP kernel: scores are never materialised.
 
-        q and the latents are projected (latents straight into the cache rows), keys are rebuilt once as
-        K~ = RoPE(X_k . B) [H, kv, D] (a transient workspace: O(kv), not O(kv^2)), the latent values are handed to
-        the kernel transposed ([G, Rv, kv], zero-padded to 64) and P.V stays in the latent space."""
+        q and the latents are projected (latents straight into the cache rows, or quantised + packed chunk by chunk), the
+        keys of ONE latent group at a time are rebuilt as K~ = RoPE(X_k . B) [gs, kv, D] and its latent values handed to the
+        kernel transposed ([Rv, kv], zero-padded to 64); P.V stays in the latent space.  Long prompts run in query chunks:
+        every transient -- K~ and V^T of one group, the context rows of one chunk, for packed caches the dequantised rows
+        of one group -- is O(kv * gs * D) or O(chunk * H * Rv), never O(kv * H * D); rebuilding a group's K~ per chunk
+        costs 1 MFLOP per cached position and chunk, a few percent of the attention itself."""
         H, G, D, gs = self.num_heads, self.num_groups, self.head_dim, self.group_size
+        Rk, Rv = self.group_rank_k, self.group_rank_v
         q_len = hidden_states.shape[1]
-        past = cache.get_seq_length(self.layer_idx)
+        li = self.layer_idx
+        past = cache.get_seq_length(li)
         dev, dt = hidden_states.device, hidden_states.dtype
-        q = self.q_proj(hidden_states).view(q_len, H, D).transpose(0, 1)                  # [H,T,D] view of [T, H*D]
-        if isinstance(cache, LatentCache):
-            key_h, val_h = self._project_into_cache(hidden_states, cache)                 # [1,G,kv,R] views
-        else:
-            # packed 3/4-bit cache: quantise + pack the new rows, attend over the de-quantised values
-            # (the accuracy path's fake-quant semantics, svd_linear.py:84-90,124-139)
-            key_h = self.k_proj.project_to_latent(hidden_states).view(1, q_len, G, self.group_rank_k).transpose(1, 2)
-            val_h = self.v_proj.project_to_latent(hidden_states).view(1, q_len, G, self.group_rank_v).transpose(1, 2)
-            key_h, val_h = cache.update(key_h, val_h, self.layer_idx)
-        kv = past + q_len
+        kv_all = past + q_len
+        # what the one-launch form would allocate: K~ for every head, V^T of every group, the context rows
+        one_launch_bytes = 2 * (H * kv_all * D + G * Rv * (kv_all + 63) + q_len * H * Rv)
+        packed = not isinstance(cache, LatentCache)
+        if packed:
+            one_launch_bytes += 2 * kv_all * G * (Rk + Rv)          # the dequantised rows
+        grouped = one_launch_bytes > self.PREFILL_WORKSPACE_BUDGET
+        qc = self.PREFILL_QUERY_CHUNK if grouped else q_len
         inv = rope_inv_freq(dev, D, self.rope_theta)
         stream = _lib.current_stream()
-        p0 = int(pos.reshape(-1)[0])
-        contiguous_pos = bool((pos.reshape(-1) == torch.arange(p0, p0 + q_len, device=pos.device)).all())
-        if contiguous_pos and q.stride(2) == 1:
-            _lib.check(_lib.lib.palu_rope_f16(q.data_ptr(), q.stride(0), q.stride(1), H, q_len, D, p0, inv.data_ptr(), stream),
-                       "palu_rope_f16")
-        else:
-            cos, sin = self._rope_tables(pos.reshape(-1), dt)
-            q = (q * cos.view(1, q_len, D) + _rotate_half(q) * sin.view(1, q_len, D)).contiguous()
-        # K~ = RoPE(X_k . B): per group the reconstruct GEMM X_g . U_g^T (:67-77, :199-201) lands head-major in the
-        # [H, kv, D] workspace, then the rotation runs in place
-        u_ok = (self.n_rep == 1 and self.group_rank_k % 64 == 0
+        pos = pos.reshape(-1)
+        p0 = int(pos[0])
+        contiguous_pos = bool((pos == torch.arange(p0, p0 + q_len, device=pos.device)).all())
+        u_ok = (self.n_rep == 1 and Rk % 64 == 0
                 and all(u.weight.dtype == dt and u.weight.is_contiguous() and u.bias is None for u in self.k_proj.U_list))
-        if u_ok:
-            keys = torch.empty((H, kv, D), dtype=dt, device=dev)
-            xk = key_h[0]
-            for gi_, u in enumerate(self.k_proj.U_list):
-                xg = xk[gi_]
-                _lib.check(_lib.lib.palu_lowrank_project_gemm(xg.data_ptr(), xg.stride(0), u.weight.data_ptr(), u.weight.stride(0),
-                                                              keys[gi_ * gs].data_ptr(), keys.stride(0), keys.stride(1), kv,
-                                                              gs * D, self.group_rank_k, D, 0, stream), "palu_lowrank_project_gemm")
-            _lib.check(_lib.lib.palu_rope_f16(keys.data_ptr(), keys.stride(0), keys.stride(1), H, kv, D, 0, inv.data_ptr(), stream),
-                       "palu_rope_f16")
-        else:
-            kc, ks = self._rope_tables(torch.arange(kv, device=dev), dt)
-            b = self.k_proj.B.view(G, gs, self.group_rank_k, D)
-            keys = torch.matmul(key_h[0].unsqueeze(1), b).view(H, kv, D)                   # K = X_k . B  (:199-201)
-            keys = (keys * kc.view(1, kv, D) + _rotate_half(keys) * ks.view(1, kv, D)).contiguous()
-        kv_pad = (kv + 63) // 64 * 64
-        vt = torch.zeros((G, self.group_rank_v, kv_pad), dtype=dt, device=dev)
-        vt[:, :, :kv].copy_(val_h[0].transpose(1, 2))
-        ctx = torch.empty((q_len, H * self.group_rank_v), dtype=dt, device=dev)
-        _lib.check(_lib.lib.palu_prefill_attn_f16(q.data_ptr(), q.stride(0), q.stride(1), keys.data_ptr(), keys.stride(0),
-                                                  keys.stride(1), vt.data_ptr(), vt.stride(0), vt.stride(1),
-                                                  ctx.data_ptr(), ctx.stride(0), H, G, D, q_len, kv, self.group_rank_v,
-                                                  past, 1 if causal else 0, 1.0 / math.sqrt(D), stream),
-                   "palu_prefill_attn_f16")
-        return self.o_proj(ctx).view(1, q_len, -1)
+        out = None
+        for c0 in range(0, q_len, qc):
+            c1 = min(q_len, c0 + qc)
+            t = c1 - c0
+            hs = hidden_states[:, c0:c1]
+            q = self.q_proj(hs).view(t, H, D).transpose(0, 1)                             # [H,t,D] view of [t, H*D]
+            if not packed:
+                self._project_into_cache(hs, cache)                                       # latents straight into the rows
+            else:
+                # packed 3/4-bit cache: quantise + pack this chunk's rows; attention runs over the de-quantised values
+                # (the accuracy path's fake-quant semantics, svd_linear.py:84-90,124-139)
+                kh = self.k_proj.project_to_latent(hs).view(1, t, G, Rk).transpose(1, 2)
+                vh = self.v_proj.project_to_latent(hs).view(1, t, G, Rv).transpose(1, 2)
+                cache.append_rows(kh, vh, li)
+                del kh, vh
+            kv = past + c1
+            if contiguous_pos and q.stride(2) == 1:
+                _lib.check(_lib.lib.palu_rope_f16(q.data_ptr(), q.stride(0), q.stride(1), H, t, D, p0 + c0, inv.data_ptr(),
+                                                  stream), "palu_rope_f16")
+            else:
+                cos, sin = self._rope_tables(pos[c0:c1], dt)
+                q = (q * cos.view(1, t, D) + _rotate_half(q) * sin.view(1, t, D)).contiguous()
+            kv_pad = (kv + 63) // 64 * 64
+            ctx = torch.empty((t, H * Rv), dtype=dt, device=dev)
+            if not grouped:
+                groups = [list(range(G))]
+            else:
+                # enough latent groups per launch for >= 512 workgroups (2 per CU): one workgroup = 128 queries of one head
+                per_group = gs * ((t + 127) // 128)
+                ngl = max(1, min(G, (512 + per_group - 1) // per_group))
+                groups = [list(range(g, min(G, g + ngl))) for g in range(0, G, ngl)]
+            for gl in groups:
+                ng = len(gl)
+                g0 = gl[0]
+                xk, xv = self._latent_rows(cache, g0, ng, kv)                             # [ng, kv, Rk], [ng, kv, Rv] fp16
+                keys = torch.empty((ng * gs, kv, D), dtype=dt, device=dev)
+                if u_ok:
+                    # per group the reconstruct GEMM X_g . U_g^T (:67-77, :199-201) lands head-major, then the rotation
+                    # runs in place
+                    for j, g in enumerate(gl):
+                        u = self.k_proj.U_list[g]
+                        xg = xk[j]
+                        _lib.check(_lib.lib.palu_lowrank_project_gemm(xg.data_ptr(), xg.stride(0), u.weight.data_ptr(),
+                                                                      u.weight.stride(0), keys[j * gs].data_ptr(), keys.stride(0),
+                                                                      keys.stride(1), kv, gs * D, Rk, D, 0, stream),
+                                   "palu_lowrank_project_gemm")
+                    _lib.check(_lib.lib.palu_rope_f16(keys.data_ptr(), keys.stride(0), keys.stride(1), ng * gs, kv, D, 0,
+                                                      inv.data_ptr(), stream), "palu_rope_f16")
+                else:
+                    kc, ks = self._rope_tables(torch.arange(kv, device=dev), dt)
+                    b = self.k_proj.B.view(G, gs, Rk, D)[g0:g0 + ng]
+                    kk = torch.matmul(xk.unsqueeze(1), b).view(ng * gs, kv, D)            # K = X_k . B  (:199-201)
+                    keys.copy_(kk * kc.view(1, kv, D) + _rotate_half(kk) * ks.view(1, kv, D))
+                    del kk
+                vt = torch.zeros((ng, Rv, kv_pad), dtype=dt, device=dev)
+                vt[:, :, :kv].copy_(xv.transpose(1, 2))
+                del xk, xv
+                qg = q[g0 * gs:(g0 + ng) * gs]
+                cg = ctx[:, g0 * gs * Rv:]
+                _lib.check(_lib.lib.palu_prefill_attn_f16(qg.data_ptr(), qg.stride(0), qg.stride(1), keys.data_ptr(),
+                                                          keys.stride(0), keys.stride(1), vt.data_ptr(), vt.stride(0),
+                                                          vt.stride(1), cg.data_ptr(), ctx.stride(0), ng * gs, ng, D, t, kv,
+                                                          Rv, past + c0, 1 if causal else 0, 1.0 / math.sqrt(D), stream),
+                           "palu_prefill_attn_f16")
+                del keys, vt
+            o = self.o_proj(ctx)
+            del ctx, q
+            if c0 == 0 and c1 == q_len:
+                out = o
+            else:
+                if out is None:
+                    out = torch.empty((q_len, o.shape[-1]), dtype=o.dtype, device=dev)
+                out[c0:c1].copy_(o)
+            del o
+        return out.view(1, q_len, -1)
+
+    def _latent_rows(self, cache, g0: int, ng: int, kv: int):
+        """fp16 latent rows [ng, kv, R] of groups g0..g0+ng-1: views of an fp16 cache, de-quantised copies (of these groups
+        only) of a packed one."""
+        li = self.layer_idx
+        if isinstance(cache, LatentCache):
+            kbuf, vbuf = cache.buffers(li)
+            return kbuf[0, g0:g0 + ng, :kv], vbuf[0, g0:g0 + ng, :kv]
+        from .quant import unpack_dequant
+        st = cache.buffers(li)
+        gsz = cache.group_size
+
+        def deq(codes, meta, R):
+            c, m = codes[0, g0:g0 + ng, :kv], meta[0, g0:g0 + ng, :kv]
+            if not gsz:
+                return unpack_dequant(c.contiguous(), m.contiguous(), cache.n_bits, R)
+            nb = gsz * cache.n_bits // 8
+            x = unpack_dequant(c.reshape(ng, kv, R // gsz, nb).contiguous(), m.reshape(ng, kv, R // gsz, 2).contiguous(),
+                               cache.n_bits, gsz)
+            return x.reshape(ng, kv, R)
+        return deq(st["kc"], st["km"], self.group_rank_k), deq(st["vc"], st["vm"], self.group_rank_v)
 
     @torch.no_grad()
     def fuse_hadamard(self):

@@ -8,6 +8,7 @@ import os
 import numpy as np
 import pytest
 import torch
+from torch import nn
 
 pytestmark = pytest.mark.gpu
 
@@ -268,3 +269,83 @@ def test_three_layers_share_one_cache(quant_bits):
                 m.layer_idx = li
             torch.testing.assert_close(hs, hp_, rtol=0, atol=0)
     assert [shared.get_seq_length(li) for li in range(3)] == [T + 2] * 3
+
+
+@pytest.mark.parametrize("bits", [16, 4])
+def test_prefill_in_query_chunks_and_groups_equals_one_launch(bits):
+    """Long prompts run in query chunks x latent groups with bounded workspaces (LlamaPaluAttention._prefill_flash); forced
+    here on a golden-sized prompt: same output and same cache contents as the one-launch form, fp16 and packed caches."""
+    from palu_amd.kernel.palu_attention import LatentCache, QuantLatentCache
+    tag, seed, hidden, H, D, gs, rank_k, rank_v, T, _ = gi.PREFILL_CASES[0]
+    if bits < 16:
+        rank_k, rank_v = 64 * (H // gs), 128 * (H // gs)
+    w, prompt, _ = gi.prefill_inputs(seed, hidden, H, D, gs, rank_k, rank_v, T, True)
+    m = _module_from_palu_weights(hidden, H, D, gs, rank_k, rank_v, w)
+    x = prompt.reshape(1, T, hidden).to(DEV)
+    mk = (lambda: LatentCache()) if bits == 16 else (lambda: QuantLatentCache(bits))
+    c1, c2 = mk(), mk()
+    with torch.no_grad():
+        ref, _, _ = m(x, past_key_value=c1, is_causal=True)
+        m.PREFILL_WORKSPACE_BUDGET, m.PREFILL_QUERY_CHUNK = 0, 48          # 48: not a multiple of the kernel's 128-query tile
+        try:
+            out, _, _ = m(x, past_key_value=c2, is_causal=True)
+        finally:
+            del m.PREFILL_WORKSPACE_BUDGET, m.PREFILL_QUERY_CHUNK
+    assert c1.get_seq_length(0) == c2.get_seq_length(0) == T
+    torch.testing.assert_close(out.float(), ref.float(), rtol=2e-3, atol=2e-3)
+    if bits == 16:
+        for a, b in zip(c1.buffers(0), c2.buffers(0)):
+            assert torch.equal(a[:, :, :T], b[:, :, :T])
+    else:
+        for k in ("kc", "km", "vc", "vm"):
+            assert torch.equal(c1.buffers(0)[k][:, :, :T], c2.buffers(0)[k][:, :, :T])
+
+
+def test_prefill_transient_memory_is_bounded():
+    """a long prompt pass need not materialise K~ for every head, V^T for every group, the context of every
+    query and (packed cache) a dequantised copy of the whole cache at once: 32k tokens at the config-2 ranks, 4-bit cache.
+    The bounded-workspace form (query chunks x latent groups; the default once the one-launch form would need more than
+    PREFILL_WORKSPACE_BUDGET = 6 GiB) allocates less than half of the one-launch form's transients and the same output."""
+    from palu_amd.kernel.palu_attention import LlamaPaluAttention, QuantLatentCache, build_b
+    hidden, H, D, gs, rank_k, rank_v, T = 4096, 32, 128, 4, 1024, 3072, 32768
+
+    class Cfg:
+        pass
+    cfg = Cfg()
+    cfg.hidden_size, cfg.num_attention_heads, cfg.attention_bias = hidden, H, False
+    cfg.group_size, cfg.num_groups, cfg.total_rank_k, cfg.total_rank_v = gs, H // gs, rank_k, rank_v
+    torch.manual_seed(0)
+    with torch.device(DEV):
+        m = LlamaPaluAttention(cfg, 0).half()
+        with torch.no_grad():
+            for lin in (m.q_proj, m.k_proj.VT, m.v_proj.VT, m.o_proj):
+                lin.weight.normal_(0.0, 0.02)
+            for u in m.k_proj.U_list:
+                u.weight.normal_(0.0, 128 ** -0.5)
+        m.k_proj.B = nn.Parameter(build_b([u.weight for u in m.k_proj.U_list], gs, D))
+    m = m.eval().prepare_decode()
+    x = torch.randn(1, T, hidden, device=DEV, dtype=torch.float16)
+    with torch.no_grad():
+        m(x[:, :256], past_key_value=QuantLatentCache(4), is_causal=True)       # warm-up: library handles, fragments
+
+    def run(budget):
+        cache = QuantLatentCache(4, capacity=T + 512)
+        cache.reserve(0, T + 512, H // gs, rank_k // (H // gs), rank_v // (H // gs), x.device)
+        m.PREFILL_WORKSPACE_BUDGET = budget
+        try:
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            torch.cuda.reset_peak_memory_stats()
+            base = torch.cuda.memory_allocated()
+            with torch.no_grad():
+                out, _, _ = m(x, past_key_value=cache, is_causal=True)
+            torch.cuda.synchronize()
+            extra = torch.cuda.max_memory_allocated() - base - out.numel() * 2
+        finally:
+            del m.PREFILL_WORKSPACE_BUDGET
+        assert cache.get_seq_length(0) == T
+        return out, extra
+    one, mem_one = run(1 << 50)
+    bounded, mem_b = run(0)
+    torch.testing.assert_close(bounded.float(), one.float(), rtol=2e-3, atol=2e-3)
+    assert mem_b < 0.5 * mem_one and mem_b < 768 << 20, (mem_b / 2 ** 20, mem_one / 2 ** 20)
