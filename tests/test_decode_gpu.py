@@ -290,6 +290,34 @@ def test_decode_step_full_size_c2_vs_oracle():
     k_new = torch.nn.functional.linear(tok.reshape(1, -1), w["vt_k"]).reshape(G, Rk)
     torch.testing.assert_close(kc[:, L].cpu(), k_new, rtol=2e-3, atol=2e-3)
     assert abs(probs.float().sum(-1) - 1).max().item() < 5e-2
+    # the attention WEIGHTS too, so that a score-side error cannot hide behind an averaging softmax -- the
+    # step's scores (the workspace rows the score kernel wrote, through the one-call step with probs requested) against
+    # the oracle's softmax weights at all 65 537 positions, and the raw scores against an fp64 evaluation
+    lib = _lib()
+    kc2 = torch.zeros_like(kc)
+    vc2 = torch.zeros_like(vc)
+    kc2[:, :L] = k.to(DEV)
+    vc2[:, :L] = v.to(DEV)
+    from palu_amd.kernel.abx_rope import prepare_b, rope_inv_freq
+    frag = prepare_b(wd["b"], G)
+    inv = rope_inv_freq(torch.device(DEV))
+    ws = torch.zeros(lib.lib.palu_decode_workspace_bytes(H, G, D, L + 64, Rv), dtype=torch.uint8, device=DEV)
+    out2 = torch.empty(HID, dtype=torch.float16, device=DEV)
+    pr = torch.empty(H, L + 1, dtype=torch.float16, device=DEV)
+    x = tok.to(DEV)
+    lib.check(lib.lib.palu_decode_step_f16(
+        x.data_ptr(), wd["wq"].data_ptr(), wd["wq"].stride(0), wd["vt_k"].data_ptr(), wd["vt_k"].stride(0),
+        wd["vt_v"].data_ptr(), wd["vt_v"].stride(0), frag.data_ptr(), wd["wo"].data_ptr(), wd["wo"].stride(0),
+        kc2.data_ptr(), kc2.stride(0), kc2.stride(1), vc2.data_ptr(), vc2.stride(0), vc2.stride(1), 0, inv.data_ptr(),
+        out2.data_ptr(), pr.data_ptr(), pr.stride(0), ws.data_ptr(), L + 64, H, G, D, HID, Rk, Rv, L, L, _stream()),
+        "palu_decode_step_f16")
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out2.cpu(), ref, rtol=1e-3, atol=1e-3)
+    torch.testing.assert_close(pr.cpu().float(), probs.float(), rtol=1e-3, atol=1e-3)
+    # relative check on the weights that matter (the largest 1 % of each head: 1e-3 absolute says little at 1 / 65537)
+    top = probs.float().topk(655, dim=-1)
+    got = pr.cpu().float().gather(-1, top.indices)
+    assert ((got - top.values).abs() / top.values).max().item() < 2e-2
 
 
 def test_softmax_pv_config5_slice():
