@@ -53,7 +53,7 @@ int palu_abx2_prepare_b(const void* b, int64_t sb_h, int64_t sb_r, int64_t sb_d,
 
 extern "C" size_t palu_rope_table_bytes(int npos) {
   if (npos <= 0) return 0;
-  return (size_t)((npos + TL - 1) / TL) * 2 * 64 * sizeof(u32x4);
+  return (size_t)((npos + TL - 1) / TL) * 2 * 32 * sizeof(u32x4);
 }
 
 extern "C" int palu_rope_table_build(const float* inv_freq, int pos_first, int npos, void* table, palu_stream_t stream) {
@@ -62,7 +62,7 @@ extern "C" int palu_rope_table_build(const float* inv_freq, int pos_first, int n
                "rope_table_build: pos_first must be a multiple of %d and npos > 0 (got %d, %d)", TL, pos_first, npos);
   PALU_REQUIRE(((uintptr_t)table & 15) == 0, PALU_ERR_ARG, "rope_table_build: table must be 16-byte aligned");
   const int ntiles = (npos + TL - 1) / TL;
-  const int64_t total = (int64_t)ntiles * 128;
+  const int64_t total = (int64_t)ntiles * 64;
   hipLaunchKernelGGL(abx2_rope_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, inv_freq,
                      pos_first / TL, ntiles, (u32x4*)table);
   PALU_LAUNCH_CHECK();

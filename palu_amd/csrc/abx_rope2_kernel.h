@@ -85,16 +85,16 @@ __global__ void abx2_prepare_b_kernel(const h16* __restrict__ b, int64_t sb_h, i
   out[idx] = *reinterpret_cast<u32x4*>(&v);
 }
 
-// Low-band coefficient table: [tile][cs 2][lane 64] u32x4 = the B operand of stage 1 (v_mfma_f32_16x16x32_f16) for the
-// 128-position tile starting at absolute position 128 * (tile_first + tile): lane = k + 16 q (k = polynomial term, terms
-// 8..15 are zero), k-slots (e4, u) = pair i = 32 + 16 cs + 4 q + e4, u = 0: a'_{k,i}, u = 1: b'_{k,i}.  fp64 arithmetic on
-// the caller's fp32 frequencies (the angle is the exact product, phi = (l0 + 63.5) f_i), one rounding to fp16.
+// Low-band coefficient table: [tile][cs 2][q 4][k 8] u32x4 (1 KB per tile) = the non-zero half of the B operand of stage 1
+// (v_mfma_f32_16x16x32_f16) for the 128-position tile starting at absolute position 128 * (tile_first + tile): MFMA lane
+// k + 16 q holds term k < 8 (lanes of the terms 8..15 carry zeros and load nothing), k-slots (e4, u) = pair
+// i = 32 + 16 cs + 4 q + e4, u = 0: a'_{k,i}, u = 1: b'_{k,i}.  fp64 arithmetic on the caller's fp32 frequencies (the angle
+// is the exact product, phi = (l0 + 63.5) f_i), one rounding to fp16.
 __global__ void abx2_rope_table_kernel(const float* __restrict__ inv_freq, int tile_first, int ntiles, u32x4* __restrict__ out) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)ntiles * 128) return;
-  const int lane = (int)(idx & 63), cs = (int)((idx >> 6) & 1);
-  const int ti = (int)(idx >> 7);
-  const int k = lane & 15, q = lane >> 4;
+  if (idx >= (int64_t)ntiles * 64) return;
+  const int k = (int)(idx & 7), q = (int)((idx >> 3) & 3), cs = (int)((idx >> 5) & 1);
+  const int ti = (int)(idx >> 6);
   const double psimax = 64.0 * (double)inv_freq[ABX2_I0];
   const double lc = (double)(tile_first + ti) * 128.0 + 63.5;
   h16x8 v;
@@ -110,8 +110,8 @@ __global__ void abx2_rope_table_kernel(const float* __restrict__ inv_freq, int t
     // cos(phi + k pi/2), sin(phi + k pi/2)
     const double ck = (k & 1) ? ((k & 2) ? sn : -sn) : ((k & 2) ? -cn : cn);
     const double sk = (k & 1) ? ((k & 2) ? -cn : cn) : ((k & 2) ? -sn : sn);
-    v[2 * e4] = k < ABX2_K ? (h16)(float)(rel * ck) : (h16)0.f;
-    v[2 * e4 + 1] = k < ABX2_K ? (h16)(float)(rel * sk) : (h16)0.f;
+    v[2 * e4] = (h16)(float)(rel * ck);
+    v[2 * e4 + 1] = (h16)(float)(rel * sk);
   }
   out[idx] = *reinterpret_cast<u32x4*>(&v);
 }
@@ -271,12 +271,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
       lowf[hh][cs] = *reinterpret_cast<h16x8*>(&v);
     }
   // coefficient fragments of this workgroup's first two tiles
-  const u32x4* tab = p.rope_tab + ((int64_t)(p.tab_tile0 + tile0) * 2) * 64 + lane;
+  const u32x4* tab = p.rope_tab + ((int64_t)(p.tab_tile0 + tile0) * 2) * 32 + (lane >> 4) * 8 + (lane & 7);
+  const bool coef_lane = (lane & 15) < ABX2_K;    // MFMA columns 8..15 of stage 1 are zero: those lanes load nothing
   auto load_coef = [&](int tt, h16x8 (&cf)[2]) {
     const int t = min(tt, ntile - 1);
 #pragma unroll
     for (int cs = 0; cs < 2; ++cs) {
-      u32x4 v = tab[(int64_t)(t * 2 + cs) * 64];
+      u32x4 v = u32x4{0u, 0u, 0u, 0u};
+      if (coef_lane) v = tab[(int64_t)(t * 2 + cs) * 32];
       cf[cs] = *reinterpret_cast<h16x8*>(&v);
     }
   };

@@ -35,7 +35,7 @@ def rope_inv_freq(device, head_dim: int = 128, theta: float = 10000.0) -> torch.
     return t
 
 
-ROPE_TABLE_POSITIONS = 1 << 18      # what the two-band score kernel covers (csrc/abx_rope2.hip); 4 MB per (device, theta)
+ROPE_TABLE_POSITIONS = 1 << 18      # what the two-band score kernel covers (csrc/abx_rope2.hip); 2 MB per (device, theta)
 _rope_tables = {}
 
 
