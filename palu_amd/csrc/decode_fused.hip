@@ -49,12 +49,15 @@ int fused_prio_mode() {   // 0 none, 2 score-block alternation (abx_rope_kernel.
 }
 
 // PALU_FUSED_ATTN: 0 = never, 1 = whenever the shape is covered, unset = auto.  Measured on MI355X (same box, interleaved,
-// tools/bench_fused_variants.py, profiles/r02_fused_vs_two_kernel_policy_sweep.txt), fused vs two kernels in us:
-//   G=1 L=16k 23.7/25.5   G=1 L=64k 37.4/42.4   G=2 L=64k 51.4/58.5   G=1 L=256k 88/98   G=4 L=64k 84.0/86.1 (tie)
-//   G=2 L=256k 154/146.5  G=8 L=64k 144.5/137.4
-// i.e. it wins while a CU streams few rows (G*L <= ~262k: the head-group shards of a multi-GPU run) and loses once the
-// steady state dominates, where the 160 KB of LDS cannot hold enough latent rows in flight next to the score kernel's
-// tiles.
+// tools/bench_fused_variants.py, profiles/r04_fused_vs_two_kernel_policy_sweep.txt), fused vs two kernels in us, round 4
+// (two-band score kernel in the two-kernel path):
+//   G=1: L=16k 24.2/27.0   64k 40.1/39.9   128k 57.0/63.3   256k 94.0/104.0
+//   G=2: 16k 29.7/28.6   32k 38.9/37.3   64k 55.9/54.5   128k 92.8/85.9
+//   G=4: 8k 28.5/27.3   16k 37.8/36.6   32k 57.5/55.0   64k 94.7/80.6
+//   G=8: 2k 20.7/24.2   4k 25.6/26.6   8k 37.5/34.3   16k 58.8/51.6   32k 95.9/81.8
+// i.e. it wins with ONE latent group per launch (every rank of an 8-GPU head-group sharding) and on very short caches,
+// where its one launch less counts; from G = 2 and a few ten thousand rows per launch the 160 KB of LDS cannot hold enough
+// latent rows in flight next to the score pipeline's tiles and the two kernels win.
 int fused_mode() {
   static int m = -2;
   if (m == -2) {
@@ -83,7 +86,9 @@ extern "C" int palu_decode_attn_supported(int H, int G, int Rk, int Rv, int D) {
 extern "C" int palu_decode_attn_preferred(int H, int G, int L, int Rk, int Rv, int D) {
   if (!palu_decode_attn_supported(H, G, Rk, Rv, D) || L <= 0) return 0;
   const int m = fused_mode();
-  return m >= 0 ? m : ((int64_t)G * L <= 300000);
+  // round 4 (the two-kernel path runs the two-band score kernel): one latent group per launch -- the per-GPU slice of an
+  // 8-way head-group sharding -- or very short caches (profiles/r04_fused_vs_two_kernel_policy_sweep.txt)
+  return m >= 0 ? m : (G == 1 ? L <= 300000 : (int64_t)G * L <= 24576);
 }
 
 extern "C" int palu_decode_attn_nsplit(int G, int L) {

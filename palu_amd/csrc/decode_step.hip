@@ -2,7 +2,7 @@
 // stream (hipGraph-capturable): the drop-in for the decode branch of LlamaPaluAttention.forward
 // (kernel/palu_attention.py:147-263, branch :207-219).
 //   qkv GEMV + q-RoPE + cache append -> abx scores -> softmax.PV + split merge -> o_proj            (5 launches)
-// or, where palu_decode_attn_preferred() says the single-kernel attention core is faster (few rows per CU: G * L <= 300k,
+// or, where palu_decode_attn_preferred() says the single-kernel attention core is faster (one latent group per launch, or a very short cache;
 // no attention weights requested; an additive mask is taken):  qkv -> fused scores/softmax/P.V (decode_fused.hip) + split merge -> o_proj.
 #include "palu_common.h"
 
