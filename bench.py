@@ -595,18 +595,28 @@ def main():
                 src = torch.zeros(plan.heads_local * Rv, dtype=torch.float16, device=dev)
                 dst = torch.empty(H * Rv, dtype=torch.float16, device=dev)
                 coll = lambda: other.all_gather_into(dst, src)
-            for _ in range(20):
-                coll()
-            sync()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(200):
-                coll()
-            e1.record()
-            torch.cuda.synchronize()
-            to = torch.tensor([e0.elapsed_time(e1) * 1e3 / 200], device=dev)
-            dist.all_reduce(to, op=dist.ReduceOp.MAX)
-            other_us = float(to.item())
+            coll()                                           # one exchange first: a peer-to-peer exchange whose peers never
+            sync()                                           # show up reports a timed-out wait (bounded spin) instead of hanging
+            healthy = 1
+            if other is p2p and p2p.status()[1] != 0:
+                healthy = 0
+            ht = torch.tensor([healthy], device=dev)
+            dist.all_reduce(ht, op=dist.ReduceOp.MIN)
+            if int(ht.item()):
+                for _ in range(20):
+                    coll()
+                sync()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(200):
+                    coll()
+                e1.record()
+                torch.cuda.synchronize()
+                to = torch.tensor([e0.elapsed_time(e1) * 1e3 / 200], device=dev)
+                dist.all_reduce(to, op=dist.ReduceOp.MAX)
+                other_us = float(to.item())
+            else:
+                other_name += " (timed out: not measured)"
 
     rec = None
     if rank == 0:

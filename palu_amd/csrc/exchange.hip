@@ -158,7 +158,7 @@ static int exchange_launch(const void* src, size_t bytes, const void* peers_dev,
   ExParams p;
   p.src = (const char*)src; p.bytes = bytes; p.peers = (char* const*)peers_dev; p.rank = rank; p.n = nranks;
   p.slot_bytes = slot_bytes; p.out = (char*)out; p.mode = mode;
-  p.max_spin = 1u << 22;               // x (s_sleep 8 + a system-scope load) ~ seconds: a hung peer surfaces as an error word
+  p.max_spin = 1u << 20;               // x (s_sleep 8 + a system-scope load) ~ 1 s: a hung peer surfaces as an error word
   hipLaunchKernelGGL(exchange_kernel, dim3(1), dim3(EX_THREADS), 0, (hipStream_t)stream, p);
   PALU_LAUNCH_CHECK();
   return PALU_OK;
