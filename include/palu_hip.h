@@ -75,7 +75,9 @@ int palu_abx_rope_f16(const void* a, int64_t sa_h, int64_t sa_d,
  * in fp32 and rounded once.  Without scratch (palu_abx_rope_f16, or scratch = 0) such ranks take the slower chunked kernel.
  * Ranks below 128 other than 32 / 64 (e.g. 96) always run the 128-column kernel with the missing columns masked. */
 /* Low-band RoPE coefficient table of the two-band score kernel (csrc/abx_rope2_kernel.h).  With 4 heads per latent group
- * and R in {32, 64, 128} the abx entry points (fp16 and packed latents, and the decode steps built on them) run a kernel
+ * and R in {32, 64, 128} -- or rank 96 / a multiple of 32 above 128, as column windows of those widths (128-wide ones, then
+ * 32 or 64, or a 128-wide window with 96 valid columns; fp32 partial scores in the scratch, the last window rounds) --
+ * the abx entry points (fp16 and packed latents, and the decode steps built on them) run a kernel
  * that treats the 32 low-frequency RoPE pairs of a 128-position tile as a degree-7 polynomial in the in-tile position:
  * a quarter of the reconstruction GEMM and of the per-position rotation work disappears.  It needs, per 128-position
  * tile, the fp16 coefficients (psi_i/psi_max)^k cos/sin(phi_i + k pi/2) of the tile's centre angle -- a function of the

@@ -122,6 +122,12 @@ extern "C" int palu_abx_rope_ws_f16(const void* a, int64_t sa_h, int64_t sa_d, c
   if (pl.chunked && pl.nkc == 1 && ((int64_t)L + 3 * 128) * sx_l * 2 < ((int64_t)1 << 31)) {
     // a rank below 128 that is not 32 / 64 (96 of the rank search, 40, 72, ...): the 128-column fast kernel on the
     // zero-padded fragments, the columns beyond R masked in its tile staging -- 3x the chunked kernel's speed
+    if (fold && palu_abx2_frag_bytes(H, G, R)) {
+      // rank 96 at 4 heads per group: one 128-wide window of the two-band kernel, 96 valid columns (abx_rope2.hip)
+      p.bfrag2 = (const u32x4*)((const char*)bfrag + abx_frag1_bytes(G, pl));
+      const int rc2 = palu_abx2_try_launch_windows(&p, nwg, 0, nullptr, 0, s);
+      if (rc2 != PALU_ABX2_SKIP) return rc2;
+    }
     p.ncols = R;
     return fold ? (pl.nmb == 2 ? launch_abx_fast<8, 2, true>(p, nwg, s) : launch_abx_fast<8, 1, true>(p, nwg, s))
                 : (pl.nmb == 2 ? launch_abx_fast<8, 2, false>(p, nwg, s) : launch_abx_fast<8, 1, false>(p, nwg, s));
@@ -129,6 +135,16 @@ extern "C" int palu_abx_rope_ws_f16(const void* a, int64_t sa_h, int64_t sa_d, c
   if (pl.chunked && pl.nkc >= 2 && scratch && ((uintptr_t)scratch & 15) == 0 &&
       ((int64_t)L + 3 * 128) * sx_l * 2 < ((int64_t)1 << 31)) {
     const int64_t acc_ld = ((int64_t)L + 7) & ~(int64_t)7;
+    if (fold && palu_abx2_frag_bytes(H, G, R)) {
+      // 4 heads per group: the column windows (128, ..., 64, 32) through the two-band kernel when a coefficient table
+      // covers the positions (abx_rope2.hip); fp32 partial scores in the scratch, one rounding below
+      p.bfrag2 = (const u32x4*)((const char*)bfrag + abx_frag1_bytes(G, pl));
+      const int rc2 = palu_abx2_try_launch_windows(&p, nwg, 0, scratch, acc_ld, s);
+      if (rc2 != PALU_ABX2_SKIP) {
+        if (rc2) return rc2;
+        return PALU_OK;
+      }
+    }
     for (int kc = 0; kc < pl.nkc; ++kc) {
       AbxParams pk = p;
       pk.x = (const h16*)x + 128 * kc;                // window kc of every row (row stride unchanged)

@@ -28,26 +28,56 @@ int two_band_enabled() {     // PALU_ABX_TWO_BAND=0 keeps every launch on abx_ro
 
 template <int NKS, int QBITS>
 int launch2(const AbxParams& p, int nwg, hipStream_t stream) {
-  return launch_kernel(abx_rope2_kernel<NKS, QBITS>, abx2_smem(NKS), p, nwg, stream);
+  if (p.acc == nullptr) return launch_kernel(abx_rope2_kernel<NKS, QBITS, 0>, abx2_smem(NKS), p, nwg, stream);
+  if (p.ks0 == 0) return launch_kernel(abx_rope2_kernel<NKS, QBITS, 1>, abx2_smem(NKS), p, nwg, stream);   // first window: store
+  if (p.ks0 == 1) return launch_kernel(abx_rope2_kernel<NKS, QBITS, 2>, abx2_smem(NKS), p, nwg, stream);   // middle ones: add
+  return launch_kernel(abx_rope2_kernel<NKS, QBITS, 3>, abx2_smem(NKS), p, nwg, stream);                    // last: add, round, store
+}
+
+// column windows of rank 96 and of the ranks above 128 (ranks are multiples of 32: palu/rank_search.py:11-17): 128-wide ones, then the
+// remainder -- 32 or 64 at their own width, 96 as a 128-wide window with 96 valid columns (measured at C2's shape: a pass
+// costs ~30 / 35 / 51 us at width 32 / 64 / 128, so 64 + 32 loses to one padded 128)
+int abx2_windows(int R, int* w, int* valid) {
+  if (R % 32 || (R <= 128 && R != 96)) return 0;
+  int n = 0, c = 0;
+  while (R - c >= 128) { w[n] = 128; valid[n++] = 128; c += 128; }
+  const int rem = R - c;
+  if (rem == 96) { w[n] = 128; valid[n++] = 96; }
+  else if (rem) { w[n] = rem; valid[n++] = rem; }
+  return n;
 }
 
 }  // namespace
 
 size_t palu_abx2_frag_bytes(int H, int G, int R) {
-  if (G <= 0 || H != 4 * G || !(R == 32 || R == 64 || R == 128)) return 0;
-  return abx2_frag_u32x4(G, R / 16) * sizeof(u32x4);
+  if (G <= 0 || H != 4 * G) return 0;
+  if (R == 32 || R == 64 || R == 128) return abx2_frag_u32x4(G, R / 16) * sizeof(u32x4);
+  int wdt[64], val[64];
+  const int nw = R <= 128 * 60 ? abx2_windows(R, wdt, val) : 0;
+  size_t n = 0;
+  for (int i = 0; i < nw; ++i) n += abx2_frag_u32x4(G, wdt[i] / 16);     // one fragment set per column window
+  return n * sizeof(u32x4);
 }
 
 // fragments of the two-band kernel, written behind the abx_rope_kernel fragments by palu_abx_prepare_b
 int palu_abx2_prepare_b(const void* b, int64_t sb_h, int64_t sb_r, int64_t sb_d, int H, int G, int R, void* frag2,
                         hipStream_t stream) {
   if (!palu_abx2_frag_bytes(H, G, R)) return PALU_OK;
-  const int nks = R / 16;
-  const int64_t n_hi = (int64_t)G * 8 * nks * 64;
-  const int64_t total = (int64_t)abx2_frag_u32x4(G, nks);
-  hipLaunchKernelGGL(abx2_prepare_b_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const h16*)b, sb_h,
-                     sb_r, sb_d, G, R, nks, (u32x4*)frag2, n_hi, total);
-  PALU_LAUNCH_CHECK();
+  int wdt[64], val[64];
+  int nw = abx2_windows(R, wdt, val);
+  if (nw == 0) { nw = 1; wdt[0] = val[0] = R; }
+  u32x4* dst = (u32x4*)frag2;
+  int c0 = 0;
+  for (int i = 0; i < nw; ++i) {
+    const int nks = wdt[i] / 16;
+    const int64_t n_hi = (int64_t)G * 8 * nks * 64;
+    const int64_t total = (int64_t)abx2_frag_u32x4(G, nks);
+    hipLaunchKernelGGL(abx2_prepare_b_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
+                       (const h16*)b + (int64_t)c0 * sb_r, sb_h, sb_r, sb_d, G, val[i], nks, dst, n_hi, total);   // rows >= val: 0
+    PALU_LAUNCH_CHECK();
+    dst += total;
+    c0 += val[i];
+  }
   return PALU_OK;
 }
 
@@ -96,6 +126,7 @@ extern "C" int palu_rope_table_unregister(const float* inv_freq) {
 // 1 when a launch with these positions would take the two-band kernel (introspection for tests and the bench)
 extern "C" int palu_abx_two_band_selected(const float* inv_freq, int H, int G, int L, int R, int pos0) {
   if (!two_band_enabled() || !palu_abx2_frag_bytes(H, G, R) || L <= 0 || pos0 < 0 || pos0 % TL) return 0;
+  if (R > 128 && ((int64_t)L + 3 * 128) * R * 2 >= ((int64_t)1 << 31)) return 0;
   if ((int64_t)pos0 + L > 262144) return 0;
   std::lock_guard<std::mutex> lk(g_tab_mutex);
   for (const auto& t : g_tabs)
@@ -116,7 +147,9 @@ extern "C" void palu_abx2_debug_buffer(void* ptr) { g_abx2_dbg = (unsigned long 
 int palu_abx2_try_launch(const void* params, int nwg, int bits, hipStream_t stream) {
   AbxParams p = *reinterpret_cast<const AbxParams*>(params);
   p.dbg = g_abx2_dbg;
-  if (!p.bfrag2 || p.ncols != 0 || p.acc || p.ks0 != 0 || p.qgroup != 0 || p.HB != 1 || p.gs != 4) return PALU_ABX2_SKIP;
+  // (a windowed pass arrives with R = the window's width, acc set and ks0 = 0 for the first window, 1 for the middle ones, 2 for the last)
+  if (!p.bfrag2 || p.ncols < 0 || p.ncols >= p.R || p.qgroup != 0 || p.HB != 1 || p.gs != 4) return PALU_ABX2_SKIP;
+  if (!(p.R == 32 || p.R == 64 || p.R == 128)) return PALU_ABX2_SKIP;
   if (!palu_abx_two_band_selected(p.inv_freq, p.H, p.G, p.L, p.R, p.pos0)) return PALU_ABX2_SKIP;
   {
     std::lock_guard<std::mutex> lk(g_tab_mutex);
@@ -134,10 +167,43 @@ int palu_abx2_try_launch(const void* params, int nwg, int bits, hipStream_t stre
       default: return launch2<8, 0>(p, nwg, stream);
     }
   }
-  if (bits == 3) return p.R == 128 ? launch2<8, 3>(p, nwg, stream) : PALU_ABX2_SKIP;
+  if (bits == 3) return p.R == 128 ? launch2<8, 3>(p, nwg, stream) : PALU_ABX2_SKIP;     // (narrower 3-bit quarter rows are not whole dwords)
   switch (p.R) {
     case 32: return launch2<2, 4>(p, nwg, stream);
     case 64: return launch2<4, 4>(p, nwg, stream);
     default: return launch2<8, 4>(p, nwg, stream);
   }
+}
+
+// Rank 96 or a rank above 128 with 4 heads per group as passes of the two-band kernel over its column windows (128, 128, ..., 64, 32),
+// fp32 partial scores in `scratch` (palu_abx_scratch_bytes); the last pass adds its window, rounds and stores `out`.  `params`: AbxParams of the whole
+// problem (x / xq, bfrag2 = the window fragment sets, R = the full rank).  PALU_ABX2_SKIP when the shape or the positions
+// do not allow it.  bits = 0 / 4; 3 when every window is 128 wide (R % 128 in {0, 96}).
+int palu_abx2_try_launch_windows(const void* params, int nwg, int bits, void* scratch, int64_t acc_ld, hipStream_t stream) {
+  const AbxParams p0 = *reinterpret_cast<const AbxParams*>(params);
+  int wdt[64], val[64];
+  const int nw = abx2_windows(p0.R, wdt, val);
+  if (nw == 0 || (nw > 1 && !scratch) || !p0.bfrag2 || p0.HB != 1 || p0.gs != 4 || p0.qgroup != 0 || p0.ncols != 0) return PALU_ABX2_SKIP;
+  if (bits == 3 && wdt[nw - 1] != 128) return PALU_ABX2_SKIP;
+  for (int i = 0; i < nw; ++i)
+    if (!palu_abx_two_band_selected(p0.inv_freq, p0.H, p0.G, p0.L, wdt[i], p0.pos0)) return PALU_ABX2_SKIP;
+  if (bits == 0 && ((int64_t)p0.L + 3 * 128) * p0.sx_l * 2 >= ((int64_t)1 << 31)) return PALU_ABX2_SKIP;
+  const u32x4* frag = p0.bfrag2;
+  int c0 = 0;
+  for (int i = 0; i < nw; ++i) {
+    AbxParams p = p0;
+    p.R = wdt[i];
+    p.ncols = val[i] == wdt[i] ? 0 : val[i];
+    p.bfrag2 = frag;
+    p.acc = nw > 1 ? (float*)scratch : nullptr;      // (rank 96: one padded window straight to `out`)
+    p.acc_ld = acc_ld;
+    p.ks0 = i == 0 ? 0 : i + 1 < nw ? 1 : 2;
+    if (bits == 0) p.x = p0.x + c0;
+    else p.xq = p0.xq + (size_t)c0 * bits / 8;
+    const int rc = palu_abx2_try_launch(&p, nwg, bits, stream);
+    if (rc != PALU_OK) return rc == PALU_ABX2_SKIP && i > 0 ? PALU_ERR_LAUNCH : rc;
+    frag += abx2_frag_u32x4(p0.G, wdt[i] / 16);
+    c0 += wdt[i];
+  }
+  return PALU_OK;
 }

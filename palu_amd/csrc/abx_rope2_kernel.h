@@ -121,7 +121,12 @@ constexpr int abx2_smem(int nks) { return 3 * TL * 32 * nks + 3 * ABX2_RED_STRID
 
 typedef __attribute__((address_space(3))) float lds_f32;
 
-template <int NKS, int QBITS = 0>
+// ACC: 0 = scores rounded to fp16 and stored to `out`; 1 / 2 = this launch is one pass over a column WINDOW of a wider
+// rank (x and the fragments of that window): fp32 partial scores stored to (1) / added to (2) p.acc (abx_rope_kernel's ACC);
+// 3 = the last window: p.acc + this window's scores, rounded to fp16 and stored to `out`.
+// p.ncols != 0: a last window of p.ncols < 16 NKS valid columns run at the full width -- its fragments carry zero rows past
+// p.ncols, the fp16 rows over-read into the next row (finite values x 0; the buffer range ends at the last row's true end).
+template <int NKS, int QBITS = 0, int ACC = 0>
 __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
   using Geo = LdsGeom<NKS>;
   constexpr int NRING = 3;
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
     const unsigned long long xb = reinterpret_cast<unsigned long long>(xg);
     xrs[0] = __builtin_amdgcn_readfirstlane((unsigned)xb);
     xrs[1] = __builtin_amdgcn_readfirstlane((unsigned)(xb >> 32));
-    xrs[2] = __builtin_amdgcn_readfirstlane((unsigned)(((int64_t)(p.L - 1) * p.sx_l + 16 * NKS) * 2));
+    xrs[2] = __builtin_amdgcn_readfirstlane((unsigned)(((int64_t)(p.L - 1) * p.sx_l + (p.ncols ? p.ncols : 16 * NKS)) * 2));
     xrs[3] = 0x00020000u;
   }
   const unsigned dma_voff = (unsigned)((tid / Geo::CPR) * p.sx_l * 2 + Geo::swz(tid / Geo::CPR, tid % Geo::CPR) * 16);
@@ -189,7 +194,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
   auto load_q = [&](int tt) {
     const int row = tid >> 2, quarter = tid & 3;
     const int l = min((tile0 + tt) * TL + row, p.L - 1);
-    const unsigned* src = reinterpret_cast<const unsigned*>(xqg + (int64_t)l * p.sq_l) + quarter * NW;
+    // (a padded last window, p.ncols valid columns: the quarters past the row's end re-read quarter 0 -- their fragment rows are 0)
+    const unsigned* src = reinterpret_cast<const unsigned*>(xqg + (int64_t)l * p.sq_l) + (p.ncols && quarter * CPQ >= p.ncols ? 0 : quarter * NW);
 #pragma unroll
     for (int k = 0; k < NW; ++k) qraw[k] = __builtin_nontemporal_load(src + k);
     qmeta = *reinterpret_cast<const unsigned*>(xmg + (int64_t)l * p.sm_l);
@@ -402,18 +408,38 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
   // scores leave through a buffer store (invalid lanes get an out-of-range offset the hardware drops)
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
 
+  u32x4 arsrc;      // fp32 score array of a multi-pass launch (same [head][position] indexing; range drops the invalid lanes)
+  {
+    const unsigned long long ab = reinterpret_cast<unsigned long long>(p.acc);
+    arsrc[0] = __builtin_amdgcn_readfirstlane((unsigned)ab);
+    arsrc[1] = __builtin_amdgcn_readfirstlane((unsigned)(ab >> 32));
+    arsrc[2] = __builtin_amdgcn_readfirstlane((unsigned)((((int64_t)(p.H - 1) * p.acc_ld + p.L) * 4)));
+    arsrc[3] = 0x00020000u;
+  }
+  const __amdgpu_buffer_rsrc_t arsrc_ld = __builtin_amdgcn_make_buffer_rsrc(
+      p.acc, 0, p.acc ? (int)(((int64_t)(p.H - 1) * p.acc_ld + p.L) * 4) : 0, 0x00020000);
   // cross-wave reduction of tile tt (partial sums of the 8 waves in slot rslot) and the fp16 store
   // (measured: LDS float atomics -- the two waves of a SIMD adding into one word -- cost 50 us per launch at C2)
   auto reduce_store = [&](int tt, int rslot) {
     const int hh = tid >> 7, pos = tid & 127;
     const unsigned r = red_base + (unsigned)((rslot * ABX2_RED_STRIDE + hh * TL + pos) * sizeof(float));
-    float s = 0.f;
-#pragma unroll
-    for (int ww = 0; ww < 8; ++ww) s += *(lds_f32*)(uintptr_t)(r + (unsigned)(ww * 4 * TL * sizeof(float)));
     const int l = (tile0 + tt) * TL + pos;
     const bool ok = tt >= 0 && l < p.L;
-    const unsigned off = ok ? (unsigned)(((int64_t)(g * 4 + hh) * p.so_h + l) * 2) : 0xFFFFFFF0u;
-    __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (h16)s), orsrc, off, 0, 0);
+    float s = 0.f;
+    if (ACC == 3)      // last window: the earlier windows' sum (out-of-range lanes read 0)
+      s = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                        arsrc_ld, ok ? (unsigned)(((int64_t)(g * 4 + hh) * p.acc_ld + l) * 4) : 0xFFFFFFF0u, 0, 0));
+#pragma unroll
+    for (int ww = 0; ww < 8; ++ww) s += *(lds_f32*)(uintptr_t)(r + (unsigned)(ww * 4 * TL * sizeof(float)));
+    if (ACC == 0 || ACC == 3) {
+      const unsigned off = ok ? (unsigned)(((int64_t)(g * 4 + hh) * p.so_h + l) * 2) : 0xFFFFFFF0u;
+      __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (h16)s), orsrc, off, 0, 0);
+    } else {
+      // every (head, position) is written once per pass, the passes are stream-ordered: deterministic
+      const unsigned aoff = ok ? (unsigned)(((int64_t)(g * 4 + hh) * p.acc_ld + l) * 4) : 0xFFFFFFF0u;
+      if (ACC == 1) asm volatile("buffer_store_dword %0, %1, %2, 0 offen\n\ts_nop 0" ::"v"(s), "v"(aoff), "s"(arsrc) : "memory");
+      else asm volatile("buffer_atomic_add_f32 %0, %1, %2, 0 offen\n\ts_nop 0" ::"v"(s), "v"(aoff), "s"(arsrc) : "memory");
+    }
   };
 
   // X fragments: ring of XD registers sets, refilled XD k-steps ahead (abx_rope_kernel); local k-step j of this wave is

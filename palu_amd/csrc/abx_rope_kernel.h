@@ -36,6 +36,7 @@
 // PALU_ABX2_SKIP when the caller should run abx_rope_kernel instead.  `params` is an AbxParams with bfrag2 set.
 #define PALU_ABX2_SKIP 1
 int palu_abx2_try_launch(const void* params, int nwg, int bits, hipStream_t stream);
+int palu_abx2_try_launch_windows(const void* params, int nwg, int bits, void* scratch, int64_t acc_ld, hipStream_t stream);
 size_t palu_abx2_frag_bytes(int H, int G, int R);   // 0 when the shape is not covered
 int palu_abx2_prepare_b(const void* b, int64_t sb_h, int64_t sb_r, int64_t sb_d, int H, int G, int R, void* frag2, hipStream_t stream);
 

@@ -104,6 +104,15 @@ static int abx_rope_q_impl(const void* a, int64_t sa_h, int64_t sa_d, const void
     hipStream_t sw = (hipStream_t)stream;
     const int nwg = abx_fill_params(p, pl, H, G, L, R, pos0);
     const int64_t acc_ld = ((int64_t)L + 7) & ~(int64_t)7;
+    if (palu_abx2_frag_bytes(H, G, R)) {              // (rank 96 or above 128)
+      // 4 heads per group: the column windows through the two-band kernel (abx_rope2.hip)
+      p.bfrag2 = (const u32x4*)((const char*)bfrag + (size_t)G * pl.hb * 8 * pl.nmb * pl.nks_tot * 64 * sizeof(u32x4));
+      const int rc2 = palu_abx2_try_launch_windows(&p, nwg, bits, scratch, acc_ld, sw);
+      if (rc2 != PALU_ABX2_SKIP) {
+        if (rc2) return rc2;
+        return PALU_OK;
+      }
+    }
     for (int kc = 0; kc < nwin; ++kc) {
       AbxParams pk = p;
       pk.xq = (const unsigned char*)codes + (size_t)kc * 128 * bits / 8;

@@ -56,7 +56,8 @@ def test_selection_rules():
     assert sel(32, 8, 65537, 128, 0) == 1 and sel(32, 8, 131073, 64, 0) == 1 and sel(4, 1, 100, 32, 256) == 1
     assert sel(32, 8, 1000, 128, 64) == 0              # tiles must start at multiples of 128
     assert sel(16, 8, 1000, 128, 0) == 0               # 2 heads per group
-    assert sel(32, 8, 1000, 96, 0) == 0                # rank outside {32, 64, 128}
+    assert sel(32, 8, 1000, 96, 0) == 1 and sel(32, 8, 1000, 224, 0) == 1      # column windows (multiples of 32)
+    assert sel(32, 8, 1000, 40, 0) == 0 and sel(32, 8, 1000, 136, 0) == 0      # other ranks: one-band kernels
     assert sel(32, 8, 262145, 128, 0) == 0             # positions beyond the table / 2^18
     assert sel(32, 8, 204800, 128, 0) == 0             # inv_freq[32] * L >= 2048 rad (0.01 * 204800)
     assert sel(32, 8, 204000, 128, 0) == 1
@@ -150,6 +151,49 @@ def test_packed_latents_score_like_their_dequantised_rows(bits, R, L):
     ref = ar.abx(ac, bc, xdq)
     assert torch.equal(out, ref)
     _p2(out, a, b, xdq.cpu())
+
+
+@pytest.mark.parametrize("R,L", [(96, 2100), (160, 3000), (192, 129), (224, 4097), (256, 2500), (352, 300), (384, 1000), (512, 777)])
+def test_ranks_above_128_run_as_two_band_column_windows(R, L):
+    """Rank 96 and the ranks the rank search emits above 128 (palu/rank_search.py:11-17) and the reference test's 512: column windows
+    (128, ..., then 32 / 64 / a 128-wide window with 96 valid columns) of the two-band kernel, fp32 partial scores, one rounding.  P2 against the oracle, and agreement with
+    the one-band window passes."""
+    _lib, ar = _mods()
+    H, G = 32, 8
+    a, b, x = _inputs(H, G, R, L, seed=11 * R + L)
+    ac, bc, xc = a.cuda(), b.cuda(), x.cuda()
+    two = ar.abx(ac, bc, xc)
+    with ar.one_band():
+        one = ar.abx(ac, bc, xc)
+    _p2(two, a, b, x)
+    _p2(one, a, b, x)
+    scale = float(one.float().abs().max())
+    assert float((two.float() - one.float()).abs().max()) <= 1e-3 * scale
+    assert not torch.equal(two, one)          # (the two kernels round differently: identical outputs = the hook did not run)
+
+
+@pytest.mark.parametrize("bits,R,L", [(4, 96, 700), (3, 96, 1500), (4, 160, 2000), (4, 224, 515), (4, 256, 4100), (3, 256, 1300), (3, 224, 1000), (3, 160, 600)])
+def test_packed_ranks_above_128_score_like_their_dequantised_rows(bits, R, L):
+    """Packed latents at a windowed rank: the same window plan as the fp16 rows (4-bit; 3-bit when every window is 128 wide: R % 128 in {0, 96}),
+    so bit-identical to `abx` on quantize_tensor(x); 3-bit R=160 stays on the one-band windows (P2 only)."""
+    _lib, ar = _mods()
+    from palu_amd.kernel import quant as pq
+    H, G = 32, 8
+    a, b, x = _inputs(H, G, R, L, seed=bits * 100 + R)
+    ac, bc, xc = a.cuda(), b.cuda(), x.cuda()
+    codes, meta = pq.quantize_pack(xc, bits)
+    xdq = pq.unpack_dequant(codes, meta, bits, R)
+    inv = ar.rope_inv_freq(xc.device)
+    frag = ar.prepare_b(bc, G)
+    out = torch.empty(H, 1, L, dtype=torch.float16, device=xc.device)
+    scr = torch.empty(max(int(_lib.lib.palu_abx_scratch_bytes(H, G, L, R)), 16), dtype=torch.uint8, device=xc.device)
+    _lib.check(_lib.lib.palu_abx_rope_qg(ac.data_ptr(), ac.stride(0), ac.stride(2), frag.data_ptr(), codes.data_ptr(),
+                                         codes.stride(0), codes.stride(1), meta.data_ptr(), meta.stride(0), meta.stride(1),
+                                         out.data_ptr(), out.stride(0), H, G, L, R, D, bits, 0, inv.data_ptr(), 0,
+                                         scr.data_ptr(), torch.cuda.current_stream().cuda_stream), "abx_qg")
+    _p2(out, a, b, xdq.cpu())
+    if bits == 4 or R % 128 in (0, 96):
+        assert torch.equal(out, ar.abx(ac, bc, xdq))
 
 
 def test_pos_offset_in_whole_tiles_and_other_theta():
