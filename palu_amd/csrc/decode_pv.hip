@@ -526,15 +526,20 @@ static __device__ __forceinline__ unsigned sgpr_const(unsigned c) {
   return d;
 }
 
-template <int GS, int BITS, int S>
+template <int GS, int BITS, int S, int CWT = 32>
 __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
   // BITS = 3 / 4: packed codes, 32 per chunk.  BITS = 16: plain fp16 latents, 8 per chunk (16 bytes) -- the same kernel
   // without a decode step: 8 accumulators instead of 32 leave room for four register sets of units in flight.
+  // CWT = 24 (4 bit only: 12-byte chunks) is for rows whose 32-code chunks would leave a quarter of the MFMA lanes idle:
+  // 192 columns = 6 x 32 = 8 x 24 with two row sets (C4).  (Measured and dropped for 3 bit -- 9-byte chunks loaded as
+  // unaligned dwordx3, 384 = 16 x 24 columns: 26.7 us against 26.4 us at C3.  The unit loop runs at 5.8 TB/s either way.)
   constexpr bool FP16 = BITS == 16;
-  constexpr int CW = FP16 ? 8 : 32;          // columns per chunk = MFMAs per unit = accumulators
-  constexpr int CHB = FP16 ? 16 : 4 * BITS;  // bytes per chunk
-  constexpr int RDW = BITS == 3 ? 3 : 4;     // dwords per chunk
-  constexpr int NW = 8, NSET = FP16 ? 4 : 2, NJ = CW;   // (packed: a third set spills next to 128 accumulator registers)
+  static_assert(CWT == 32 || (CWT == 24 && BITS == 4), "24-code chunks: 4 bit only");
+  constexpr int CW = FP16 ? 8 : CWT;                     // columns per chunk = MFMAs per unit = accumulators
+  constexpr int CHB = FP16 ? 16 : CW * BITS / 8;         // bytes per chunk: 12 / 16 (32 codes), 12 (24 codes at 4 bit)
+  constexpr int RDW = (BITS == 3 || CWT == 24) ? 3 : 4;  // dwords a lane loads per row
+  constexpr int NW = 8, NSET = FP16 ? 4 : 2, NJ = CW;    // (packed: a third set spills next to 128 accumulator registers;
+                                                         //  next to the 96 of 24-code chunks it fits and measured 1 us slower)
   constexpr int NJP = NJ + 1;                // red: code columns + 1 pad (chunks on different banks)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const unsigned smem_lds = (unsigned)reinterpret_cast<uintptr_t>(smem_raw);
@@ -553,7 +558,10 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
   const int nsl = p.qr_nsl, ncw = p.qr_ncw;                      // slices, chunks per slice (host plan; S = p.qr_s row sets)
   constexpr int RU = 32 * S;
   const int sl = wv % nsl, wph = wv / nsl, nws = NW / nsl;       // this wave: slice, row phase; waves per slice
-  const int rpw = p.rps / nws;                                   // rows per wave: a multiple of RU, any number of batches
+  // rows per wave: a multiple of RU, any number of batches.  (The two waves of a SIMD do not run at the same speed -- the
+  // one dispatched first leaves the loop at 12 us, the other at 18 us -- but shifting rows from one to the other, 32..192
+  // of 256, changes nothing: the unit loop as a whole streams at 5.8 TB/s, profiles/r04_pv_q_experiments.txt)
+  const int rpw = p.rps / nws;
   const int r0 = wph * rpw;
   const int nw = max(0, min(n - r0, rpw));                       // valid rows of this wave
   const int nwlast = max(nw - 1, 0);
@@ -582,7 +590,7 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
     const unsigned vo = u < nunit ? voff0 + (unsigned)(u * RU) * sc_l : 0x80000000u;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      if (BITS == 3) {
+      if (RDW == 3) {
         const auto v = __builtin_amdgcn_raw_buffer_load_b96(rs, vo + (unsigned)(4 * e) * sc_l, 0, 0);
         r[e][0] = v[0]; r[e][1] = v[1]; r[e][2] = v[2];
       } else {
@@ -652,7 +660,7 @@ __global__ __launch_bounds__(512) void pv_partial_qr_kernel(PvQParams p) {
   // (Requesting the set's next unit right after the windows are formed -- the packed words are dead from there -- was
   //  tried: it keeps two units in flight all the time, but the 32 window registers on top of both sets spill.)
   auto consume = [&](const unsigned (&r)[8][RDW], int u) {
-    constexpr int NB = BITS == 3 ? 4 : 8, NWIN = BITS == 3 ? 2 : 1, NK = BITS == 3 ? 8 : 4;
+    constexpr int NB = BITS == 3 ? CW / 8 : CW / 4, NWIN = BITS == 3 ? 2 : 1, NK = BITS == 3 ? 8 : 4;
     const u32x4 pw = *(const lds_u32x4*)(uintptr_t)(wl_lane + (unsigned)(u * RU * sizeof(h16)));   // u: unit inside the batch
     const h16x8 pop = __builtin_bit_cast(h16x8, pw);
     if (FP16) {
@@ -1107,12 +1115,13 @@ extern "C" size_t palu_pv_workspace_bytes(int H, int G, int L, int Rv) {
 }
 
 static int pv_qr_plan(int G, int L, int Rv, int cw, int* nsl_o, int* ncw_o, int* S_o, int* rps_o);
+static int pv_qr_chunk_width(int Rv, int bits);
 // split count of the register-direct kernel for (G, L, Rv, bits = 3 / 4 / 16): what palu_pv_workspace_bytes has to cover
 // (introspection for tests and tools; 0 for shapes that kernel does not take)
 extern "C" int palu_pv_direct_nsplit(int G, int L, int Rv, int bits) {
   if (G <= 0 || L <= 0 || Rv <= 0 || !(bits == 3 || bits == 4 || bits == 16)) return 0;
-  const int cw = bits == 16 ? 8 : 32;
-  if (Rv % cw != 0 || Rv / cw > 128) return 0;
+  const int cw = pv_qr_chunk_width(Rv, bits);
+  if (cw == 0) return 0;
   int nsl, ncw, S, rps;
   return pv_qr_plan(G, L, Rv, cw, &nsl, &ncw, &S, &rps);
 }
@@ -1131,6 +1140,23 @@ constexpr int PV_QR_NOT_TAKEN = 1;
 // round of 8-wave workgroups (256 VGPRs per wave: one workgroup per CU): CUs / G ranges per group, each cut into
 // nws = 8 / slices wave ranges of whole units (32 S rows); the statistics are computed online, so a wave range may have
 // any number of rows.  Returns the number of ranges.
+// columns per chunk of a register-direct launch: 8 (fp16), 32 or 24 (packed) -- whichever fills more of the 16 MFMA lanes
+// (row sets x chunks of a slice) -- or 0 when the kernel does not take the shape
+static int pv_qr_lanes(int Rv, int cw) {
+  const int nch = Rv / cw;
+  int nsl = 1;
+  while (nsl * 16 < nch) nsl *= 2;
+  const int ncw = (nch + nsl - 1) / nsl;
+  int S = 16 / ncw;
+  if (S > 2) S = 2;
+  return S * ncw;
+}
+static int pv_qr_chunk_width(int Rv, int bits) {
+  if (bits == 16) return (Rv % 8 == 0 && Rv / 8 <= 128) ? 8 : 0;
+  const bool ok32 = Rv % 32 == 0 && Rv / 32 <= 128, ok24 = bits == 4 && Rv % 24 == 0 && Rv / 24 <= 128;
+  if (ok24 && (!ok32 || pv_qr_lanes(Rv, 24) > pv_qr_lanes(Rv, 32))) return 24;
+  return ok32 ? 32 : 0;
+}
 static int pv_qr_plan(int G, int L, int Rv, int cw, int* nsl_o, int* ncw_o, int* S_o, int* rps_o) {
   const int nch = Rv / cw;
   int nsl = 1;
@@ -1161,12 +1187,14 @@ static int pv_qr_launch(const void* scores, int64_t ss_h, const void* mask, cons
     qr16_enabled = e16 ? atoi(e16) : 0;
   }
   const int gs = H / G;
-  const int cw = bits == 16 ? 8 : 32;
+  int cw = pv_qr_chunk_width(Rv, bits);
+  const bool al16 = ((uintptr_t)rows & 15) == 0 && sc_g % 16 == 0 && sc_l % 16 == 0;
+  if (cw == 32 && bits == 4 && !al16) cw = 0;                          // 16-byte chunks are loaded as aligned dwordx4
   const long long row_bytes = (long long)Rv * bits / 8;
   const long long span = (long long)(L - 1) * sc_l + row_bytes;
-  bool ok = (bits == 16 ? qr16_enabled : qr_enabled) && (gs == 1 || gs == 2 || gs == 4) && Rv % cw == 0 && Rv / cw <= 128 &&
+  bool ok = (bits == 16 ? qr16_enabled : qr_enabled) && (gs == 1 || gs == 2 || gs == 4) && cw != 0 &&
             span + 4096ll * sc_l < 0x7FFFFFFFll && ((uintptr_t)rows & 3) == 0 && sc_g % 4 == 0 && sc_l % 4 == 0 &&
-            (bits == 3 || (((uintptr_t)rows & 15) == 0 && sc_g % 16 == 0 && sc_l % 16 == 0)) && pv_exact_rcp(sqrt_d) != 0.f;
+            (bits != 16 || al16) && pv_exact_rcp(sqrt_d) != 0.f;
   if (!ok) return PV_QR_NOT_TAKEN;
   int nsl, ncw, S, rps;
   const int ns = pv_qr_plan(G, L, Rv, cw, &nsl, &ncw, &S, &rps);   // ranges (one workgroup each) = splits seen by pv_combine
@@ -1208,16 +1236,17 @@ static int pv_qr_launch(const void* scores, int64_t ss_h, const void* mask, cons
   p.qr_park_off = (unsigned)ldsr;
   ldsr += (size_t)8 * 3 * 64 * 4 * sizeof(float);
   dim3 gridr(G * ns), blockr(512);
-#define PALU_PVQR2(GSV, BV)                                                                            \
-  {                                                                                                    \
-    if (S == 1) hipLaunchKernelGGL((pv_partial_qr_kernel<GSV, BV, 1>), gridr, blockr, ldsr, s, p);     \
-    else hipLaunchKernelGGL((pv_partial_qr_kernel<GSV, BV, 2>), gridr, blockr, ldsr, s, p);            \
+#define PALU_PVQR2(GSV, BV, CWV)                                                                            \
+  {                                                                                                         \
+    if (S == 1) hipLaunchKernelGGL((pv_partial_qr_kernel<GSV, BV, 1, CWV>), gridr, blockr, ldsr, s, p);     \
+    else hipLaunchKernelGGL((pv_partial_qr_kernel<GSV, BV, 2, CWV>), gridr, blockr, ldsr, s, p);            \
   }
-#define PALU_PVQR(GSV)                        \
-  {                                           \
-    if (bits == 16) PALU_PVQR2(GSV, 16)       \
-    else if (bits == 4) PALU_PVQR2(GSV, 4)    \
-    else PALU_PVQR2(GSV, 3)                   \
+#define PALU_PVQR(GSV)                                      \
+  {                                                         \
+    if (bits == 16) PALU_PVQR2(GSV, 16, 32)                 \
+    else if (bits == 4 && cw == 24) PALU_PVQR2(GSV, 4, 24)  \
+    else if (bits == 4) PALU_PVQR2(GSV, 4, 32)              \
+    else PALU_PVQR2(GSV, 3, 32)                             \
   }
   switch (gs) {
     case 1: PALU_PVQR(1) break;

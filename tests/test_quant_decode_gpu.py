@@ -356,3 +356,28 @@ def test_softmax_pv_q_late_maximum_forces_rescale(bits, Rv, L, spikes):
     c64 = torch.matmul(p64.reshape(G, gs, L), deq.cpu().double()).reshape(H, Rv)
     assert torch.isfinite(ctx).all()
     assert (ctx.cpu().double() - c64).abs().max().item() <= 1.5e-3 * max(1.0, c64.abs().max().item())
+
+
+@pytest.mark.parametrize("Rv,gs,H,L", [(192, 4, 32, 131), (96, 2, 8, 4100), (288, 4, 8, 900), (96, 1, 4, 70), (576, 4, 8, 2500),
+                                       (1536, 4, 4, 333)])
+def test_softmax_pv_q4_in_24_code_chunks(Rv, gs, H, L):
+    """4-bit rows whose 32-code chunks would leave MFMA lanes idle run in 12-byte
+    chunks of 24 codes: against the fp64 softmax on the dequantised latents."""
+    from palu_amd import _lib
+    from palu_amd.kernel import quant as q
+    rng = np.random.default_rng(Rv + L)
+    G = H // gs
+    assert _lib.lib.palu_pv_direct_nsplit(G, L, Rv, 4) > 0
+    scores = torch.from_numpy((rng.standard_normal((H, L)) * 15).astype(np.float16)).to(DEV)
+    v = torch.from_numpy((rng.standard_normal((G, L, Rv)) * rng.uniform(0.2, 3, (G, L, 1))).astype(np.float16)).to(DEV)
+    codes, meta, deq = q.quantize_pack(v, 4, want_dequant=True)
+    ws = torch.empty(_lib.lib.palu_pv_workspace_bytes(H, G, L, Rv), dtype=torch.uint8, device=DEV)
+    ctx = torch.empty(H, Rv, dtype=torch.float16, device=DEV)
+    _lib.check(_lib.lib.palu_softmax_pv_q(scores.data_ptr(), scores.stride(0), 0, codes.data_ptr(), codes.stride(0),
+                                          codes.stride(1), meta.data_ptr(), meta.stride(0), meta.stride(1), ctx.data_ptr(),
+                                          0, 0, ws.data_ptr(), H, G, L, Rv, 4, math.sqrt(128.0), _lib.current_stream()), "pv_q")
+    x = (scores.cpu().float() / math.sqrt(128.0)).half()
+    p64 = torch.softmax(x.double(), dim=-1)
+    c64 = torch.matmul(p64.reshape(G, gs, L), deq.cpu().double()).reshape(H, Rv)
+    assert torch.isfinite(ctx).all()
+    assert (ctx.cpu().double() - c64).abs().max().item() <= 1.5e-3 * max(1.0, c64.abs().max().item())
