@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""us per palu_softmax_pv_q call (partial kernel + merge), back to back:  time_pvq_loop.py BITS RV L [reps]"""
+"""us per palu_softmax_pv_q call (partial kernel + merge), back to back:  time_pvq_loop.py BITS RV_PER_GROUP L [reps]
+(C3: 3 384 65536; C4: 4 192 131072)"""
 import math, sys
 import torch
 from palu_amd import _lib
