@@ -381,3 +381,21 @@ def test_softmax_pv_q4_in_24_code_chunks(Rv, gs, H, L):
     c64 = torch.matmul(p64.reshape(G, gs, L), deq.cpu().double()).reshape(H, Rv)
     assert torch.isfinite(ctx).all()
     assert (ctx.cpu().double() - c64).abs().max().item() <= 1.5e-3 * max(1.0, c64.abs().max().item())
+
+
+@pytest.mark.parametrize("kind", ["pvq3", "pvq4"])
+def test_quantised_pv_cold_start_is_deterministic(kind):
+    """pv_partial_qr_kernel runs waves 4-7 at a raised (static) priority: its first launch in a FRESH process equals its second
+    and third -- 8 processes per kind (the guard the score kernels have in test_two_band_gpu.py)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    outs = []
+    for _ in range(2):
+        procs = [subprocess.Popen([sys.executable, os.path.join(root, "tools", "diag_cold_start.py"), kind], env=env, cwd=root,
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for _ in range(4)]
+        outs += [p.communicate(timeout=600)[0] for p in procs]
+    for o in outs:
+        assert "first!=second: 0  second!=third: 0" in o, o

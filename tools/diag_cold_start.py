@@ -1,5 +1,5 @@
 """First launch vs second / third launch of one kernel in a FRESH process (profiles/r03_shared_b_cold_start.txt):
-    python tools/diag_cold_start.py perhead | shared | q3 | q4 | fused_c5 | fused_c2
+    python tools/diag_cold_start.py perhead | shared | q3 | q4 | fused_c5 | fused_c2 | pvq3 | pvq4
 Run it many times (one process each): a kernel with a start-up race differs in its first launch only."""
 import sys, math, numpy as np, torch
 from palu_amd import _lib
@@ -45,6 +45,20 @@ elif kind in ("fused_c5", "fused_c2"):
                                                  k.stride(0), k.stride(1), v.data_ptr(), v.stride(0), v.stride(1),
                                                  ctx.data_ptr(), ws.data_ptr(), H, G, L, Rk, Rv, D, inv.data_ptr(), 0,
                                                  math.sqrt(D), S()), "decode_attn")
+        return ctx
+elif kind in ("pvq3", "pvq4"):
+    # quantised softmax.PV (pv_partial_qr_kernel: the one kernel that raises a wave priority, statically for its whole loop)
+    bits = 3 if kind == "pvq3" else 4
+    H, G, Rv, L = (32, 8, 384, 65537) if bits == 3 else (32, 8, 192, 131073)
+    scores = t16(H, L, scale=20.0)
+    v = t16(G, L, Rv)
+    codes, meta = q.quantize_pack(v, bits)
+    ws = torch.zeros(_lib.lib.palu_pv_workspace_bytes(H, G, L, Rv), dtype=torch.uint8, device="cuda")
+    def f():
+        ctx = torch.empty(H, Rv, dtype=torch.float16, device="cuda")
+        _lib.check(_lib.lib.palu_softmax_pv_q(scores.data_ptr(), scores.stride(0), 0, codes.data_ptr(), codes.stride(0),
+                                              codes.stride(1), meta.data_ptr(), meta.stride(0), meta.stride(1), ctx.data_ptr(),
+                                              0, 0, ws.data_ptr(), H, G, L, Rv, bits, math.sqrt(D), S()), "pv_q")
         return ctx
 first = f(); torch.cuda.synchronize()
 second = f(); torch.cuda.synchronize()
