@@ -361,8 +361,9 @@ def bench_shared_b(rank_k, rank_v, Lp, steps, dev):
 def bench_prefill(rank_k, rank_v, T, dev):
     """the prompt pass of ONE attention module (LlamaPaluAttention.forward, q_len = T, empty cache) through
     the flash-style prefill kernel -- ms and peak transient memory (above weights, input, output and the cache) for the
-    one-launch form (K~ of every head, V^T of every group, every context row at once: the default up to 6 GiB of transients)
-    and the bounded-workspace form (query chunks x latent groups), fp16 and packed 4-bit caches."""
+    one-launch form (K~ of every head, V^T of every group, every context row at once: the default up to 6 GiB of transients),
+    the bounded-workspace form (query chunks x latent groups), fp16 and packed 4-bit caches, and the kv-panel form (carried
+    softmax state: transients independent of the prompt length)."""
     from torch import nn
     from palu_amd.kernel.palu_attention import LatentCache, LlamaPaluAttention, QuantLatentCache, build_b
 
@@ -384,8 +385,12 @@ def bench_prefill(rank_k, rank_v, T, dev):
     x = torch.randn(1, T, HIDDEN, device=dev, dtype=torch.float16)
     rec = {"workload": "prompt pass of one attention module, %d tokens, rank_k=%d rank_v=%d gs=%d, causal" % (T, rank_k, rank_v, GS)}
     for tag, bits, budget in (("fp16_cache", 16, None), ("fp16_cache_bounded_workspace", 16, 0), ("packed_4bit_cache", 4, None),
-                              ("packed_4bit_cache_bounded_workspace", 4, 0)):
+                              ("packed_4bit_cache_bounded_workspace", 4, 0), ("packed_4bit_cache_kv_panels", 4, "panels")):
         mk = (lambda: LatentCache(capacity=T + 512)) if bits >= 16 else (lambda: QuantLatentCache(bits, capacity=T + 512))
+        panels = budget == "panels"         # kv panels with carried softmax state: transients independent of T (<= 64 MiB)
+        if panels:
+            budget = None
+            m.PREFILL_PANEL_ROWS = 2048
         if budget is not None:
             m.PREFILL_WORKSPACE_BUDGET = budget
         try:
@@ -421,6 +426,8 @@ def bench_prefill(rank_k, rank_v, T, dev):
         finally:
             if budget is not None:
                 del m.PREFILL_WORKSPACE_BUDGET
+            if panels:
+                del m.PREFILL_PANEL_ROWS
         torch.cuda.empty_cache()
     return rec
 

@@ -360,6 +360,18 @@ int palu_prefill_attn_f16(const void* q, int64_t sq_h, int64_t sq_t, const void*
                           const void* vt, int64_t sv_g, int64_t sv_c, void* out, int64_t so_t, int H, int G,
                           int D, int Tq, int Tk, int Rv, int past, int causal, float scale,
                           palu_stream_t stream);
+/* The same over kv PANELS, for prompt passes whose reconstructed keys / transposed values must not exist all at once (the
+ * reference materialises the full K and the [H, T, T] scores, palu_attention.py:199-205): k / vt hold the kv positions
+ * [kv0, kv0 + Tk) only; past_rel = (absolute position of query row 0) - kv0, negative when the panel starts behind the first
+ * query.  The online-softmax state of every (head, query) travels between the launches in fp32: state_o [H][Tq][Rv]
+ * (un-normalised context), state_ml [H][Tq][8] (running maximum + partial sums); palu_prefill_state_bytes(H, Tq, Rv, 0 / 1)
+ * gives their sizes.  first != 0: start from the empty state (the buffers need no initialisation); last != 0: normalise and
+ * write `out` instead of the state.  The panels of one (query chunk, head set) run in ascending kv order on one stream. */
+int palu_prefill_attn_panel_f16(const void* q, int64_t sq_h, int64_t sq_t, const void* k, int64_t sk_h, int64_t sk_t,
+                                const void* vt, int64_t sv_g, int64_t sv_c, void* out, int64_t so_t, int H, int G,
+                                int D, int Tq, int Tk, int Rv, int past_rel, int causal, float scale,
+                                void* state_o, void* state_ml, int first, int last, palu_stream_t stream);
+size_t palu_prefill_state_bytes(int H, int Tq, int Rv, int which);
 
 /* ------------------------------------------------------------------------------------------
  * One-shot peer-to-peer exchange for the head-group-parallel decode step (the reference is single-GPU and

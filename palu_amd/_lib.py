@@ -84,6 +84,9 @@ SIGNATURES = {
     "palu_rope_f16": (i32, [vp, i64, i64, i32, i32, i32, i32, vp, vp]),
     "palu_prefill_attn_f16": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i32, i32, i32, i32, i32, i32,
                                     i32, i32, f32, vp]),
+    "palu_prefill_attn_panel_f16": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i32, i32, i32, i32, i32, i32,
+                                          i32, i32, f32, vp, vp, i32, i32, vp]),
+    "palu_prefill_state_bytes": (sz, [i32, i32, i32, i32]),
     "palu_packed_row_bytes": (sz, [i32, i32]),
     "palu_quantize_pack": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, vp]),
     "palu_quantize_pack_ex": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, i32, f32, vp]),

@@ -37,7 +37,49 @@ struct PfParams {
   int nqt;
   int head_major;     // dispatch order: 0 tile-major (all tiles of a head together), 1 head-major (heavy tiles of ALL heads
                       // first), 2 eight heads at a time, one per XCD, heavy tiles first (default beyond 2048 workgroups)
+  // kv PANELS (palu_prefill_attn_panel_f16): k / vt hold the kv positions [kv0, kv0 + Tk) only and `past` is RELATIVE to the
+  // panel (past_abs - kv0, may be negative: the whole causal logic is in panel-local indices).  The online-softmax state of
+  // every (head, query) is carried from panel to panel in fp32: st_o [H][Tq][Rv] (un-normalised O), st_ml [H][Tq][8]
+  // (running maximum, then the partial sums of the lanes / waves that share a query).  first: start from the empty state;
+  // last: normalise and store fp16 `out` instead of the state.  st_o == nullptr: the one-launch kernel.
+  float* st_o;
+  float* st_ml;
+  int first, last;
 };
+
+// state of one lane: its running maximum, its share of the running sum (slot `ls` of the query's 8 floats) and its O columns
+template <int NB>
+static __device__ __forceinline__ void pf_state_load(const PfParams& p, int h, int qrow, bool qvalid, int c0, int hi, int ls,
+                                                     f32x16 (&acc)[NB], float& m_run, float& l_run) {
+  if (!qvalid) return;
+  const float* ml = p.st_ml + ((int64_t)h * p.Tq + qrow) * 8;
+  m_run = ml[0];
+  l_run = ml[1 + ls];
+  const float* so = p.st_o + ((int64_t)h * p.Tq + qrow) * p.Rv + c0 + 4 * hi;
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+    for (int r2 = 0; r2 < 4; ++r2) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(so + 32 * cb + 8 * r2);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[cb][4 * r2 + e] = v[e];
+    }
+}
+template <int NB>
+static __device__ __forceinline__ void pf_state_store(const PfParams& p, int h, int qrow, bool qvalid, int c0, int hi, int ls,
+                                                      const f32x16 (&acc)[NB], float m_run, float l_run) {
+  if (!qvalid) return;
+  float* ml = p.st_ml + ((int64_t)h * p.Tq + qrow) * 8;
+  ml[0] = m_run;                  // (every lane / wave / column chunk of the query writes the same value)
+  ml[1 + ls] = l_run;
+  float* so = p.st_o + ((int64_t)h * p.Tq + qrow) * p.Rv + c0 + 4 * hi;
+#pragma unroll
+  for (int cb = 0; cb < NB; ++cb)
+#pragma unroll
+    for (int r2 = 0; r2 < 4; ++r2)
+      *reinterpret_cast<f32x4*>(so + 32 * cb + 8 * r2) =
+          f32x4{acc[cb][4 * r2], acc[cb][4 * r2 + 1], acc[cb][4 * r2 + 2], acc[cb][4 * r2 + 3]};
+}
 
 template <int NCB>
 __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(PfParams p) {
@@ -138,6 +180,7 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(PfParams p)
     for (int e = 0; e < 16; ++e) acc_o[cb][e] = 0.f;
   float m_run = -INFINITY;   // running max of the raw scores (scale > 0 is applied inside the exponent)
   float l_run = 0.f;         // this lane's half of the running sum (the halves share m_run)
+  if (p.st_o && !p.first) pf_state_load<NCB>(p, h, qrow, qvalid, c0, hi, hi, acc_o, m_run, l_run);
 
   // K~ A-fragment row of this lane: bits 2 and 3 of the MFMA row swapped (see header)
   const int krow = (n & 0x13) | ((n & 4) << 1) | ((n & 8) >> 1);
@@ -240,6 +283,10 @@ __global__ __launch_bounds__(PF_THREADS, 2) void prefill_attn_kernel(PfParams p)
     __syncthreads();
   }
 
+  if (p.st_o && !p.last) {
+    pf_state_store<NCB>(p, h, qrow, qvalid, c0, hi, hi, acc_o, m_run, l_run);
+    return;
+  }
   // ---- epilogue: 1/l (both halves), fp16 store; lane (t, hi) register r of block cb is column 32cb + (r&3) + 8(r>>2) + 4hi
   {
     const unsigned lb = __float_as_uint(l_run);
@@ -376,6 +423,7 @@ __global__ __launch_bounds__(PFP_THREADS, 1) void prefill_attn_pair_kernel(PfPar
     for (int e = 0; e < 16; ++e) acc_o[cb][e] = 0.f;
   float m_run = -INFINITY;
   float l_run = 0.f;   // this lane's share: its hi-half of this wave's kv half
+  if (p.st_o && !p.first) pf_state_load<NCBH>(p, h, qrow, qvalid, c0, hi, 2 * half + hi, acc_o, m_run, l_run);
 
   // lane-constant LDS byte offsets of the fragments (tile buffer and column block ride in the immediates)
   const int krow = half * 32 + ((n & 0x13) | ((n & 4) << 1) | ((n & 8) >> 1));
@@ -518,6 +566,10 @@ __global__ __launch_bounds__(PFP_THREADS, 1) void prefill_attn_pair_kernel(PfPar
     __syncthreads();                                    // A: maxima + staged tiles visible, exchange slots free
   }
 
+  if (p.st_o && !p.last) {
+    pf_state_store<NCBH>(p, h, qrow, qvalid, c0, hi, 2 * half + hi, acc_o, m_run, l_run);
+    return;
+  }
   // ---- epilogue: total l = both hi halves of both waves of the pair
   {
     const unsigned lb = __float_as_uint(l_run);
@@ -568,14 +620,53 @@ int launch_prefill(const PfParams& p, hipStream_t stream) {
 
 }  // namespace
 
+static int prefill_impl(const void* q, int64_t sq_h, int64_t sq_t, const void* k, int64_t sk_h, int64_t sk_t, const void* vt,
+                        int64_t sv_g, int64_t sv_c, void* out, int64_t so_t, int H, int G, int D, int Tq, int Tk, int Rv,
+                        int past, int causal, float scale, float* st_o, float* st_ml, int first, int last,
+                        palu_stream_t stream);
+
 extern "C" int palu_prefill_attn_f16(const void* q, int64_t sq_h, int64_t sq_t, const void* k, int64_t sk_h, int64_t sk_t,
                                      const void* vt, int64_t sv_g, int64_t sv_c, void* out, int64_t so_t, int H, int G,
                                      int D, int Tq, int Tk, int Rv, int past, int causal, float scale,
                                      palu_stream_t stream) {
+  PALU_REQUIRE(past >= 0, PALU_ERR_ARG, "prefill_attn: negative length");
+  return prefill_impl(q, sq_h, sq_t, k, sk_h, sk_t, vt, sv_g, sv_c, out, so_t, H, G, D, Tq, Tk, Rv, past, causal, scale, nullptr,
+                      nullptr, 1, 1, stream);
+}
+
+// One kv PANEL of a prompt pass whose keys / values do not fit the workspace at once: k / vt hold the kv positions
+// [kv0, kv0 + Tk) only, `past_rel` = (absolute position of the first query) - kv0 (negative when the panel starts behind the
+// first query; a panel that lies entirely in a query tile's causal future leaves that tile's state untouched).  The
+// online-softmax state travels in state_o [H][Tq][Rv] fp32 and state_ml [H][Tq][8] fp32 (palu_prefill_state_bytes):
+// first != 0 starts from the empty state, last != 0 normalises and writes `out` (fp16) instead of the state.  Panels of one
+// (query chunk, head set) are launched in ascending kv order on one stream.  Same results as one launch over all panels
+// up to the fp32 rounding of the rescale order (the running maximum moves at panel boundaries exactly as at tile boundaries).
+extern "C" int palu_prefill_attn_panel_f16(const void* q, int64_t sq_h, int64_t sq_t, const void* k, int64_t sk_h,
+                                           int64_t sk_t, const void* vt, int64_t sv_g, int64_t sv_c, void* out, int64_t so_t,
+                                           int H, int G, int D, int Tq, int Tk, int Rv, int past_rel, int causal,
+                                           float scale, void* state_o, void* state_ml, int first, int last,
+                                           palu_stream_t stream) {
+  PALU_REQUIRE(state_o && state_ml, PALU_ERR_ARG, "prefill_attn_panel: null state");
+  PALU_REQUIRE((((uintptr_t)state_o | (uintptr_t)state_ml) & 15) == 0, PALU_ERR_ARG, "prefill_attn_panel: state must be 16-byte aligned");
+  return prefill_impl(q, sq_h, sq_t, k, sk_h, sk_t, vt, sv_g, sv_c, out, so_t, H, G, D, Tq, Tk, Rv, past_rel, causal, scale,
+                      (float*)state_o, (float*)state_ml, first ? 1 : 0, last ? 1 : 0, stream);
+}
+
+// bytes of (state_o, state_ml) for H heads x Tq queries
+extern "C" size_t palu_prefill_state_bytes(int H, int Tq, int Rv, int which) {
+  if (H <= 0 || Tq <= 0 || Rv <= 0) return 0;
+  return which == 0 ? (size_t)H * Tq * Rv * sizeof(float) : (size_t)H * Tq * 8 * sizeof(float);
+}
+
+static int prefill_impl(const void* q, int64_t sq_h, int64_t sq_t, const void* k, int64_t sk_h, int64_t sk_t, const void* vt,
+                        int64_t sv_g, int64_t sv_c, void* out, int64_t so_t, int H, int G, int D, int Tq, int Tk, int Rv,
+                        int past, int causal, float scale, float* st_o, float* st_ml, int first, int last,
+                        palu_stream_t stream) {
   PALU_REQUIRE(q && k && vt && out, PALU_ERR_ARG, "prefill_attn: null pointer");
   PALU_REQUIRE(H > 0 && G > 0 && H % G == 0, PALU_ERR_ARG, "prefill_attn: bad heads/groups H=%d G=%d", H, G);
   PALU_REQUIRE(D == 128, PALU_ERR_UNSUPPORTED, "prefill_attn: head_dim must be 128 (got %d)", D);
-  PALU_REQUIRE(Tq >= 0 && Tk >= 0 && past >= 0, PALU_ERR_ARG, "prefill_attn: negative length");
+  PALU_REQUIRE(Tq >= 0 && Tk >= 0, PALU_ERR_ARG, "prefill_attn: negative length");
+  PALU_REQUIRE(past > -(1 << 30) && (int64_t)past + Tq < (1 << 30), PALU_ERR_ARG, "prefill_attn: position offset out of range");
   if (Tq == 0) return PALU_OK;
   PALU_REQUIRE(Tk > 0, PALU_ERR_ARG, "prefill_attn: no keys");
   PALU_REQUIRE(Rv > 0 && Rv % 32 == 0, PALU_ERR_UNSUPPORTED, "prefill_attn: latent value rank per group must be a multiple of 32 (got %d)", Rv);
@@ -596,6 +687,7 @@ extern "C" int palu_prefill_attn_f16(const void* q, int64_t sq_h, int64_t sq_t, 
   p.H = H; p.G = G; p.gs = H / G; p.Tq = Tq; p.Tk = Tk; p.Rv = Rv; p.past = past; p.causal = causal ? 1 : 0;
   p.scale_log2 = scale * 1.4426950408889634f;
   p.nqt = (Tq + PF_BM - 1) / PF_BM;
+  p.st_o = st_o; p.st_ml = st_ml; p.first = first; p.last = last;
   {
     static int force = -2;                       // PALU_PREFILL_HEAD_MAJOR = 0 / 1 overrides the size rule
     if (force == -2) {
@@ -611,6 +703,11 @@ extern "C" int palu_prefill_attn_f16(const void* q, int64_t sq_h, int64_t sq_t, 
     const char* e = palu_exp_env("PALU_PREFILL_PAIR");
     use_pair = e ? atoi(e) : 1;
   }
+  // a launch too small to give every CU a workgroup (kv panels under a tight memory bound: few queries x few heads) takes the
+  // 4-wave kernel with the latent columns split over blockIdx.z instead: more, smaller workgroups for the price of recomputed scores
+  const bool small = st_o != nullptr && (int64_t)p.nqt * H * 2 <= palu_num_cus();
+  if (small && Rv % 96 == 0) return launch_prefill<3>(p, s);
+  if (small && Rv % 64 == 0) return launch_prefill<2>(p, s);
   if (use_pair && Rv % 64 == 0 && Rv <= 384) {          // two waves per 32 queries, each half of the latent columns
     switch (Rv / 64) {
       case 1: return launch_prefill_pair<1>(p, s);

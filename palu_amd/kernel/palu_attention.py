@@ -710,6 +710,17 @@ class LlamaPaluAttention(nn.Module):
     # attributes: a deployment that is short of memory lowers the budget.
     PREFILL_WORKSPACE_BUDGET = 6 << 30
     PREFILL_QUERY_CHUNK = 8192
+    # kv PANELS: with PREFILL_PANEL_ROWS > 0 the prompt pass never holds more than one panel of reconstructed keys / transposed
+    # values: query chunks of PREFILL_PANEL_QUERY rows x PREFILL_PANEL_GROUPS latent groups x panels of PREFILL_PANEL_ROWS kv
+    # positions, the online-softmax state carried between the panel launches in fp32 (palu_prefill_attn_panel_f16).  Transient
+    # memory is independent of the prompt length -- per (chunk of t queries, ng groups, panel of C rows), in bytes:
+    #   2 t H (D + Rv) [q, context rows]  +  4 ng gs t (Rv + 8) [state]  +  2 ng C (gs D + Rv) [K~, V^T]
+    #   (+ 2 ng C (Rk + Rv) de-quantised rows of a packed cache)  ~ 55 MiB at the defaults and the config-2 ranks --
+    # at the price of small launches (t / 128 x ng x gs workgroups) and of rebuilding K~ per (chunk, panel): a mode for
+    # memory-starved deployments, off by default.
+    PREFILL_PANEL_ROWS = 0
+    PREFILL_PANEL_QUERY = 512
+    PREFILL_PANEL_GROUPS = 4
 
     def _prefill_flash(self, hidden_states, pos, cache, causal: bool):
         """Prompt branch (:196-257) on the flash-style HIP kernel: scores are never materialised.
@@ -727,13 +738,17 @@ class LlamaPaluAttention(nn.Module):
         past = cache.get_seq_length(li)
         dev, dt = hidden_states.device, hidden_states.dtype
         kv_all = past + q_len
+        panel_rows = int(self.PREFILL_PANEL_ROWS)
         # what the one-launch form would allocate: K~ for every head, V^T of every group, the context rows
         one_launch_bytes = 2 * (H * kv_all * D + G * Rv * (kv_all + 63) + q_len * H * Rv)
         packed = not isinstance(cache, LatentCache)
         if packed:
             one_launch_bytes += 2 * kv_all * G * (Rk + Rv)          # the dequantised rows
-        grouped = one_launch_bytes > self.PREFILL_WORKSPACE_BUDGET
+        grouped = one_launch_bytes > self.PREFILL_WORKSPACE_BUDGET or panel_rows > 0
         qc = self.PREFILL_QUERY_CHUNK if grouped else q_len
+        if panel_rows > 0:
+            panel_rows = max(64, panel_rows // 64 * 64)
+            qc = max(128, int(self.PREFILL_PANEL_QUERY))
         inv = rope_inv_freq(dev, D, self.rope_theta)
         stream = _lib.current_stream()
         pos = pos.reshape(-1)
@@ -767,6 +782,9 @@ class LlamaPaluAttention(nn.Module):
             ctx = torch.empty((t, H * Rv), dtype=dt, device=dev)
             if not grouped:
                 groups = [list(range(G))]
+            elif panel_rows > 0:
+                ngl = max(1, min(G, int(self.PREFILL_PANEL_GROUPS)))
+                groups = [list(range(g, min(G, g + ngl))) for g in range(0, G, ngl)]
             else:
                 # enough latent groups per launch for >= 512 workgroups (2 per CU): one workgroup = 128 queries of one head
                 per_group = gs * ((t + 127) // 128)
@@ -775,6 +793,9 @@ class LlamaPaluAttention(nn.Module):
             for gl in groups:
                 ng = len(gl)
                 g0 = gl[0]
+                if panel_rows > 0:
+                    self._prefill_panels(cache, q, ctx, g0, ng, kv, past + c0, panel_rows, causal, u_ok, inv, stream)
+                    continue
                 xk, xv = self._latent_rows(cache, g0, ng, kv)                             # [ng, kv, Rk], [ng, kv, Rv] fp16
                 keys = torch.empty((ng * gs, kv, D), dtype=dt, device=dev)
                 if u_ok:
@@ -817,19 +838,71 @@ class LlamaPaluAttention(nn.Module):
             del o
         return out.view(1, q_len, -1)
 
-    def _latent_rows(self, cache, g0: int, ng: int, kv: int):
-        """fp16 latent rows [ng, kv, R] of groups g0..g0+ng-1: views of an fp16 cache, de-quantised copies (of these groups
-        only) of a packed one."""
+    def _prefill_panels(self, cache, q, ctx, g0, ng, kv, qpos0, C, causal, u_ok, inv, stream):
+        """The latent groups g0..g0+ng-1 of one query chunk (q [H, t, D] rotated, first row at absolute position qpos0) over
+        the kv positions 0..kv-1 in panels of C rows: per panel K~ = RoPE(X_k . B) and V^T are built for the panel only and
+        palu_prefill_attn_panel_f16 folds it into the carried online-softmax state; the last panel writes the context rows."""
+        H, D, gs = self.num_heads, self.head_dim, self.group_size
+        Rk, Rv = self.group_rank_k, self.group_rank_v
+        dev, dt = q.device, q.dtype
+        t = q.shape[1]
+        nh = ng * gs
+        st_o = torch.empty(_lib.lib.palu_prefill_state_bytes(nh, t, Rv, 0) // 4, dtype=torch.float32, device=dev)
+        st_ml = torch.empty(_lib.lib.palu_prefill_state_bytes(nh, t, Rv, 1) // 4, dtype=torch.float32, device=dev)
+        qg = q[g0 * gs:(g0 + ng) * gs]
+        cg = ctx[:, g0 * gs * Rv:]
+        starts = list(range(0, kv, C))
+        cmax = min(C, kv)
+        keys = torch.empty((nh, cmax, D), dtype=dt, device=dev)
+        vt = torch.empty((ng, Rv, (cmax + 63) // 64 * 64), dtype=dt, device=dev)
+        for pi, k0 in enumerate(starts):
+            n = min(kv, k0 + C) - k0
+            xk, xv = self._latent_rows(cache, g0, ng, k0 + n, k0)                          # [ng, n, Rk], [ng, n, Rv] fp16
+            kp = keys[:, :n]
+            if u_ok:
+                for j in range(ng):
+                    u = self.k_proj.U_list[g0 + j]
+                    xg = xk[j]
+                    _lib.check(_lib.lib.palu_lowrank_project_gemm(xg.data_ptr(), xg.stride(0), u.weight.data_ptr(),
+                                                                  u.weight.stride(0), kp[j * gs].data_ptr(), kp.stride(0),
+                                                                  kp.stride(1), n, gs * D, Rk, D, 0, stream),
+                               "palu_lowrank_project_gemm")
+                _lib.check(_lib.lib.palu_rope_f16(kp.data_ptr(), kp.stride(0), kp.stride(1), nh, n, D, k0, inv.data_ptr(), stream),
+                           "palu_rope_f16")
+            else:
+                kc, ks = self._rope_tables(torch.arange(k0, k0 + n, device=dev), dt)
+                b = self.k_proj.B.view(self.num_groups, gs, Rk, D)[g0:g0 + ng]
+                kk = torch.matmul(xk.unsqueeze(1), b).view(nh, n, D)
+                kp.copy_(kk * kc.view(1, n, D) + _rotate_half(kk) * ks.view(1, n, D))
+                del kk
+            n_pad = (n + 63) // 64 * 64
+            vp = vt[:, :, :n_pad]
+            if n_pad != n:
+                vp[:, :, n:].zero_()
+            vp[:, :, :n].copy_(xv.transpose(1, 2))
+            del xk, xv
+            _lib.check(_lib.lib.palu_prefill_attn_panel_f16(qg.data_ptr(), qg.stride(0), qg.stride(1), kp.data_ptr(), kp.stride(0),
+                                                            kp.stride(1), vp.data_ptr(), vp.stride(0), vp.stride(1),
+                                                            cg.data_ptr(), ctx.stride(0), nh, ng, D, t, n, Rv, qpos0 - k0,
+                                                            1 if causal else 0, 1.0 / math.sqrt(D), st_o.data_ptr(),
+                                                            st_ml.data_ptr(), 1 if pi == 0 else 0,
+                                                            1 if pi == len(starts) - 1 else 0, stream),
+                       "palu_prefill_attn_panel_f16")
+
+    def _latent_rows(self, cache, g0: int, ng: int, kv: int, k0: int = 0):
+        """fp16 latent rows [ng, kv - k0, R] (positions k0..kv-1) of groups g0..g0+ng-1: views of an fp16 cache, de-quantised
+        copies (of these groups and rows only) of a packed one."""
         li = self.layer_idx
         if isinstance(cache, LatentCache):
             kbuf, vbuf = cache.buffers(li)
-            return kbuf[0, g0:g0 + ng, :kv], vbuf[0, g0:g0 + ng, :kv]
+            return kbuf[0, g0:g0 + ng, k0:kv], vbuf[0, g0:g0 + ng, k0:kv]
         from .quant import unpack_dequant
         st = cache.buffers(li)
         gsz = cache.group_size
+        kv = kv - k0
 
         def deq(codes, meta, R):
-            c, m = codes[0, g0:g0 + ng, :kv], meta[0, g0:g0 + ng, :kv]
+            c, m = codes[0, g0:g0 + ng, k0:k0 + kv], meta[0, g0:g0 + ng, k0:k0 + kv]
             if not gsz:
                 return unpack_dequant(c.contiguous(), m.contiguous(), cache.n_bits, R)
             nb = gsz * cache.n_bits // 8

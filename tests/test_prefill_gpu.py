@@ -349,3 +349,152 @@ def test_prefill_transient_memory_is_bounded():
     bounded, mem_b = run(0)
     torch.testing.assert_close(bounded.float(), one.float(), rtol=2e-3, atol=2e-3)
     assert mem_b < 0.5 * mem_one and mem_b < 768 << 20, (mem_b / 2 ** 20, mem_one / 2 ** 20)
+
+
+def prefill_attn_panels(q, k, v_lat, past, causal, C):
+    """The same through palu_prefill_attn_panel_f16: kv panels of C rows, fp32 state between the launches."""
+    lib = _lib()
+    H, Tq, D = q.shape
+    Tk = k.shape[1]
+    G, _, Rv = v_lat.shape
+    out = torch.full((Tq, H * Rv), float("nan"), dtype=torch.float16, device=DEV)
+    st_o = torch.full((lib.lib.palu_prefill_state_bytes(H, Tq, Rv, 0) // 4,), float("nan"), dtype=torch.float32, device=DEV)
+    st_ml = torch.full((lib.lib.palu_prefill_state_bytes(H, Tq, Rv, 1) // 4,), float("nan"), dtype=torch.float32, device=DEV)
+    starts = list(range(0, Tk, C))
+    for pi, k0 in enumerate(starts):
+        n = min(Tk, k0 + C) - k0
+        kp = k[:, k0:k0 + n].contiguous()
+        pad = (n + 63) // 64 * 64
+        vt = torch.zeros(G, Rv, pad, dtype=torch.float16, device=DEV)
+        vt[:, :, :n].copy_(v_lat[:, k0:k0 + n].transpose(1, 2))
+        lib.check(lib.lib.palu_prefill_attn_panel_f16(q.data_ptr(), q.stride(0), q.stride(1), kp.data_ptr(), kp.stride(0),
+                                                      kp.stride(1), vt.data_ptr(), vt.stride(0), vt.stride(1), out.data_ptr(),
+                                                      out.stride(0), H, G, D, Tq, n, Rv, past - k0, 1 if causal else 0,
+                                                      1.0 / math.sqrt(D), st_o.data_ptr(), st_ml.data_ptr(),
+                                                      1 if pi == 0 else 0, 1 if pi == len(starts) - 1 else 0,
+                                                      torch.cuda.current_stream().cuda_stream), "prefill_attn_panel")
+    return out
+
+
+@pytest.mark.parametrize("H,gs,Tq,Tk,Rv,causal,C", [
+    (8, 4, 300, 300, 384, True, 64), (8, 4, 300, 300, 384, True, 128), (32, 4, 257, 1000, 384, True, 448),
+    (8, 4, 130, 130, 96, True, 64), (8, 2, 200, 700, 448, True, 192), (4, 2, 70, 333, 64, False, 100 // 64 * 64 + 64),
+    (8, 4, 129, 129, 192, True, 1024), (4, 4, 1, 500, 384, True, 128), (8, 4, 640, 640, 256, True, 320)])
+def test_prefill_panels_equal_one_launch(H, gs, Tq, Tk, Rv, causal, C):
+    """kv panels with the carried online-softmax state (palu_prefill_attn_panel_f16) against the one-launch kernel and the
+    fp32 restatement: panels that end inside a 64-row tile, panels wholly in a query tile's causal future (its state passes
+    through), a single panel, both kernel variants (two waves per 32 queries for Rv <= 384, column chunks above)."""
+    rng = np.random.default_rng(H + Tq + Tk + Rv + C)
+    G = H // gs
+    past = Tk - Tq
+    q = torch.from_numpy(rng.standard_normal((H, Tq, 128)).astype(np.float16)).to(DEV)
+    k = torch.from_numpy(rng.standard_normal((H, Tk, 128)).astype(np.float16)).to(DEV)
+    v = torch.from_numpy(rng.standard_normal((G, Tk, Rv)).astype(np.float16)).to(DEV)
+    scale = 1.0 / math.sqrt(128.0)
+    one = prefill_attn(q, k, v, past, causal)
+    pan = prefill_attn_panels(q, k, v, past, causal, C)
+    ref = ref_attn_f32(q, k, v, past, causal, scale)
+    assert torch.isfinite(pan.float()).all()
+    tol = 2e-3 * max(1.0, ref.abs().max().item())
+    assert (pan.float() - ref).abs().max().item() <= tol
+    assert (pan.float() - one.float()).abs().max().item() <= tol
+
+
+def _c2_module(T_warm=256):
+    from palu_amd.kernel.palu_attention import LlamaPaluAttention, QuantLatentCache, build_b
+    hidden, H, D, gs, rank_k, rank_v = 4096, 32, 128, 4, 1024, 3072
+
+    class Cfg:
+        pass
+    cfg = Cfg()
+    cfg.hidden_size, cfg.num_attention_heads, cfg.attention_bias = hidden, H, False
+    cfg.group_size, cfg.num_groups, cfg.total_rank_k, cfg.total_rank_v = gs, H // gs, rank_k, rank_v
+    torch.manual_seed(0)
+    with torch.device(DEV):
+        m = LlamaPaluAttention(cfg, 0).half()
+        with torch.no_grad():
+            for lin in (m.q_proj, m.k_proj.VT, m.v_proj.VT, m.o_proj):
+                lin.weight.normal_(0.0, 0.02)
+            for u in m.k_proj.U_list:
+                u.weight.normal_(0.0, 128 ** -0.5)
+        m.k_proj.B = nn.Parameter(build_b([u.weight for u in m.k_proj.U_list], gs, D))
+    m = m.eval().prepare_decode()
+    with torch.no_grad():
+        m(torch.randn(1, T_warm, hidden, device=DEV, dtype=torch.float16), past_key_value=QuantLatentCache(4), is_causal=True)
+    return m
+
+
+@pytest.mark.parametrize("bits", [16, 4])
+def test_prefill_module_in_panels_equals_one_launch(bits):
+    """The prompt pass of a config-2 module in kv panels (PREFILL_PANEL_ROWS) -- two prompt chunks, so the second one has a
+    past -- equals the one-launch pass and leaves the same cache rows."""
+    from palu_amd.kernel.palu_attention import LatentCache, QuantLatentCache
+    m = _c2_module()
+    T = 2300
+    x = torch.randn(1, T, 4096, device=DEV, dtype=torch.float16)
+    mk = (lambda: LatentCache()) if bits == 16 else (lambda: QuantLatentCache(bits))
+
+    def run(panel):
+        cache = mk()
+        if panel:
+            m.PREFILL_PANEL_ROWS, m.PREFILL_PANEL_QUERY, m.PREFILL_PANEL_GROUPS = 448, 256, 3
+        try:
+            with torch.no_grad():
+                a, _, _ = m(x[:, :1500], past_key_value=cache, is_causal=True)
+                b, _, _ = m(x[:, 1500:], past_key_value=cache, is_causal=True)
+        finally:
+            if panel:
+                del m.PREFILL_PANEL_ROWS, m.PREFILL_PANEL_QUERY, m.PREFILL_PANEL_GROUPS
+        return torch.cat((a, b), dim=1), cache
+    ref, c1 = run(False)
+    out, c2 = run(True)
+    assert c1.get_seq_length(0) == c2.get_seq_length(0) == T
+    torch.testing.assert_close(out.float(), ref.float(), rtol=2e-3, atol=2e-3)
+    if bits == 16:
+        for a, b in zip(c1.buffers(0), c2.buffers(0)):
+            assert torch.equal(a[:, :, :T], b[:, :, :T])
+    else:
+        # the packed path projects each query chunk with a torch GEMM, whose rounding depends on the chunk's row count (1500
+        # rows at once vs 256-row chunks): (scale, zero) pairs agree to fp16 rounding, codes almost everywhere
+        for k in ("km", "vm"):
+            torch.testing.assert_close(c1.buffers(0)[k][:, :, :T].float(), c2.buffers(0)[k][:, :, :T].float(), rtol=1e-2, atol=1.0)
+        for k in ("kc", "vc"):
+            same = (c1.buffers(0)[k][:, :, :T] == c2.buffers(0)[k][:, :, :T]).float().mean().item()
+            assert same > 0.97, same
+
+
+def test_prefill_in_panels_needs_64_mib_at_64k_tokens():
+    """peak EXTRA memory of a 64k-token prompt pass into a packed (4-bit) cache <= 64 MiB -- the kv-panel
+    form at its defaults (512 queries x 4 latent groups x 2048-row panels): no transient grows with the prompt."""
+    from palu_amd.kernel.palu_attention import QuantLatentCache
+    m = _c2_module()
+    H, gs, rank_k, rank_v, T = 32, 4, 1024, 3072, 65536
+    x = torch.randn(1, T, 4096, device=DEV, dtype=torch.float16)
+    cache = QuantLatentCache(4, capacity=T + 512)
+    cache.reserve(0, T + 512, H // gs, rank_k // (H // gs), rank_v // (H // gs), x.device)
+    m.PREFILL_PANEL_ROWS = 2048
+    try:
+        with torch.no_grad():
+            m(x[:, :1024], past_key_value=QuantLatentCache(4), is_causal=True)       # the panel path's own warm-up
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        with torch.no_grad():
+            out, _, _ = m(x, past_key_value=cache, is_causal=True)
+        torch.cuda.synchronize()
+        extra = torch.cuda.max_memory_allocated() - base - out.numel() * 2
+    finally:
+        del m.PREFILL_PANEL_ROWS
+    assert cache.get_seq_length(0) == T
+    assert torch.isfinite(out.float()).all()
+    assert extra <= 64 << 20, extra / 2 ** 20
+    # the last rows against the one-launch kernel on the same cache contents: rows T-256.. as a chunk with a past
+    ref_cache = QuantLatentCache(4, capacity=T + 512)
+    ref_cache.reserve(0, T + 512, H // gs, rank_k // (H // gs), rank_v // (H // gs), x.device)
+    for k in ("kc", "km", "vc", "vm"):
+        ref_cache.buffers(0)[k][:, :, :T - 256].copy_(cache.buffers(0)[k][:, :, :T - 256])
+    ref_cache.advance(0, T - 256)
+    with torch.no_grad():
+        tail, _, _ = m(x[:, T - 256:], past_key_value=ref_cache, is_causal=True)
+    torch.testing.assert_close(out[:, T - 256:].float(), tail.float(), rtol=2e-3, atol=2e-3)
