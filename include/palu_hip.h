@@ -331,6 +331,18 @@ int palu_decode_step_q(const void* hidden,
 int palu_lowrank_project_gemm(const void* x, int64_t ldx, const void* w, int64_t ldw,
                               void* out, int64_t so_g, int64_t so_l,
                               int M, int N, int K, int R, int row0, palu_stream_t stream);
+/* The same with a fused quantise + pack epilogue (a packed-cache prompt pass never materialises fp16
+ * latents): the tile's (token, group) rows are quantised as quantize_tensor does with the reference defaults (asymmetric,
+ * group_size 0, clip_ratio 1: palu/model/modules/quant.py:29-39; svd_linear.py:124-139) and written as packed rows
+ *   codes[(n / R) * sc_g + (row0 + m) * sc_l + ...]  (bytes; a row = R * bits / 8 bytes, the layout of palu_quantize_pack)
+ *   meta [(n / R) * sm_g + (row0 + m) * sm_l + {0, 1}] = (scale, zero) fp16 (elements)
+ * bit-identical to palu_lowrank_project_gemm followed by palu_quantize_pack.  bits = 3 / 4.  The fused tile needs whole groups
+ * per workgroup (32 NI | R, R | 128 NI, N % (128 NI) == 0 for an NI in {1, 2, 3}) and M >= 512, N >= 256, K >= 512:
+ * palu_lowrank_project_gemm_q_supported says whether a shape qualifies; otherwise PALU_ERR_UNSUPPORTED (run the two calls). */
+int palu_lowrank_project_gemm_q(const void* x, int64_t ldx, const void* w, int64_t ldw,
+                                void* codes, int64_t sc_g, int64_t sc_l, void* meta, int64_t sm_g, int64_t sm_l,
+                                int M, int N, int K, int R, int row0, int bits, palu_stream_t stream);
+int palu_lowrank_project_gemm_q_supported(int M, int N, int K, int R, int bits);
 
 /* ------------------------------------------------------------------------------------------
  * In-place rotary embedding of x [H, T, D] fp16 (strides sx_h, sx_t; D contiguous), row t at position

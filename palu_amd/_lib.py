@@ -81,6 +81,8 @@ SIGNATURES = {
                                   vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64,
                                   vp, vp, vp, vp, i64, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "palu_lowrank_project_gemm": (i32, [vp, i64, vp, i64, vp, i64, i64, i32, i32, i32, i32, i32, vp]),
+    "palu_lowrank_project_gemm_q": (i32, [vp, i64, vp, i64, vp, i64, i64, vp, i64, i64, i32, i32, i32, i32, i32, i32, vp]),
+    "palu_lowrank_project_gemm_q_supported": (i32, [i32, i32, i32, i32, i32]),
     "palu_rope_f16": (i32, [vp, i64, i64, i32, i32, i32, i32, vp, vp]),
     "palu_prefill_attn_f16": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i32, i32, i32, i32, i32, i32,
                                     i32, i32, f32, vp]),

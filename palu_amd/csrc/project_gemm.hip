@@ -18,6 +18,9 @@ struct PgParams {
   const h16* w;  int64_t ldw;       // [N, K]
   h16* out;      int64_t so_g, so_l; // out[(n / R) * so_g + (row0 + m) * so_l + n % R]
   int M, N, K, R, row0;
+  // fused quantise + pack epilogue (project_gemm_256_kernel<NI, 3 | 4>): packed rows and (scale, zero) pairs of the latent cache
+  unsigned char* codes; int64_t sc_g, sc_l;   // bytes: codes[(n / R) * sc_g + (row0 + m) * sc_l + bit stream of the row]
+  h16* meta;            int64_t sm_g, sm_l;   // elements: meta[(n / R) * sm_g + (row0 + m) * sm_l + {0, 1}]
 };
 
 __device__ __forceinline__ int pg_swz(int row, int c) { return c ^ ((row >> 1) & 7); }   // 128-byte rows, 8 chunks
@@ -121,7 +124,14 @@ __global__ __launch_bounds__(PG_THREADS, 2) void project_gemm_kernel(PgParams p)
 // its column tiles back to back, so the X rows of a token tile are fetched into ONE L2.
 constexpr int PL_BM = 256, PL_THREADS = 512;   // column tile: 128 * NI (NI = 2: 256 x 256; NI = 1: 256 x 128 for grids that would not fill the chip)
 
-template <int NI>
+// QB = 3 / 4: the tile is not stored as fp16 latents but quantised and packed in the epilogue -- quantize_tensor's
+// asymmetric per-(token, group) row form (palu/model/modules/quant.py:29-39 with the reference defaults group_size = 0,
+// clip_ratio = 1; csrc/quant.hip has the op-by-op fp16 semantics), bit-identical to this kernel's fp16 output run through
+// palu_quantize_pack.  A workgroup's 128 NI columns hold whole groups (host: 32 NI | R, R | 128 NI): the R / (32 NI) waves of
+// a group exchange their row minima / maxima through the (then free) LDS, every lane derives (scale, zero) itself, codes its
+// 16 NI values per token, and lane pairs (kb = 0, 1: columns 8q .. 8q+3 / 8q+4 .. 8q+7) assemble 32 codes = 16 / 12 bytes
+// per store.  The fp16 latents of a packed-cache prompt pass never exist in memory.
+template <int NI, int QB = 0>
 __global__ __launch_bounds__(PL_THREADS, 1) void project_gemm_256_kernel(PgParams p, int ntn, int ntm) {
   extern __shared__ __attribute__((aligned(1024))) char smem_l[];   // [buf][X 256 rows | VT 128 NI rows][64 halfs] = 2 x (32 + 16 NI) KB
   constexpr int PL_BN = 128 * NI;
@@ -149,9 +159,9 @@ __global__ __launch_bounds__(PL_THREADS, 1) void project_gemm_256_kernel(PgParam
   const int prow = lane >> 3, key = (4 * (wv & 1) + (lane >> 4)) & 7, csrc = (lane & 7) ^ key;
   unsigned xvo[4], wvo[2 * NI];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < (2 * NI > 4 ? 2 * NI : 4); ++i) {
     const int row = 8 * (wv + 8 * i) + prow;
-    xvo[i] = (unsigned)(min(row, p.M - 1 - m0) * (int)p.ldx * 2 + csrc * 16);
+    if (i < 4) xvo[i] = (unsigned)(min(row, p.M - 1 - m0) * (int)p.ldx * 2 + csrc * 16);
     if (i < 2 * NI) wvo[i] = (unsigned)(min(row, p.N - 1 - n0) * (int)p.ldw * 2 + csrc * 16);
   }
   const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>(smem_l);
@@ -168,8 +178,8 @@ __global__ __launch_bounds__(PL_THREADS, 1) void project_gemm_256_kernel(PgParam
     const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)kt * (PG_BK * 2));
     const unsigned d = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * BUF + wv * 1024));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      dma(d + i * 8192, xvo[i], xrs, soff);
+    for (int i = 0; i < (2 * NI > 4 ? 2 * NI : 4); ++i) {
+      if (i < 4) dma(d + i * 8192, xvo[i], xrs, soff);
       if (i < 2 * NI) dma(d + TILE + i * 8192, wvo[i], wrs, soff);
     }
   };
@@ -211,6 +221,90 @@ __global__ __launch_bounds__(PL_THREADS, 1) void project_gemm_256_kernel(PgParam
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
+  if (QB != 0) {
+    constexpr float QMAX = (float)((1 << QB) - 1);
+    float* mm = reinterpret_cast<float*>(smem_l);            // [wm 2][wn 4][128 tokens][min, max]: the tiles are consumed
+    const int wpg = p.R / (32 * NI);                         // waves per latent group: 1, 2 or 4
+    const int wn0 = wn / wpg * wpg;
+    // round to fp16 once (the value the unfused path would have stored), row extrema of this wave's 32 NI columns
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      float mx = -INFINITY, mn = INFINITY;
+#pragma unroll
+      for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const float v = (float)(h16)acc[i][jj][e];
+          acc[i][jj][e] = v;
+          mx = fmaxf(mx, v);
+          mn = fminf(mn, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mn = fminf(mn, __shfl_xor(mn, 32));
+      if (kb == 0) {
+        float* d = mm + ((wm * 4 + wn) * 128 + jj * 32 + fr) * 2;
+        d[0] = mn;
+        d[1] = mx;
+      }
+    }
+    __syncthreads();
+    const int nw0 = n0 + wn * 32 * NI;                       // first column of this wave
+    const int g = nw0 / p.R, cg0 = nw0 - g * p.R;            // its group, its first column inside the group
+    const float floor16 = (float)(h16)1e-5f;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      float mx = -INFINITY, mn = INFINITY;
+      for (int k = 0; k < wpg; ++k) {
+        const float* d = mm + ((wm * 4 + wn0 + k) * 128 + jj * 32 + fr) * 2;
+        mn = fminf(mn, d[0]);
+        mx = fmaxf(mx, d[1]);
+      }
+      // quant.py:29-38 (csrc/quant.hip quantize_row, asymmetric, clip 1): every op an fp32 op on fp16 values, rounded once
+      float range = (float)(h16)(mx - mn);
+      range = fmaxf(range, floor16);
+      const float scale = (float)(h16)(range / QMAX);
+      float zero = rintf((float)(h16)(-mn / scale));
+      zero = fminf(fmaxf(zero, 0.f), QMAX);
+      const int m = m0 + wm * 128 + jj * 32 + fr;
+      const bool valid = m < p.M;
+      if (valid && kb == 0 && wn == wn0) {
+        h16* md = p.meta + (int64_t)g * p.sm_g + (int64_t)(p.row0 + m) * p.sm_l;
+        md[0] = (h16)scale;
+        md[1] = (h16)zero;
+      }
+      unsigned char* crow = p.codes + (int64_t)g * p.sc_g + (int64_t)(p.row0 + m) * p.sc_l;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        unsigned u[4], pu[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          u[q] = 0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float qv = (float)(h16)(rintf((float)(h16)(acc[i][jj][4 * q + r] / scale)) + zero);   // quant.py:39
+            qv = fminf(fmaxf(qv, 0.f), QMAX);
+            u[q] |= (unsigned)qv << (QB * r);
+          }
+          pu[q] = (unsigned)__shfl_xor((int)u[q], 32);       // the partner lane's columns 8q + 4 .. 8q + 7
+        }
+        if (valid && kb == 0) {
+          const int cg = cg0 + 32 * i;                       // 32 codes from column cg of the group's row
+          if (QB == 4) {
+            *reinterpret_cast<u32x4*>(crow + cg / 2) = u32x4{u[0] | (pu[0] << 16), u[1] | (pu[1] << 16), u[2] | (pu[2] << 16),
+                                                             u[3] | (pu[3] << 16)};
+          } else {
+            const unsigned t0 = u[0] | (pu[0] << 12), t1 = u[1] | (pu[1] << 12), t2 = u[2] | (pu[2] << 12),
+                           t3 = u[3] | (pu[3] << 12);        // 24 bits each
+            unsigned* d = reinterpret_cast<unsigned*>(crow + cg * 3 / 8);
+            d[0] = t0 | (t1 << 24);
+            d[1] = (t1 >> 8) | (t2 << 16);
+            d[2] = (t2 >> 16) | (t3 << 8);
+          }
+        }
+      }
+    }
+    return;
+  }
   // C^T tiles: lane column (lane & 31) = token, rows = latent columns (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5): a lane
   // holds 4 consecutive latent columns of one token (N % R == 0 and R % 4 == 0: never across a group boundary)
 #pragma unroll
@@ -232,6 +326,71 @@ __global__ __launch_bounds__(PL_THREADS, 1) void project_gemm_256_kernel(PgParam
 }
 
 }  // namespace
+
+// tile width (NI) of the fused quantise epilogue for group rank R over N columns: whole groups per workgroup
+// (32 NI | R, R | 128 NI, N % (128 NI) == 0); 0 = the shape stays on the unfused path
+static int pgq_ni(int M, int N, int K, int R, int64_t ldx, int64_t ldw) {
+  const bool large = M >= 512 && N >= 256 && K >= 512 && 256 * ldx * 2 < (int64_t(1) << 31) && 384 * ldw * 2 < (int64_t(1) << 31);
+  if (!large || K % PG_BK != 0 || R <= 0 || N % R != 0) return 0;
+  auto ok = [&](int ni) { return R % (32 * ni) == 0 && (128 * ni) % R == 0 && N % (128 * ni) == 0; };
+  const int ntm = (M + PL_BM - 1) / PL_BM;
+  if (ok(2) && (int64_t)ntm * (N / 256) >= palu_num_cus()) return 2;
+  if (ok(1)) return 1;
+  if (ok(2)) return 2;
+  if (ok(3)) return 3;
+  return 0;
+}
+
+extern "C" int palu_lowrank_project_gemm_q_supported(int M, int N, int K, int R, int bits) {
+  if (!(bits == 3 || bits == 4)) return 0;
+  return pgq_ni(M, N, K, R, K, K) != 0 ? 1 : 0;
+}
+
+// The projection with the quantise + pack epilogue: X [M, K] . VT^T [N, K] -> packed rows codes[(n / R)][row0 + m] (byte
+// strides sc_g, sc_l; a row is R * bits / 8 bytes) and meta[(n / R)][row0 + m] = (scale, zero) fp16 (element strides sm_g,
+// sm_l) -- asymmetric per-(token, group) rows, clip 1, group_size 0 (the reference defaults).  Bit-identical to
+// palu_lowrank_project_gemm followed by palu_quantize_pack.  PALU_ERR_UNSUPPORTED for shapes the fused tile does not take
+// (palu_lowrank_project_gemm_q_supported): run the two calls instead.
+extern "C" int palu_lowrank_project_gemm_q(const void* x, int64_t ldx, const void* w, int64_t ldw, void* codes, int64_t sc_g,
+                                           int64_t sc_l, void* meta, int64_t sm_g, int64_t sm_l, int M, int N, int K, int R,
+                                           int row0, int bits, palu_stream_t stream) {
+  PALU_REQUIRE(x && w && codes && meta && M >= 0 && N > 0 && K > 0 && R > 0 && row0 >= 0, PALU_ERR_ARG, "project_gemm_q: bad arguments");
+  PALU_REQUIRE(bits == 3 || bits == 4, PALU_ERR_UNSUPPORTED, "project_gemm_q: bits must be 3 or 4");
+  PALU_REQUIRE(ldx % 8 == 0 && ldw % 8 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0, PALU_ERR_ARG,
+               "project_gemm_q: X / VT rows must be 16-byte aligned");
+  const int align = bits == 4 ? 16 : 4;
+  PALU_REQUIRE(((uintptr_t)codes % align) == 0 && sc_g % align == 0 && sc_l % align == 0 && sc_l >= (int64_t)R * bits / 8,
+               PALU_ERR_ARG, "project_gemm_q: packed rows must be %d-byte aligned", align);
+  PALU_REQUIRE(((uintptr_t)meta & 3) == 0 && sm_g % 2 == 0 && sm_l % 2 == 0 && sm_l >= 2, PALU_ERR_ARG,
+               "project_gemm_q: meta rows must be 4-byte aligned (scale, zero) pairs");
+  if (M == 0) return PALU_OK;
+  const int ni = pgq_ni(M, N, K, R, ldx, ldw);
+  PALU_REQUIRE(ni != 0, PALU_ERR_UNSUPPORTED, "project_gemm_q: no fused tile for M=%d N=%d K=%d R=%d", M, N, K, R);
+  PgParams p = {};
+  p.x = (const h16*)x; p.ldx = ldx; p.w = (const h16*)w; p.ldw = ldw;
+  p.M = M; p.N = N; p.K = K; p.R = R; p.row0 = row0;
+  p.codes = (unsigned char*)codes; p.sc_g = sc_g; p.sc_l = sc_l;
+  p.meta = (h16*)meta; p.sm_g = sm_g; p.sm_l = sm_l;
+  const int ntm = (M + PL_BM - 1) / PL_BM;
+  const int bn = 128 * ni, ntn = N / bn;
+  const int smem = 2 * (PL_BM + bn) * PG_BK * 2;
+  const dim3 grid(((ntm + 7) / 8) * 8 * ntn), block(PL_THREADS);
+  hipStream_t s = (hipStream_t)stream;
+#define PALU_PGQ(NIV, QBV)                                                                                                  \
+  {                                                                                                                         \
+    const void* fn = (const void*)project_gemm_256_kernel<NIV, QBV>;                                                        \
+    PALU_REQUIRE(palu_func_max_lds(fn, smem) == 0, PALU_ERR_LAUNCH, "project_gemm_q: cannot reserve %d bytes of LDS", smem); \
+    hipLaunchKernelGGL((project_gemm_256_kernel<NIV, QBV>), grid, block, smem, s, p, ntn, ntm);                             \
+  }
+  if (bits == 4) {
+    if (ni == 1) PALU_PGQ(1, 4) else if (ni == 2) PALU_PGQ(2, 4) else PALU_PGQ(3, 4)
+  } else {
+    if (ni == 1) PALU_PGQ(1, 3) else if (ni == 2) PALU_PGQ(2, 3) else PALU_PGQ(3, 3)
+  }
+#undef PALU_PGQ
+  PALU_LAUNCH_CHECK();
+  return PALU_OK;
+}
 
 extern "C" int palu_lowrank_project_gemm(const void* x, int64_t ldx, const void* w, int64_t ldw, void* out, int64_t so_g,
                                          int64_t so_l, int M, int N, int K, int R, int row0, palu_stream_t stream) {

@@ -695,6 +695,35 @@ class LlamaPaluAttention(nn.Module):
         cache.advance(li, q_len)
         return kbuf[:, :, :n + q_len], vbuf[:, :, :n + q_len]
 
+    def _project_into_packed_cache(self, hs, cache) -> bool:
+        """The chunk's latent rows straight into a packed cache: the projection GEMM with the quantise + pack epilogue
+        (palu_lowrank_project_gemm_q) -- no fp16 latents in memory.  False when the fused tile does not take the shape (short
+        chunks, group ranks that do not tile, per-column-group metas): the caller projects, then appends."""
+        if getattr(cache, "group_size", 0) or self.k_proj.VT.bias is not None or self.v_proj.VT.bias is not None:
+            return False
+        x = hs.reshape(-1, hs.shape[-1])
+        t = x.shape[0]
+        if x.stride(1) != 1 or x.dtype != torch.float16:
+            return False
+        G, Rk, Rv = self.num_groups, self.group_rank_k, self.group_rank_v
+        lib = _lib.lib
+        for w, R in ((self.k_proj.VT.weight, Rk), (self.v_proj.VT.weight, Rv)):
+            if (w.dtype != torch.float16 or w.stride(1) != 1
+                    or not lib.palu_lowrank_project_gemm_q_supported(t, w.shape[0], w.shape[1], R, cache.n_bits)):
+                return False
+        li = self.layer_idx
+        cache._ensure_layer(li)
+        n = cache.get_seq_length(li)
+        cache.reserve(li, n + t + cache._headroom, G, Rk, Rv, x.device)
+        st = cache.buffers(li)
+        for w, codes, meta, R in ((self.k_proj.VT.weight, st["kc"], st["km"], Rk), (self.v_proj.VT.weight, st["vc"], st["vm"], Rv)):
+            _lib.check(lib.palu_lowrank_project_gemm_q(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), codes.data_ptr(),
+                                                       codes.stride(1), codes.stride(2), meta.data_ptr(), meta.stride(1),
+                                                       meta.stride(2), t, w.shape[0], w.shape[1], R, n, cache.n_bits,
+                                                       _lib.current_stream()), "palu_lowrank_project_gemm_q")
+        cache.advance(li, t)
+        return True
+
     def _mask_is_causal(self, attention_mask, q_len, past):
         """True iff the additive mask is the standard causal one (0 on/below the diagonal shifted by `past`,
         <= -1e4 above it) -- the only mask the flash prefill kernel understands."""
@@ -764,7 +793,7 @@ class LlamaPaluAttention(nn.Module):
             q = self.q_proj(hs).view(t, H, D).transpose(0, 1)                             # [H,t,D] view of [t, H*D]
             if not packed:
                 self._project_into_cache(hs, cache)                                       # latents straight into the rows
-            else:
+            elif not self._project_into_packed_cache(hs, cache):
                 # packed 3/4-bit cache: quantise + pack this chunk's rows; attention runs over the de-quantised values
                 # (the accuracy path's fake-quant semantics, svd_linear.py:84-90,124-139)
                 kh = self.k_proj.project_to_latent(hs).view(1, t, G, Rk).transpose(1, 2)

@@ -498,3 +498,51 @@ def test_prefill_in_panels_needs_64_mib_at_64k_tokens():
     with torch.no_grad():
         tail, _, _ = m(x[:, T - 256:], past_key_value=ref_cache, is_causal=True)
     torch.testing.assert_close(out[:, T - 256:].float(), tail.float(), rtol=2e-3, atol=2e-3)
+
+
+@pytest.mark.parametrize("bits", [4, 3])
+@pytest.mark.parametrize("M,N,K,R,row0", [(1024, 1024, 4096, 128, 0), (1000, 3072, 4096, 384, 37), (8192, 1024, 4096, 128, 0),
+                                          (777, 512, 1024, 64, 5), (600, 1536, 2048, 192, 0), (2048, 768, 512, 96, 3),
+                                          (4096, 2048, 1024, 256, 0), (530, 256, 512, 32, 1)])
+def test_projection_gemm_fused_quantise_epilogue_is_bit_exact(bits, M, N, K, R, row0):
+    """palu_lowrank_project_gemm_q (projection + quantise + pack in the GEMM's epilogue) against
+    palu_lowrank_project_gemm followed by palu_quantize_pack: codes and (scale, zero) pairs bit for bit; and the dequantised
+    rows against the oracle's quantize_rows on the fp16 GEMM output (the g5 semantics)."""
+    lib = _lib()
+    from palu_amd.kernel import quant as pq
+    assert lib.lib.palu_lowrank_project_gemm_q_supported(M, N, K, R, bits) == 1
+    rng = np.random.default_rng(M + N + K + R + bits)
+    G = N // R
+    x = torch.from_numpy(rng.standard_normal((M, K)).astype(np.float16)).to(DEV)
+    w = torch.from_numpy((rng.standard_normal((N, K)) * K ** -0.5 * rng.uniform(0.3, 3.0, (N, 1))).astype(np.float16)).to(DEV)
+    cap = row0 + M + 9
+    lat = torch.zeros(G, cap, R, dtype=torch.float16, device=DEV)
+    lib.check(lib.lib.palu_lowrank_project_gemm(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), lat.data_ptr(),
+                                                lat.stride(0), lat.stride(1), M, N, K, R, row0,
+                                                torch.cuda.current_stream().cuda_stream), "gemm")
+    rows = lat[:, row0:row0 + M].contiguous()
+    codes_ref, meta_ref = pq.quantize_pack(rows, bits)
+    rb = R * bits // 8
+    codes = torch.full((G, cap, rb), 0xEE, dtype=torch.uint8, device=DEV)
+    meta = torch.full((G, cap, 2), -7.0, dtype=torch.float16, device=DEV)
+    lib.check(lib.lib.palu_lowrank_project_gemm_q(x.data_ptr(), x.stride(0), w.data_ptr(), w.stride(0), codes.data_ptr(),
+                                                  codes.stride(0), codes.stride(1), meta.data_ptr(), meta.stride(0),
+                                                  meta.stride(1), M, N, K, R, row0, bits,
+                                                  torch.cuda.current_stream().cuda_stream), "gemm_q")
+    assert torch.equal(meta[:, row0:row0 + M], meta_ref)
+    assert torch.equal(codes[:, row0:row0 + M], codes_ref)
+    # rows outside [row0, row0 + M) untouched
+    assert bool((codes[:, :row0] == 0xEE).all()) and bool((codes[:, row0 + M:] == 0xEE).all())
+    assert bool((meta[:, :row0] == -7.0).all()) and bool((meta[:, row0 + M:] == -7.0).all())
+    deq = pq.unpack_dequant(codes[:, row0:row0 + M].contiguous(), meta[:, row0:row0 + M].contiguous(), bits, R)
+    want = oracle.quantize_rows(rows[:, :64].cpu().reshape(-1, R), bits)[0].reshape(G, 64, R)
+    assert torch.equal(deq[:, :64].cpu(), want)
+
+
+def test_projection_gemm_q_unsupported_shapes_say_so():
+    lib = _lib()
+    sup = lib.lib.palu_lowrank_project_gemm_q_supported
+    assert sup(256, 1024, 4096, 128, 4) == 0        # short chunks run the small-tile kernel
+    assert sup(4096, 1280, 4096, 160, 4) == 0       # 160 columns per group do not tile
+    assert sup(4096, 1024, 4096, 128, 8) == 0
+    assert sup(4096, 1024, 4096, 128, 3) == 1 and sup(4096, 3072, 4096, 384, 4) == 1
