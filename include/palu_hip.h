@@ -180,6 +180,13 @@ int palu_gemv_f16(const void* W, int64_t ldw, const void* x, void* y, int N, int
 /* y = W x + bias, bias [N] fp16 added to the fp32 accumulator before the rounding (or NULL): o_proj of a model built with
  * config.attention_bias (kernel/palu_attention.py:145). */
 int palu_gemv_bias_f16(const void* W, int64_t ldw, const void* x, const void* bias, void* y, int N, int K, palu_stream_t stream);
+/* Whole-model decode (outside the attention module): y[n] = silu(Wg[n] . x) * (Wu[n] . x), the gate and up
+ * projections of a gated MLP (transformers LlamaMLP: act_fn(gate_proj(x)) * up_proj(x)) for ONE token in one pass; fp16
+ * roundings where the torch composition has them.  Wg, Wu: [N, K] fp16 (ldg, ldu), K % 8 == 0, K <= 32768. */
+int palu_gemv_silu_mul_f16(const void* Wg, int64_t ldg, const void* Wu, int64_t ldu, const void* x, void* y,
+                           int N, int K, palu_stream_t stream);
+/* RMSNorm of one token (transformers LlamaRMSNorm: fp32 normalisation, fp16 rounding, times the fp16 weight), one launch. */
+int palu_rmsnorm_row_f16(const void* x, const void* w, void* y, int K, float eps, palu_stream_t stream);
 /* Same product, fp32 accumulators written out unrounded (y: [N] fp32): the per-rank partial of a column-sharded o_proj
  * (kernel/palu_attention.py:254-257): W = this rank's [hidden, H/N*Rv] column block (ldw = H*Rv),
  * x = its context slice; the ranks all-reduce the partials and round to fp16 once. */

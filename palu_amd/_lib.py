@@ -65,6 +65,8 @@ SIGNATURES = {
                                         i32, vp, i32, f32, vp]),
     "palu_gemv_f16": (i32, [vp, i64, vp, vp, i32, i32, vp]),
     "palu_gemv_bias_f16": (i32, [vp, i64, vp, vp, vp, i32, i32, vp]),
+    "palu_gemv_silu_mul_f16": (i32, [vp, i64, vp, i64, vp, vp, i32, i32, vp]),
+    "palu_rmsnorm_row_f16": (i32, [vp, vp, vp, i32, f32, vp]),
     "palu_decode_qkv_bias_f16": (i32, [vp, i64, vp, vp, i64, vp, i64, vp, vp, vp, i64, i64, vp, i64, i64, vp,
                                        i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "palu_gemv_f16_acc32": (i32, [vp, i64, vp, vp, i32, i32, vp]),

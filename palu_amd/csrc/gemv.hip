@@ -87,6 +87,57 @@ __global__ __launch_bounds__(GV_THREADS) void gemv_kernel(const h16* __restrict_
   }
 }
 
+// act[n] = silu(W_gate[n] . x) * (W_up[n] . x): the two up-projections of a gated MLP for one token in one pass over x
+// (whole-model decode, SURVEY 8(f) N2 -- not part of the attention module).  One wave per output element: its gate row and
+// its up row.  fp16 semantics of the torch composition: both dot products are rounded to fp16 (two nn.Linear outputs), silu
+// is evaluated in fp32 on the rounded gate and rounded, the product is rounded.
+__global__ __launch_bounds__(GV_THREADS) void gemv_silu_mul_kernel(const h16* __restrict__ Wg, int64_t ldg,
+                                                                   const h16* __restrict__ Wu, int64_t ldu,
+                                                                   const h16* __restrict__ x, h16* __restrict__ y, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  h16* xs = reinterpret_cast<h16*>(smem_raw);
+  stage_x(x, xs, K, threadIdx.x);
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * (GV_THREADS / 64) + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float g, u;
+  row_pair_dot(Wg + (int64_t)n * ldg, Wu + (int64_t)n * ldu, xs, K, lane, &g, &u);
+  if (lane == 0) {
+    const float g16 = (float)(h16)g, u16 = (float)(h16)u;
+    const float s16 = (float)(h16)(g16 / (1.0f + __expf(-g16)));
+    y[n] = (h16)(s16 * u16);
+  }
+}
+
+// RMSNorm of ONE token (transformers LlamaRMSNorm: x * rsqrt(mean(x^2) + eps) in fp32, rounded to fp16, times the fp16
+// weight) in one launch instead of the seven of the torch composition -- whole-model decode.
+__global__ __launch_bounds__(GV_THREADS) void rmsnorm_row_kernel(const h16* __restrict__ x, const h16* __restrict__ w,
+                                                                 h16* __restrict__ y, int K, float eps) {
+  __shared__ float part[GV_THREADS / 64];
+  const int tid = threadIdx.x;
+  float ss = 0.f;
+  for (int c = tid; c < (K >> 3); c += GV_THREADS) {
+    const h16x8 v = *(reinterpret_cast<const h16x8*>(x) + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss = fmaf((float)v[e], (float)v[e], ss);
+  }
+  ss = wave_sum(ss);
+  if ((tid & 63) == 0) part[tid >> 6] = ss;
+  __syncthreads();
+  float tot = 0.f;
+#pragma unroll
+  for (int i = 0; i < GV_THREADS / 64; ++i) tot += part[i];
+  const float rs = rsqrtf(tot / (float)K + eps);
+  for (int c = tid; c < (K >> 3); c += GV_THREADS) {
+    const h16x8 v = *(reinterpret_cast<const h16x8*>(x) + c);
+    const h16x8 g = *(reinterpret_cast<const h16x8*>(w) + c);
+    h16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (h16)((float)g[e] * (float)(h16)((float)v[e] * rs));
+    *(reinterpret_cast<h16x8*>(y) + c) = o;
+  }
+}
+
 struct QkvParams {
   const h16 *wq, *vtk, *vtv, *x;
   int64_t ldq, ldk, ldv;
@@ -180,6 +231,28 @@ extern "C" int palu_gemv_bias_f16(const void* W, int64_t ldw, const void* x, con
   const int blocks = (pairs + GV_THREADS / 64 - 1) / (GV_THREADS / 64);
   hipLaunchKernelGGL(gemv_kernel<h16>, dim3(blocks), dim3(GV_THREADS), (size_t)K * 2, (hipStream_t)stream, (const h16*)W,
                      ldw, (const h16*)x, (h16*)y, N, K, (const h16*)bias);
+  PALU_LAUNCH_CHECK();
+  return PALU_OK;
+}
+
+extern "C" int palu_gemv_silu_mul_f16(const void* Wg, int64_t ldg, const void* Wu, int64_t ldu, const void* x, void* y, int N,
+                                      int K, palu_stream_t stream) {
+  PALU_REQUIRE(Wg && Wu && x && y && N > 0 && K > 0, PALU_ERR_ARG, "gemv_silu_mul: bad arguments");
+  PALU_REQUIRE(K % 8 == 0 && ldg % 8 == 0 && ldu % 8 == 0 && (((uintptr_t)Wg | (uintptr_t)Wu | (uintptr_t)x) & 15) == 0,
+               PALU_ERR_ARG, "gemv_silu_mul: K, ldg, ldu must be multiples of 8 and the operands 16-byte aligned");
+  PALU_REQUIRE((size_t)K * 2 <= 64 * 1024, PALU_ERR_UNSUPPORTED, "gemv_silu_mul: K too large for the LDS-resident vector");
+  const int blocks = (N + GV_THREADS / 64 - 1) / (GV_THREADS / 64);
+  hipLaunchKernelGGL(gemv_silu_mul_kernel, dim3(blocks), dim3(GV_THREADS), (size_t)K * 2, (hipStream_t)stream, (const h16*)Wg,
+                     ldg, (const h16*)Wu, ldu, (const h16*)x, (h16*)y, N, K);
+  PALU_LAUNCH_CHECK();
+  return PALU_OK;
+}
+
+extern "C" int palu_rmsnorm_row_f16(const void* x, const void* w, void* y, int K, float eps, palu_stream_t stream) {
+  PALU_REQUIRE(x && w && y && K > 0 && K % 8 == 0, PALU_ERR_ARG, "rmsnorm_row: K must be a positive multiple of 8");
+  PALU_REQUIRE((((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) & 15) == 0, PALU_ERR_ARG, "rmsnorm_row: 16-byte aligned operands");
+  hipLaunchKernelGGL(rmsnorm_row_kernel, dim3(1), dim3(GV_THREADS), 0, (hipStream_t)stream, (const h16*)x, (const h16*)w, (h16*)y,
+                     K, eps);
   PALU_LAUNCH_CHECK();
   return PALU_OK;
 }

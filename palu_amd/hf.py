@@ -169,3 +169,106 @@ def convert_llama_to_palu(model, rank_k: int, rank_v: int, group_size: int = 4, 
         inner.prepare_decode()            # fragments + shared-B decision now, not inside the first (possibly captured) step
         layer.self_attn = PaluAttentionHF(inner)
     return model
+
+
+class _DecodeGemvLinear(nn.Module):
+    """An `nn.Linear` whose batch-1, one-token call is the HIP GEMV (weights streamed once at HBM rate, `palu_gemv_bias_f16`);
+    every other call is the wrapped linear.  Whole-model decode only -- the attention module has its own."""
+
+    def __init__(self, lin: nn.Linear):
+        super().__init__()
+        self.lin = lin
+        w = lin.weight
+        self._ok = (w.dtype == torch.float16 and w.is_cuda and w.stride(1) == 1 and w.shape[1] % 8 == 0
+                    and w.shape[1] * 2 <= 64 * 1024 and w.stride(0) % 8 == 0)
+
+    @property
+    def weight(self):
+        return self.lin.weight
+
+    def forward(self, x):
+        w = self.lin.weight
+        if not (self._ok and x.numel() == w.shape[1] and x.dtype == torch.float16 and x.is_cuda and x.is_contiguous()):
+            return self.lin(x)
+        from . import _lib
+        y = torch.empty(x.shape[:-1] + (w.shape[0],), dtype=x.dtype, device=x.device)
+        b = self.lin.bias
+        _lib.check(_lib.lib.palu_gemv_bias_f16(w.data_ptr(), w.stride(0), x.data_ptr(), 0 if b is None else b.data_ptr(),
+                                               y.data_ptr(), w.shape[0], w.shape[1], _lib.current_stream()), "palu_gemv_bias_f16")
+        return y
+
+
+class _DecodeGatedMLP(nn.Module):
+    """transformers' LlamaMLP (`down_proj(act_fn(gate_proj(x)) * up_proj(x))`) whose one-token call is two HIP launches: the
+    gate and up GEMVs with the SiLU product in their epilogue (`palu_gemv_silu_mul_f16`), then the down GEMV."""
+
+    def __init__(self, mlp):
+        super().__init__()
+        self.mlp = mlp
+        g, u, d = mlp.gate_proj, mlp.up_proj, mlp.down_proj
+        act = getattr(mlp, "act_fn", None)
+        silu = isinstance(act, nn.SiLU) or getattr(act, "__name__", "") == "silu" or type(act).__name__ in ("SiLUActivation", "SiLU")
+        self._ok = (silu and all(l.bias is None and l.weight.dtype == torch.float16 and l.weight.is_cuda and l.weight.stride(1) == 1
+                                 and l.weight.shape[1] % 8 == 0 and l.weight.shape[1] * 2 <= 64 * 1024 for l in (g, u, d))
+                    and g.weight.shape == u.weight.shape)
+
+    def forward(self, x):
+        g, u, d = self.mlp.gate_proj.weight, self.mlp.up_proj.weight, self.mlp.down_proj.weight
+        if not (self._ok and x.numel() == g.shape[1] and x.dtype == torch.float16 and x.is_cuda and x.is_contiguous()):
+            return self.mlp(x)
+        from . import _lib
+        s = _lib.current_stream()
+        act = torch.empty(g.shape[0], dtype=x.dtype, device=x.device)
+        _lib.check(_lib.lib.palu_gemv_silu_mul_f16(g.data_ptr(), g.stride(0), u.data_ptr(), u.stride(0), x.data_ptr(),
+                                                   act.data_ptr(), g.shape[0], g.shape[1], s), "palu_gemv_silu_mul_f16")
+        y = torch.empty(x.shape[:-1] + (d.shape[0],), dtype=x.dtype, device=x.device)
+        _lib.check(_lib.lib.palu_gemv_f16(d.data_ptr(), d.stride(0), act.data_ptr(), y.data_ptr(), d.shape[0], d.shape[1], s),
+                   "palu_gemv_f16")
+        return y
+
+
+class _DecodeRMSNorm(nn.Module):
+    """LlamaRMSNorm whose one-token call is one HIP launch (`palu_rmsnorm_row_f16`) instead of seven torch kernels."""
+
+    def __init__(self, norm):
+        super().__init__()
+        self.norm = norm
+        w = norm.weight
+        self.eps = float(getattr(norm, "variance_epsilon", getattr(norm, "eps", 1e-6)))
+        self._ok = w.dtype == torch.float16 and w.is_cuda and w.dim() == 1 and w.shape[0] % 8 == 0 and w.is_contiguous()
+
+    @property
+    def weight(self):
+        return self.norm.weight
+
+    def forward(self, x):
+        w = self.norm.weight
+        if not (self._ok and x.numel() == w.shape[0] and x.dtype == torch.float16 and x.is_cuda and x.is_contiguous()):
+            return self.norm(x)
+        from . import _lib
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib.palu_rmsnorm_row_f16(x.data_ptr(), w.data_ptr(), y.data_ptr(), w.shape[0], self.eps,
+                                                 _lib.current_stream()), "palu_rmsnorm_row_f16")
+        return y
+
+
+def use_hip_decode_linears(model):
+    """Route the one-token calls of every gated MLP, every RMSNorm and `lm_head` of a Llama-style model through HIP kernels
+    (prompt passes and batches keep the wrapped torch modules).  Optional: whole-model decode throughput, not attention
+    parity."""
+    base = getattr(model, "model", model)
+    for layer in base.layers:
+        if hasattr(layer, "mlp") and not isinstance(layer.mlp, _DecodeGatedMLP) and all(
+                hasattr(layer.mlp, a) for a in ("gate_proj", "up_proj", "down_proj")):
+            layer.mlp = _DecodeGatedMLP(layer.mlp)
+        for name in ("input_layernorm", "post_attention_layernorm"):
+            n = getattr(layer, name, None)
+            if n is not None and not isinstance(n, _DecodeRMSNorm) and type(n).__name__.endswith("RMSNorm"):
+                setattr(layer, name, _DecodeRMSNorm(n))
+    fin = getattr(base, "norm", None)
+    if fin is not None and not isinstance(fin, _DecodeRMSNorm) and type(fin).__name__.endswith("RMSNorm"):
+        base.norm = _DecodeRMSNorm(fin)
+    head = getattr(model, "lm_head", None)
+    if isinstance(head, nn.Linear):
+        model.lm_head = _DecodeGemvLinear(head)
+    return model

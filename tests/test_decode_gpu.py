@@ -683,3 +683,42 @@ def test_decode_step_with_attention_bias(bits):
     torch.testing.assert_close(out.cpu().reshape(-1).float(), o2, rtol=1e-3, atol=1e-3)
     # the bias really took part
     assert (qb.abs().max() > 0.1) and float((out.cpu().reshape(-1).float() - (o2 - ob.float())).abs().max()) > 1e-2
+
+
+def test_hip_decode_linears_match_the_torch_mlp_and_lm_head():
+    """palu_amd.hf.use_hip_decode_linears: the one-token calls of every gated MLP (gate / up GEMVs with the SiLU product in
+    the epilogue, then the down GEMV) and of lm_head on the HIP GEMV kernels; prompt passes keep the torch modules.  Logits of
+    a prompt and of three decode steps against the same model without the substitution."""
+    transformers = pytest.importorskip("transformers")
+    from transformers import LlamaConfig, LlamaForCausalLM
+    from palu_amd.hf import PaluCacheHF, convert_llama_to_palu, use_hip_decode_linears, _DecodeGatedMLP, _DecodeGemvLinear
+    import copy
+    torch.manual_seed(3)
+    cfg = LlamaConfig(vocab_size=1000, hidden_size=512, intermediate_size=1376, num_hidden_layers=2, num_attention_heads=4,
+                      num_key_value_heads=4, head_dim=128, max_position_embeddings=512, rope_theta=10000.0,
+                      attention_bias=False, tie_word_embeddings=False)
+    cfg._attn_implementation = "eager"
+    base = convert_llama_to_palu(LlamaForCausalLM(cfg).to(DEV, torch.float16).eval(), rank_k=512, rank_v=512, group_size=2)
+    fast = use_hip_decode_linears(copy.deepcopy(base))
+    assert all(isinstance(l.mlp, _DecodeGatedMLP) and l.mlp._ok for l in fast.model.layers)
+    assert isinstance(fast.lm_head, _DecodeGemvLinear) and fast.lm_head._ok
+    ids = torch.randint(0, 1000, (1, 21), device=DEV)
+    c1, c2 = PaluCacheHF(bits=16), PaluCacheHF(bits=16)
+    with torch.no_grad():
+        a = base(ids, past_key_values=c1, use_cache=True).logits
+        b = fast(ids, past_key_values=c2, use_cache=True).logits
+    assert torch.equal(a, b)                                   # a prompt pass takes the wrapped torch modules
+    tok = a[:, -1:].argmax(-1)
+    for _ in range(3):
+        with torch.no_grad():
+            a = base(tok, past_key_values=c1, use_cache=True).logits
+            b = fast(tok, past_key_values=c2, use_cache=True).logits
+        torch.testing.assert_close(b.float(), a.float(), rtol=2e-2, atol=2e-2)
+        tok = a[:, -1:].argmax(-1)
+    # the fused gate/up kernel alone against the torch composition
+    mlp = base.model.layers[0].mlp
+    x = torch.randn(1, 1, 512, device=DEV, dtype=torch.float16)
+    with torch.no_grad():
+        want = mlp(x)
+        got = fast.model.layers[0].mlp(x)
+    torch.testing.assert_close(got.float(), want.float(), rtol=5e-3, atol=5e-3)

@@ -64,11 +64,13 @@ def fill_cache(cache, layers, G, Rk, Rv, L, dev, bits):
         del k, v
 
 
-def run(layers=32, rank_k=1024, rank_v=3072, group_size=4, prompt_len=65536, bits=16, reps=20, dev="cuda:0"):
-    from palu_amd.hf import PaluCacheHF
+def run(layers=32, rank_k=1024, rank_v=3072, group_size=4, prompt_len=65536, bits=16, reps=20, dev="cuda:0", hip_mlp=True):
+    from palu_amd.hf import PaluCacheHF, use_hip_decode_linears
     torch.manual_seed(0)
     t0 = time.perf_counter()
     model, cfg = build_model(layers, rank_k, rank_v, group_size, dev)
+    if hip_mlp:
+        use_hip_decode_linears(model)      # MLP and lm_head GEMVs of the one-token step on the HIP kernels too
     G = 32 // group_size
     cache = PaluCacheHF(bits=bits, capacity=prompt_len + 64)
     fill_cache(cache, layers, G, rank_k // G, rank_v // G, prompt_len, dev, bits)
@@ -102,7 +104,8 @@ def run(layers=32, rank_k=1024, rank_v=3072, group_size=4, prompt_len=65536, bit
     rec = {"workload": "Llama-2-7B geometry (%d layers, random weights), rank_k=%d rank_v=%d gs=%d, %d cached positions per layer, "
                        "%s latent caches, batch 1: one decode step of the WHOLE model through palu_amd.hf" %
                        (layers, rank_k, rank_v, group_size, prompt_len, "fp16" if bits >= 16 else "%d-bit packed" % bits),
-           "layers": layers, "eager_ms_per_token": round(eager_ms, 3), "eager_tokens_per_s": round(1e3 / eager_ms, 1),
+           "layers": layers, "mlp_and_lm_head": "HIP GEMVs (palu_amd.hf.use_hip_decode_linears)" if hip_mlp else "torch",
+           "eager_ms_per_token": round(eager_ms, 3), "eager_tokens_per_s": round(1e3 / eager_ms, 1),
            "setup_s": round(setup_s, 1)}
     # one hipGraph for the whole forward
     try:
@@ -149,8 +152,9 @@ def main():
     ap.add_argument("--prompt_len", type=int, default=65536)
     ap.add_argument("--bits", type=int, default=16)
     ap.add_argument("--json", action="store_true")
+    ap.add_argument("--torch_mlp", action="store_true", help="leave the MLPs and lm_head on torch (hipBLASLt GEMVs)")
     a = ap.parse_args()
-    rec = run(a.layers, a.rank_k, a.rank_v, a.group_size, a.prompt_len, a.bits)
+    rec = run(a.layers, a.rank_k, a.rank_v, a.group_size, a.prompt_len, a.bits, hip_mlp=not a.torch_mlp)
     print(json.dumps(rec) if a.json else "\n".join(f"{k}: {v}" for k, v in rec.items()))
 
 
