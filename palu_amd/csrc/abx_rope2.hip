@@ -167,7 +167,13 @@ int palu_abx2_try_launch(const void* params, int nwg, int bits, hipStream_t stre
       default: return launch2<8, 0>(p, nwg, stream);
     }
   }
-  if (bits == 3) return p.R == 128 ? launch2<8, 3>(p, nwg, stream) : PALU_ABX2_SKIP;     // (narrower 3-bit quarter rows are not whole dwords)
+  if (bits == 3) {
+    switch (p.R) {          // (narrower 3-bit rows are staged by 2 / 1 lanes per row: 32 codes = 12 bytes each)
+      case 32: return launch2<2, 3>(p, nwg, stream);
+      case 64: return launch2<4, 3>(p, nwg, stream);
+      default: return launch2<8, 3>(p, nwg, stream);
+    }
+  }
   switch (p.R) {
     case 32: return launch2<2, 4>(p, nwg, stream);
     case 64: return launch2<4, 4>(p, nwg, stream);
@@ -178,13 +184,12 @@ int palu_abx2_try_launch(const void* params, int nwg, int bits, hipStream_t stre
 // Rank 96 or a rank above 128 with 4 heads per group as passes of the two-band kernel over its column windows (128, 128, ..., 64, 32),
 // fp32 partial scores in `scratch` (palu_abx_scratch_bytes); the last pass adds its window, rounds and stores `out`.  `params`: AbxParams of the whole
 // problem (x / xq, bfrag2 = the window fragment sets, R = the full rank).  PALU_ABX2_SKIP when the shape or the positions
-// do not allow it.  bits = 0 / 4; 3 when every window is 128 wide (R % 128 in {0, 96}).
+// do not allow it.  bits = 0 / 3 / 4.
 int palu_abx2_try_launch_windows(const void* params, int nwg, int bits, void* scratch, int64_t acc_ld, hipStream_t stream) {
   const AbxParams p0 = *reinterpret_cast<const AbxParams*>(params);
   int wdt[64], val[64];
   const int nw = abx2_windows(p0.R, wdt, val);
   if (nw == 0 || (nw > 1 && !scratch) || !p0.bfrag2 || p0.HB != 1 || p0.gs != 4 || p0.qgroup != 0 || p0.ncols != 0) return PALU_ABX2_SKIP;
-  if (bits == 3 && wdt[nw - 1] != 128) return PALU_ABX2_SKIP;
   for (int i = 0; i < nw; ++i)
     if (!palu_abx_two_band_selected(p0.inv_freq, p0.H, p0.G, p0.L, wdt[i], p0.pos0)) return PALU_ABX2_SKIP;
   if (bits == 0 && ((int64_t)p0.L + 3 * 128) * p0.sx_l * 2 >= ((int64_t)1 << 31)) return PALU_ABX2_SKIP;

@@ -184,15 +184,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
   };
   auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
-  constexpr int CPQ = 4 * NKS;
+  // packed rows: LPR lanes share a row of 16 NKS codes, each loading whole dwords -- a quarter row (4 lanes: every thread of
+  // the workgroup stages) except for 3-bit rows of 64 / 32 codes, where 12 bytes = 32 codes are the smallest whole-dword
+  // piece: 2 lanes (threads 0..255) / 1 lane (threads 0..127) per row
+  constexpr int LPR = (QBITS == 3 && NKS < 8) ? NKS / 2 : 4;
+  constexpr int CPQ = 16 * NKS / LPR;
   constexpr int NW = QBITS ? (CPQ * QBITS) / 32 : 1;
-  static_assert(QBITS == 0 || (CPQ * QBITS) % 32 == 0, "packed quarter rows must be whole dwords");
+  static_assert(QBITS == 0 || (CPQ * QBITS) % 32 == 0, "the packed piece of a lane must be whole dwords");
+  const bool qactive = tid < TL * LPR;            // (wave-uniform: whole waves)
   unsigned qraw[NW];
   unsigned qmeta = 0;
   const unsigned char* xqg = QBITS ? p.xq + (int64_t)g * p.sq_g : nullptr;
   const h16* xmg = QBITS ? p.xmeta + (int64_t)g * p.sm_g : nullptr;
   auto load_q = [&](int tt) {
-    const int row = tid >> 2, quarter = tid & 3;
+    if (!qactive) return;
+    const int row = tid / LPR, quarter = tid % LPR;
     const int l = min((tile0 + tt) * TL + row, p.L - 1);
     // (a padded last window, p.ncols valid columns: the quarters past the row's end re-read quarter 0 -- their fragment rows are 0)
     const unsigned* src = reinterpret_cast<const unsigned*>(xqg + (int64_t)l * p.sq_l) + (p.ncols && quarter * CPQ >= p.ncols ? 0 : quarter * NW);
@@ -201,7 +207,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
     qmeta = *reinterpret_cast<const unsigned*>(xmg + (int64_t)l * p.sm_l);
   };
   auto store_q = [&](int slot) {
-    const int row = tid >> 2, quarter = tid & 3;
+    if (!qactive) return;
+    const int row = tid / LPR, quarter = tid % LPR;
     const h16x2 m2 = __builtin_bit_cast(h16x2, qmeta);
     const h16x2 scale2 = h16x2{m2[0], m2[0]};
     const h16 nb = -((h16)1024.f + m2[1]);

@@ -75,7 +75,8 @@ static int abx_rope_q_impl(const void* a, int64_t sa_h, int64_t sa_d, const void
   PALU_REQUIRE((bits == 4 && R % 8 == 0) || (bits == 3 && R % 32 == 0), PALU_ERR_UNSUPPORTED,
                "abx_q: bits must be 3 (R %% 32 == 0) or 4 (R %% 8 == 0); got (%d, %d)", bits, R);
   // fast path (tile staging of whole quarter rows): (4, 32|64|128), (3, 128); everything else -- the ranks the rank
-  // search emits (96, 160, 224, 256, ...) and 3-bit at 32 / 64 -- runs the chunked kernel
+  // search emits (96, 160, 224, 256, ...) and 3-bit at 32 / 64 -- goes to the two-band kernel when its rules are met (below), else to
+  // the windowed / chunked one-band kernels
   const bool fast = group_size == 0 && ((bits == 4 && (R == 32 || R == 64 || R == 128)) || (bits == 3 && R == 128));
   PALU_REQUIRE(L >= 0, PALU_ERR_ARG, "abx_q: negative L");
   if (L == 0) return PALU_OK;
@@ -138,6 +139,16 @@ static int abx_rope_q_impl(const void* a, int64_t sa_h, int64_t sa_d, const void
       PALU_LAUNCH_CHECK();
     }
     return PALU_OK;
+  }
+  if (!fast && group_size == 0 && bits == 3 && (R == 32 || R == 64) && !pl.chunked && palu_abx2_frag_bytes(H, G, R)) {
+    // 3-bit rows of 32 / 64 codes at 4 heads per group: the two-band kernel stages them 12 bytes per lane (abx_rope2_kernel.h);
+    // other group sizes and positions without a coefficient table stay on the chunked kernel below
+    const int nwg2 = abx_fill_params(p, pl, H, G, L, R, pos0);
+    p.nks_frag = nks_frag;
+    p.qgroup = 0;
+    p.bfrag2 = (const u32x4*)((const char*)bfrag + (size_t)G * pl.hb * 8 * pl.nmb * pl.nks_tot * 64 * sizeof(u32x4));
+    const int rc2 = palu_abx2_try_launch(&p, nwg2, 3, (hipStream_t)stream);
+    if (rc2 != PALU_ABX2_SKIP) return rc2;
   }
   if (!fast) {
     // plan the launch as the chunked fp16 kernel does: 128-column chunks whatever R is
