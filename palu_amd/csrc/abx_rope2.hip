@@ -29,8 +29,8 @@ int two_band_enabled() {     // PALU_ABX_TWO_BAND=0 keeps every launch on abx_ro
 template <int NKS, int QBITS>
 int launch2(const AbxParams& p, int nwg, hipStream_t stream) {
   if (p.acc == nullptr) return launch_kernel(abx_rope2_kernel<NKS, QBITS, 0>, abx2_smem(NKS), p, nwg, stream);
-  if (p.ks0 == 0) return launch_kernel(abx_rope2_kernel<NKS, QBITS, 1>, abx2_smem(NKS), p, nwg, stream);   // first window: store
-  if (p.ks0 == 1) return launch_kernel(abx_rope2_kernel<NKS, QBITS, 2>, abx2_smem(NKS), p, nwg, stream);   // middle ones: add
+  if (p.win_pass == 0) return launch_kernel(abx_rope2_kernel<NKS, QBITS, 1>, abx2_smem(NKS), p, nwg, stream);   // first window: store
+  if (p.win_pass == 1) return launch_kernel(abx_rope2_kernel<NKS, QBITS, 2>, abx2_smem(NKS), p, nwg, stream);   // middle ones: add
   return launch_kernel(abx_rope2_kernel<NKS, QBITS, 3>, abx2_smem(NKS), p, nwg, stream);                    // last: add, round, store
 }
 
@@ -147,7 +147,7 @@ extern "C" void palu_abx2_debug_buffer(void* ptr) { g_abx2_dbg = (unsigned long 
 int palu_abx2_try_launch(const void* params, int nwg, int bits, hipStream_t stream) {
   AbxParams p = *reinterpret_cast<const AbxParams*>(params);
   p.dbg = g_abx2_dbg;
-  // (a windowed pass arrives with R = the window's width, acc set and ks0 = 0 for the first window, 1 for the middle ones, 2 for the last)
+  // (a windowed pass arrives with R = the window's width, acc set and win_pass = 0 for the first window, 1 for the middle ones, 2 for the last)
   if (!p.bfrag2 || p.ncols < 0 || p.ncols >= p.R || p.qgroup != 0 || p.HB != 1 || p.gs != 4) return PALU_ABX2_SKIP;
   if (!(p.R == 32 || p.R == 64 || p.R == 128)) return PALU_ABX2_SKIP;
   if (!palu_abx_two_band_selected(p.inv_freq, p.H, p.G, p.L, p.R, p.pos0)) return PALU_ABX2_SKIP;
@@ -202,7 +202,7 @@ int palu_abx2_try_launch_windows(const void* params, int nwg, int bits, void* sc
     p.bfrag2 = frag;
     p.acc = nw > 1 ? (float*)scratch : nullptr;      // (rank 96: one padded window straight to `out`)
     p.acc_ld = acc_ld;
-    p.ks0 = i == 0 ? 0 : i + 1 < nw ? 1 : 2;
+    p.win_pass = i == 0 ? 0 : i + 1 < nw ? 1 : 2;
     if (bits == 0) p.x = p0.x + c0;
     else p.xq = p0.xq + (size_t)c0 * bits / 8;
     const int rc = palu_abx2_try_launch(&p, nwg, bits, stream);

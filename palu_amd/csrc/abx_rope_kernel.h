@@ -73,6 +73,7 @@ struct AbxParams {
   int ncols;                // fast fp16 kernel: valid columns of the 16*NKS-column window (0 = all); the rest reads as zero
   // multi-pass use of the fast kernel (ranks above 128: one launch per 128-column window of x, fp32 accumulation):
   int ks0;                  // first fragment k-step of this pass (0)
+  int win_pass;             // two-band column windows (abx_rope2.hip): 0 = first window (store), 1 = middle (add), 2 = last (add, round)
   float* acc;               // fp32 scores [H][acc_ld] of the ACC = 1 / 2 instantiations (store / atomic add of the partials)
   int64_t acc_ld;
   // two-band kernel (abx_rope2_kernel.h): its fragment layout (behind the fragments above in the same allocation), the
