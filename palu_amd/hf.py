@@ -32,14 +32,17 @@ class PaluCacheHF(_HFCache):
     """`transformers.Cache` facade over the latent caches of every layer.  The attention modules never call `update`
     with reconstructed K/V (there are none): they append latent rows through `self.latent`."""
 
-    def __init__(self, bits: int = 16, capacity: int = 0, headroom: int = 256):
+    def __init__(self, bits: int = 16, capacity: int = 0, headroom: int = 256, group_size: int = 0):
+        """group_size: quantize_tensor's column-group width for packed caches (quant.py:11-13, `--lt_group_size`); 0 = one
+        (scale, zero) pair per (token, head-group) row, the reference default."""
         if _HFCache is not object:
             try:
                 super().__init__(layers=[])
             except TypeError:          # older Cache.__init__ without arguments
                 super().__init__()
-        self.latent = LatentCache(capacity, headroom) if bits >= 16 else QuantLatentCache(bits, capacity, headroom)
-        self.bits, self._capacity, self._headroom = bits, capacity, headroom
+        self.latent = (LatentCache(capacity, headroom) if bits >= 16
+                       else QuantLatentCache(bits, capacity, headroom, group_size=group_size))
+        self.bits, self._capacity, self._headroom, self._group_size = bits, capacity, headroom, group_size
         self._mask_memo = None            # (mask identity, "is the plain causal mask") of the current forward pass
 
     # -- what transformers' model code asks a cache ------------------------------------------------------------
@@ -65,7 +68,7 @@ class PaluCacheHF(_HFCache):
 
     def reset(self):
         self.latent = (LatentCache(self._capacity, self._headroom) if self.bits >= 16
-                       else QuantLatentCache(self.bits, self._capacity, self._headroom))
+                       else QuantLatentCache(self.bits, self._capacity, self._headroom, group_size=self._group_size))
         self._mask_memo = None
 
     def __len__(self):
