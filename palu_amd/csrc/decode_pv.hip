@@ -925,13 +925,18 @@ struct CombineParams {
 };
 
 
-// grid (H, ceil(Rv/64)), 512 threads: the 8 waves share the splits of one head for 64 context columns
-// (8 independent loads in flight per lane: the merge is latency-, not bandwidth-bound), LDS sum at the end.
+// grid H * ceil(Rv / CL) workgroups of 512 threads: the 8 waves share the splits of one head for CL context columns
+// (8 independent loads in flight per lane: the merge is latency-, not bandwidth-bound), LDS sum at the end.  CL = 64: one
+// column per lane.  CL = 16 (few heads -- a one-group shard of an 8-GPU head-group sharding has H = 4, i.e. 24 workgroups
+// at 64 columns each for up to ~1000 ranges): the four 16-lane groups of a wave take every fourth batch of splits, four
+// times the workgroups and four times the loads in flight per column.
 constexpr int CB_WAVES = 8;
+template <int CL>
 __global__ __launch_bounds__(64 * CB_WAVES) void pv_combine_kernel(CombineParams p) {
+  constexpr int NS = 64 / CL;                       // split streams per wave
   __shared__ float red[CB_WAVES][64];
-  __shared__ float redt[CB_WAVES];
-  // 1-D grid of H * ceil(Rv / 64) workgroups; workgroup b -> (group, head in group, column block) with group = b % G:
+  __shared__ float redt[CB_WAVES][NS];
+  // 1-D grid; workgroup b -> (group, head in group, column block) with group = b % G:
   // the partials of latent group g were written by workgroups with id % G == g (pv_partial*, decode_fused), i.e. with
   // G = 8 on XCD g -- the merge reads them from that XCD's L2 instead of from memory (placement: speed only)
   const int g = blockIdx.x % p.G;
@@ -939,14 +944,15 @@ __global__ __launch_bounds__(64 * CB_WAVES) void pv_combine_kernel(CombineParams
   const int hh = rest % p.gs, yb = rest / p.gs;
   const int h = g * p.gs + hh;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int r = yb * 64 + lane;
+  const int cl = lane % CL, sub = lane / CL;
+  const int r = yb * CL + cl;
   const float* ml = p.ml + ((size_t)g * p.nsplit * p.gs + hh) * 2;
   const size_t ml_stride = (size_t)p.gs * 2;
   const float* part = p.part + ((size_t)g * p.nsplit * p.gs + hh) * p.Rv + min(r, p.Rv - 1);
   const size_t pstride = (size_t)p.gs * p.Rv;
   float acc = 0.f, tot = 0.f;
   constexpr int UN = 16;
-  // first batch of this wave's splits is requested BEFORE the global maximum is reduced: the partial rows do not depend
+  // first batch of this stream's splits is requested BEFORE the global maximum is reduced: the partial rows do not depend
   // on it, and the merge is one memory round trip instead of two (it is latency-bound: 4.7 us for ~1.5 MB)
   float m[UN], sm[UN], pv[UN];
   auto load_batch = [&](int s0) {
@@ -958,13 +964,14 @@ __global__ __launch_bounds__(64 * CB_WAVES) void pv_combine_kernel(CombineParams
       pv[u] = part[s * pstride];
     }
   };
-  load_batch(wv * UN);
+  const int stream = wv * NS + sub;
+  load_batch(stream * UN);
   // global max over the splits (every wave computes it: nsplit is small)
   float M = -INFINITY;
   for (int s = lane; s < p.nsplit; s += 64) M = fmaxf(M, ml[s * ml_stride]);
   M = wave_max(M);
-  for (int s0 = wv * UN; s0 < p.nsplit; s0 += CB_WAVES * UN) {
-    if (s0 != wv * UN) load_batch(s0);
+  for (int s0 = stream * UN; s0 < p.nsplit; s0 += CB_WAVES * NS * UN) {
+    if (s0 != stream * UN) load_batch(s0);
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const float wgt = (s0 + u < p.nsplit && m[u] != -INFINITY) ? __expf(m[u] - M) : 0.f;
@@ -973,21 +980,31 @@ __global__ __launch_bounds__(64 * CB_WAVES) void pv_combine_kernel(CombineParams
     }
   }
   red[wv][lane] = acc;
-  if (lane == 0) redt[wv] = tot;
+  if (cl == 0) redt[wv][sub] = tot;
   __syncthreads();
-  if (wv == 0) {
+  if (wv == 0 && lane < CL) {
     float a = 0.f, t = 0.f;
 #pragma unroll
-    for (int k = 0; k < CB_WAVES; ++k) {
-      a += red[k][lane];
-      t += redt[k];
-    }
+    for (int k = 0; k < CB_WAVES; ++k)
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        a += red[k][q * CL + lane];
+        t += redt[k][q];
+      }
     if (yb == 0 && lane == 0) {
       p.stats[2 * h] = M;
       p.stats[2 * h + 1] = t;
     }
     if (r < p.Rv) p.ctx[(size_t)h * p.ctx_ld + r] = (h16)(a / t);
   }
+}
+
+static void pv_combine_dispatch(const CombineParams& c, int H, int Rv, hipStream_t s) {
+  // few heads (one or two latent groups per launch): 16 columns per workgroup, four split streams per wave
+  if ((int64_t)H * ((Rv + 63) / 64) < 96)
+    hipLaunchKernelGGL(pv_combine_kernel<16>, dim3(H * ((Rv + 15) / 16)), dim3(64 * CB_WAVES), 0, s, c);
+  else
+    hipLaunchKernelGGL(pv_combine_kernel<64>, dim3(H * ((Rv + 63) / 64)), dim3(64 * CB_WAVES), 0, s, c);
 }
 
 // attention weights: softmax(x, fp32).to(fp16)  (palu_attention.py:238)
@@ -1095,7 +1112,7 @@ int palu_pv_combine_launch(float* ws, void* ctx, int H, int G, int Rv, int ns, h
   c.stats = ws;
   c.G = G; c.gs = H / G; c.Rv = Rv; c.nsplit = ns;
   c.ctx_ld = ctx_ld > 0 ? ctx_ld : Rv;
-  hipLaunchKernelGGL(pv_combine_kernel, dim3(H * ((Rv + 63) / 64)), dim3(64 * CB_WAVES), 0, s, c);
+  pv_combine_dispatch(c, H, Rv, s);
   PALU_LAUNCH_CHECK();
   return PALU_OK;
 }
@@ -1315,7 +1332,7 @@ extern "C" int palu_softmax_pv_f16(const void* scores, int64_t ss_h, const void*
   c.part = p.part; c.ml = p.ml; c.ctx = (h16*)ctx; c.stats = stats;
   c.G = G; c.gs = gs; c.Rv = Rv; c.nsplit = ns;
   c.ctx_ld = ctx_ld > 0 ? ctx_ld : Rv;
-  hipLaunchKernelGGL(pv_combine_kernel, dim3(H * ((Rv + 63) / 64)), dim3(64 * CB_WAVES), 0, s, c);
+  pv_combine_dispatch(c, H, Rv, s);
   PALU_LAUNCH_CHECK();
   if (probs) {
     int bx = (L + 255) / 256;
@@ -1404,7 +1421,7 @@ static int softmax_pv_q_impl(const void* scores, int64_t ss_h, const void* mask,
   c.part = p.part; c.ml = p.ml; c.ctx = (h16*)ctx; c.stats = stats;
   c.G = G; c.gs = gs; c.Rv = Rv; c.nsplit = ns;
   c.ctx_ld = ctx_ld > 0 ? ctx_ld : Rv;
-  hipLaunchKernelGGL(pv_combine_kernel, dim3(H * ((Rv + 63) / 64)), dim3(64 * CB_WAVES), 0, s, c);
+  pv_combine_dispatch(c, H, Rv, s);
   PALU_LAUNCH_CHECK();
   if (probs) {
     int bx = (L + 255) / 256;
