@@ -64,6 +64,21 @@ def test_host_only_entry_points_work_without_gpu():
     assert _lib.lib.palu_pv_workspace_bytes(32, 8, 2048, 96) > 0
     assert _lib.lib.palu_decode_workspace_bytes(32, 8, 128, 4096, 96) > 0
     assert _lib.lib.palu_version() >= 100
+    # round 4 host arithmetic (no GPU): column windows of the two-band kernel (one fragment set per window: 96 -> one padded
+    # 128-wide window; 160 -> 128 + 32; 224 -> 128 + padded 128), the fused-quantise GEMM's tiling rule, the prefill state
+    one_band = lambda R: 32 * ((R + 127) // 128 * 128) * 128 * 2            # chunked layout: whole 128-column chunks
+    two_band = lambda cols: 32 * cols * 128 * 2
+    assert _lib.lib.palu_abx_bfrag_bytes(32, 8, 96) == one_band(96) + two_band(128)
+    assert _lib.lib.palu_abx_bfrag_bytes(32, 8, 160) == one_band(160) + two_band(128 + 32)
+    assert _lib.lib.palu_abx_bfrag_bytes(32, 8, 224) == one_band(224) + two_band(128 + 128)
+    sup = _lib.lib.palu_lowrank_project_gemm_q_supported
+    assert sup(4096, 1024, 4096, 128, 4) == 1 and sup(4096, 3072, 4096, 384, 3) == 1 and sup(1000, 1536, 2048, 192, 4) == 1
+    assert sup(256, 1024, 4096, 128, 4) == 0 and sup(4096, 1280, 4096, 160, 4) == 0 and sup(4096, 1024, 4096, 128, 8) == 0
+    assert _lib.lib.palu_prefill_state_bytes(32, 512, 384, 0) == 32 * 512 * 384 * 4
+    assert _lib.lib.palu_prefill_state_bytes(32, 512, 384, 1) == 32 * 512 * 8 * 4
+    # quantised P.V on the matrix cores: 32-code chunks, or 24-code chunks for 4-bit rows they fill better (192 = 8 x 24)
+    assert _lib.lib.palu_pv_direct_nsplit(8, 65536, 384, 3) == 32 and _lib.lib.palu_pv_direct_nsplit(8, 131072, 192, 4) == 32
+    assert _lib.lib.palu_pv_direct_nsplit(8, 1000, 40, 4) == 0
 
 
 def test_pv_workspace_covers_every_fill_level():
