@@ -148,7 +148,8 @@ int palu_abx2_try_launch(const void* params, int nwg, int bits, hipStream_t stre
   AbxParams p = *reinterpret_cast<const AbxParams*>(params);
   p.dbg = g_abx2_dbg;
   // (a windowed pass arrives with R = the window's width, acc set and win_pass = 0 for the first window, 1 for the middle ones, 2 for the last)
-  if (!p.bfrag2 || p.ncols < 0 || p.ncols >= p.R || p.qgroup != 0 || p.HB != 1 || p.gs != 4) return PALU_ABX2_SKIP;
+  if (!p.bfrag2 || p.ncols < 0 || p.ncols >= p.R || p.qgroup < 0 || p.qgroup % 32 != 0 || p.HB != 1 || p.gs != 4) return PALU_ABX2_SKIP;
+  if (bits == 0 && p.qgroup != 0) return PALU_ABX2_SKIP;
   if (!(p.R == 32 || p.R == 64 || p.R == 128)) return PALU_ABX2_SKIP;
   if (!palu_abx_two_band_selected(p.inv_freq, p.H, p.G, p.L, p.R, p.pos0)) return PALU_ABX2_SKIP;
   {
@@ -189,7 +190,7 @@ int palu_abx2_try_launch_windows(const void* params, int nwg, int bits, void* sc
   const AbxParams p0 = *reinterpret_cast<const AbxParams*>(params);
   int wdt[64], val[64];
   const int nw = abx2_windows(p0.R, wdt, val);
-  if (nw == 0 || (nw > 1 && !scratch) || !p0.bfrag2 || p0.HB != 1 || p0.gs != 4 || p0.qgroup != 0 || p0.ncols != 0) return PALU_ABX2_SKIP;
+  if (nw == 0 || (nw > 1 && !scratch) || !p0.bfrag2 || p0.HB != 1 || p0.gs != 4 || p0.ncols != 0) return PALU_ABX2_SKIP;
   for (int i = 0; i < nw; ++i)
     if (!palu_abx_two_band_selected(p0.inv_freq, p0.H, p0.G, p0.L, wdt[i], p0.pos0)) return PALU_ABX2_SKIP;
   if (bits == 0 && ((int64_t)p0.L + 3 * 128) * p0.sx_l * 2 >= ((int64_t)1 << 31)) return PALU_ABX2_SKIP;
@@ -203,6 +204,7 @@ int palu_abx2_try_launch_windows(const void* params, int nwg, int bits, void* sc
     p.acc = nw > 1 ? (float*)scratch : nullptr;      // (rank 96: one padded window straight to `out`)
     p.acc_ld = acc_ld;
     p.win_pass = i == 0 ? 0 : i + 1 < nw ? 1 : 2;
+    p.qcol0 = c0;                                    // (per-column-group metas: the pair index counts from the row's start)
     if (bits == 0) p.x = p0.x + c0;
     else p.xq = p0.xq + (size_t)c0 * bits / 8;
     const int rc = palu_abx2_try_launch(&p, nwg, bits, stream);

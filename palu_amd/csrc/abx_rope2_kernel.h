@@ -196,6 +196,14 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
   unsigned qmeta = 0;
   const unsigned char* xqg = QBITS ? p.xq + (int64_t)g * p.sq_g : nullptr;
   const h16* xmg = QBITS ? p.xmeta + (int64_t)g * p.sm_g : nullptr;
+  if (QBITS != 0 && p.qgroup > 0) {
+    // rows quantised in column groups (quantize_tensor with group_size > 0, quant.py:11-13): the (scale, zero) pair of THIS
+    // lane's piece -- qgroup is a multiple of 32, a piece (8 .. 32 columns at a multiple of its width) never straddles two
+    // groups; a padded last window's pieces past the row's end take the last valid pair (their fragment rows are 0)
+    int c = p.qcol0 + (tid % LPR) * CPQ;
+    if (p.ncols) c = min(c, p.qcol0 + p.ncols - 1);
+    xmg += 2 * (c / p.qgroup);
+  }
   auto load_q = [&](int tt) {
     if (!qactive) return;
     const int row = tid / LPR, quarter = tid % LPR;

@@ -69,7 +69,8 @@ struct AbxParams {
   int64_t sq_g, sq_l;       // bytes
   const h16* xmeta;
   int64_t sm_g, sm_l;       // elements
-  int qgroup;               // columns per (scale, zero) pair: 0 = one pair per row, else R / qgroup pairs (chunked kernel)
+  int qgroup;               // columns per (scale, zero) pair: 0 = one pair per row, else R / qgroup pairs (chunked / two-band kernels)
+  int qcol0;                // two-band column windows with qgroup > 0: the window's first column of the row (selects the pair)
   int ncols;                // fast fp16 kernel: valid columns of the 16*NKS-column window (0 = all); the rest reads as zero
   // multi-pass use of the fast kernel (ranks above 128: one launch per 128-column window of x, fp32 accumulation):
   int ks0;                  // first fragment k-step of this pass (0)

@@ -140,6 +140,22 @@ static int abx_rope_q_impl(const void* a, int64_t sa_h, int64_t sa_d, const void
     }
     return PALU_OK;
   }
+  if (group_size > 0 && group_size % 32 == 0 && palu_abx2_frag_bytes(H, G, R)) {
+    // rows quantised in column groups at 4 heads per group: the two-band kernel picks the (scale, zero) pair per lane piece
+    // (abx_rope2_kernel.h); single launch at R in {32, 64, 128}, column windows otherwise (they need the fp32 scratch)
+    const int nwg2 = abx_fill_params(p, pl, H, G, L, R, pos0);
+    p.nks_frag = nks_frag;
+    p.qgroup = group_size;
+    p.qcol0 = 0;
+    p.bfrag2 = (const u32x4*)((const char*)bfrag + (size_t)G * pl.hb * 8 * pl.nmb * pl.nks_tot * 64 * sizeof(u32x4));
+    int rc2 = PALU_ABX2_SKIP;
+    if (R == 32 || R == 64 || R == 128) rc2 = palu_abx2_try_launch(&p, nwg2, bits, (hipStream_t)stream);
+    else if (R == 96 || (scratch && ((uintptr_t)scratch & 15) == 0))
+      rc2 = palu_abx2_try_launch_windows(&p, nwg2, bits, scratch, ((int64_t)L + 7) & ~(int64_t)7, (hipStream_t)stream);
+    if (rc2 != PALU_ABX2_SKIP) return rc2;
+    p.qgroup = 0;
+    p.bfrag2 = nullptr;
+  }
   if (!fast && group_size == 0 && bits == 3 && (R == 32 || R == 64) && !pl.chunked && palu_abx2_frag_bytes(H, G, R)) {
     // 3-bit rows of 32 / 64 codes at 4 heads per group: the two-band kernel stages them 12 bytes per lane (abx_rope2_kernel.h);
     // other group sizes and positions without a coefficient table stay on the chunked kernel below

@@ -232,3 +232,31 @@ def test_cold_start_first_launch_is_deterministic(kind, two_band):
     outs += [p.communicate(timeout=600)[0] for p in procs]
     for o in outs:
         assert "first!=second: 0  second!=third: 0" in o, o
+
+
+@pytest.mark.parametrize("bits,R,gsz,L", [(4, 128, 32, 1500), (4, 128, 64, 700), (3, 128, 32, 2100), (4, 64, 32, 900), (3, 64, 32, 1300),
+                                          (4, 256, 64, 1000), (3, 160, 32, 800), (4, 96, 32, 600), (4, 224, 32, 500)])
+def test_rows_quantised_in_column_groups_run_the_two_band_kernel(bits, R, gsz, L):
+    """quantize_tensor with group_size > 0 (quant.py:11-13, `--lt_group_size`): every `gsz` columns of a row carry their own
+    (scale, zero).  The two-band kernel picks the pair per lane piece (single launch at R in {32, 64, 128}, column windows
+    otherwise): bit-identical to the fp16 kernel on the dequantised rows, P2 against the oracle."""
+    _lib, ar = _mods()
+    from palu_amd.kernel import quant as pq
+    H, G = 32, 8
+    a, b, x = _inputs(H, G, R, L, seed=bits * 100 + R + gsz)
+    ac, bc, xc = a.cuda(), b.cuda(), x.cuda()
+    ng = R // gsz
+    c, m = pq.quantize_pack(xc.reshape(G, L, ng, gsz).contiguous(), bits)
+    codes = c.reshape(G, L, -1).contiguous()
+    meta = m.reshape(G, L, 2 * ng).contiguous()
+    xdq = pq.unpack_dequant(c, m, bits, gsz).reshape(G, L, R)
+    inv = ar.rope_inv_freq(xc.device)
+    frag = ar.prepare_b(bc, G)
+    out = torch.empty(H, 1, L, dtype=torch.float16, device=xc.device)
+    scr = torch.empty(max(int(_lib.lib.palu_abx_scratch_bytes(H, G, L, R)), 16), dtype=torch.uint8, device=xc.device)
+    _lib.check(_lib.lib.palu_abx_rope_qg(ac.data_ptr(), ac.stride(0), ac.stride(2), frag.data_ptr(), codes.data_ptr(),
+                                         codes.stride(0), codes.stride(1), meta.data_ptr(), meta.stride(0), meta.stride(1),
+                                         out.data_ptr(), out.stride(0), H, G, L, R, D, bits, gsz, inv.data_ptr(), 0,
+                                         scr.data_ptr(), torch.cuda.current_stream().cuda_stream), "abx_qg")
+    _p2(out, a, b, xdq.cpu())
+    assert torch.equal(out, ar.abx(ac, bc, xdq))
