@@ -95,6 +95,14 @@ int palu_rope_table_build(const float* inv_freq, int pos_first, int npos, void* 
 int palu_rope_table_register(const float* inv_freq, const void* table, int pos_first, int npos, float inv_freq_32);
 int palu_rope_table_unregister(const float* inv_freq);
 int palu_abx_two_band_selected(const float* inv_freq, int H, int G, int L, int R, int pos0);
+/* The two-band kernel has two forms with the same algebra, fragments and table: the position-split one
+ * (csrc/abx_rope3_kernel.h: 4 waves per workgroup, a wave owns whole 32-position blocks for all RoPE pairs, high-band
+ * fragments in AGPRs, no cross-wave reduction) and the pair-split one (csrc/abx_rope2_kernel.h: 8 waves, 4 pairs each,
+ * per-tile LDS reduction).  The first needs 2/3 of the cycles per tile and a longer prologue: it is selected (fp16 latents,
+ * one launch) from n = 3 tiles per wave on.  palu_abx_set_position_split(n): 0 = never (PALU_ABX_SPLIT=0 in the environment
+ * starts there), n >= 1 = from n tiles per wave on (1 = whenever the shape allows); returns the previous setting.
+ * Process-wide, for A/B measurements. */
+int palu_abx_set_position_split(int enable);
 size_t palu_abx_scratch_bytes(int H, int G, int L, int R);
 int palu_abx_rope_ws_f16(const void* a, int64_t sa_h, int64_t sa_d, const void* bfrag,
                          const void* x, int64_t sx_g, int64_t sx_l, void* out, int64_t so_h,

@@ -16,6 +16,8 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libpalu_hip.so")
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
+# per-file flags: the position-split score kernel schedules its VALU work by hand (no packed fp32 forms)
+FILE_FLAGS = {"abx_rope3.hip": ["-fno-slp-vectorize"]}
 
 
 def sources():
@@ -43,7 +45,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in sources():                      # one hipcc per translation unit, in parallel
         obj = os.path.join(LIBDIR, os.path.basename(src) + ".o")
         objs.append(obj)
-        cmd = [hipcc, *CFLAGS, *os.environ.get("PALU_EXTRA_CFLAGS", "").split(), "-c", src, "-o", obj]
+        cmd = [hipcc, *CFLAGS, *FILE_FLAGS.get(os.path.basename(src), []), *os.environ.get("PALU_EXTRA_CFLAGS", "").split(), "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -26,8 +26,31 @@ int two_band_enabled() {     // PALU_ABX_TWO_BAND=0 keeps every launch on abx_ro
   return v;
 }
 
+int g_position_split = -1;       // -1: not read yet; PALU_ABX_SPLIT=0 in the environment starts with the pair-split kernel
+int position_split_enabled() {
+  if (g_position_split < 0) {
+    const char* e = getenv("PALU_ABX_SPLIT");
+    g_position_split = e ? (atoi(e) != 0) : 1;
+  }
+  return g_position_split;
+}
+
+// The position-split kernel pays a longer prologue (every wave takes all high-band fragments) for a main loop that needs
+// 2/3 of the cycles: it wins once a wave (4 per CU) has about three 128-position tiles (profiles/r05_abx_split_vs_pair.txt).
+// g_split_min_tiles: tiles per wave from which it is selected (palu_abx_set_position_split(n > 1) sets it; 1 = always)
+int g_split_min_tiles = 3;
+bool position_split_preferred(const AbxParams& p) {
+  const int on = position_split_enabled();
+  if (!on) return false;
+  int nch = palu_num_cus() / p.G;
+  if (nch < 1) nch = 1;
+  const int64_t ntiles = ((int64_t)p.L + TL - 1) / TL;
+  return ntiles >= (int64_t)g_split_min_tiles * 4 * nch;
+}
+
 template <int NKS, int QBITS>
 int launch2(const AbxParams& p, int nwg, hipStream_t stream) {
+  if (QBITS == 0 && p.acc == nullptr && p.ncols == 0 && position_split_preferred(p)) return palu_abx3_launch(&p, NKS, stream);
   if (p.acc == nullptr) return launch_kernel(abx_rope2_kernel<NKS, QBITS, 0>, abx2_smem(NKS), p, nwg, stream);
   if (p.win_pass == 0) return launch_kernel(abx_rope2_kernel<NKS, QBITS, 1>, abx2_smem(NKS), p, nwg, stream);   // first window: store
   if (p.win_pass == 1) return launch_kernel(abx_rope2_kernel<NKS, QBITS, 2>, abx2_smem(NKS), p, nwg, stream);   // middle ones: add
@@ -81,9 +104,14 @@ int palu_abx2_prepare_b(const void* b, int64_t sb_h, int64_t sb_r, int64_t sb_d,
   return PALU_OK;
 }
 
+// table = [coefficient tiles: 1 KB per 128 positions][T1: 256 B per tile][T2: 33 x 256 B] (abx_rope2_kernel.h)
+static inline size_t tab_tiles_bytes(int ntiles) { return (size_t)ntiles * 2 * 32 * sizeof(u32x4); }
+static inline size_t tab_t1_bytes(int ntiles) { return (size_t)ntiles * ABX2_T1_TILE_FLOATS * sizeof(float); }
+
 extern "C" size_t palu_rope_table_bytes(int npos) {
   if (npos <= 0) return 0;
-  return (size_t)((npos + TL - 1) / TL) * 2 * 32 * sizeof(u32x4);
+  const int ntiles = (npos + TL - 1) / TL;
+  return tab_tiles_bytes(ntiles) + tab_t1_bytes(ntiles) + ABX2_T2_FLOATS * sizeof(float);
 }
 
 extern "C" int palu_rope_table_build(const float* inv_freq, int pos_first, int npos, void* table, palu_stream_t stream) {
@@ -95,6 +123,11 @@ extern "C" int palu_rope_table_build(const float* inv_freq, int pos_first, int n
   const int64_t total = (int64_t)ntiles * 64;
   hipLaunchKernelGGL(abx2_rope_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, inv_freq,
                      pos_first / TL, ntiles, (u32x4*)table);
+  PALU_LAUNCH_CHECK();
+  float* t1 = (float*)((char*)table + tab_tiles_bytes(ntiles));
+  const int64_t total2 = (int64_t)ntiles * 32 + 33 * 32;
+  hipLaunchKernelGGL(abx2_rope_start_kernel, dim3((unsigned)((total2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, inv_freq,
+                     pos_first / TL, ntiles, t1, (float*)((char*)t1 + tab_t1_bytes(ntiles)));
   PALU_LAUNCH_CHECK();
   return PALU_OK;
 }
@@ -140,6 +173,15 @@ extern "C" int palu_abx_two_band_selected(const float* inv_freq, int H, int G, i
   return 0;
 }
 
+// Process-wide switch between the two forms of the two-band kernel (returns the previous value): 1 (default) the
+// position-split kernel (abx_rope3_kernel.h) where it applies, 0 the pair-split kernel (abx_rope2_kernel.h) everywhere
+extern "C" int palu_abx_set_position_split(int enable) {
+  const int o = position_split_enabled() ? g_split_min_tiles : 0;
+  g_position_split = enable ? 1 : 0;
+  if (enable > 0) g_split_min_tiles = enable;        // (1 = whenever the shape allows, n = from n tiles per wave on)
+  return o;
+}
+
 static unsigned long long* g_abx2_dbg = nullptr;
 // debug: device buffer of >= 176 KB that workgroup 0 of the next two-band launches dumps its first W image into (0 = off)
 extern "C" void palu_abx2_debug_buffer(void* ptr) { g_abx2_dbg = (unsigned long long*)ptr; }
@@ -160,6 +202,8 @@ int palu_abx2_try_launch(const void* params, int nwg, int bits, hipStream_t stre
     if (!t) return PALU_ABX2_SKIP;
     p.rope_tab = t->tab;
     p.tab_tile0 = p.pos0 / TL - t->tile_first;
+    p.rope_t1 = (const float*)((const char*)t->tab + tab_tiles_bytes(t->ntiles));
+    p.rope_t2 = (const float*)((const char*)p.rope_t1 + tab_t1_bytes(t->ntiles));
   }
   if (bits == 0) {
     switch (p.R) {

@@ -116,6 +116,31 @@ __global__ void abx2_rope_table_kernel(const float* __restrict__ inv_freq, int t
   out[idx] = *reinterpret_cast<u32x4*>(&v);
 }
 
+// RoPE start tables of the position-split kernel (abx_rope3_kernel.h), behind the coefficient tiles in the same allocation:
+//   T1 [tile][hi 2][q 16][2] fp32 = (cos, sin) of the EXACT product (128 (tile_first + tile)) f_i, pair i = 4 (q >> 1) + 2 (q & 1) + hi
+//      (the order a lane of that kernel holds its 16 high-band pairs in), 256 B per tile;
+//   T2 [n 0..32][hi 2][q 16][2] fp32 = (cos, sin)(n f_i): the lane's offset inside a block (n < 32), the step between
+//      blocks (n = 32) and the one-block-early start of the last M-block's pairs (32 - n).
+// fp64 sincos of the exact products, one rounding to fp32: a wave's start state is one complex product per pair.
+constexpr int ABX2_T1_TILE_FLOATS = 64;
+constexpr int ABX2_T2_FLOATS = 33 * 64;
+__global__ void abx2_rope_start_kernel(const float* __restrict__ inv_freq, int tile_first, int ntiles, float* __restrict__ t1,
+                                       float* __restrict__ t2) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n1 = (int64_t)ntiles * 32;
+  if (idx >= n1 + 33 * 32) return;
+  const int64_t row = idx < n1 ? idx / 32 : (idx - n1) / 32;          // tile, or in-block offset n
+  const int e = (int)(idx % 32);
+  const int hi = e >> 4, q = e & 15;
+  const double f = (double)inv_freq[4 * (q >> 1) + 2 * (q & 1) + hi];
+  const double pos = idx < n1 ? (double)(tile_first + row) * 128.0 : (double)row;
+  double sn, cn;
+  sincos(pos * f, &sn, &cn);
+  float* dst = idx < n1 ? t1 + idx * 2 : t2 + (idx - n1) * 2;
+  dst[0] = (float)cn;
+  dst[1] = (float)sn;
+}
+
 constexpr int ABX2_RED_STRIDE = 8 * 4 * TL;   // floats per partial-sum slot: [8 waves][4 heads][TL]
 constexpr int abx2_smem(int nks) { return 3 * TL * 32 * nks + 3 * ABX2_RED_STRIDE * (int)sizeof(float) + 2 * nks * 1024; }
 

@@ -1,0 +1,650 @@
+// Position-split form of the two-band score kernel: the fused  K = X.B -> RoPE -> q.K^T  of abx_rope2_kernel.h (same
+// algebra, same fragments, same coefficient table, same numerics contract: oracle `torch_abx`, kernel/abx_rope.py:152-171;
+// replaces the Triton `_abx_fwd`, kernel/abx_rope.py:79-111) with the work split by POSITION instead of by RoPE pair.
+//
+// abx_rope2_kernel gives each of its 8 waves 4 of the 32 high-band pairs of every position: every wave reads every X
+// fragment from LDS (one ds_read_b128 + wait per MFMA), the per-position sum over the pairs is a cross-wave LDS
+// reduction behind a per-tile workgroup barrier, and two half-size waves per SIMD pay every per-wave overhead twice
+// (417 issued instructions per wave and tile for 44 MFMAs, 62 % of the wave time waiting).
+//
+// Here a workgroup is 4 waves, ONE per SIMD, each with the 512-register budget:
+//   * a wave owns whole 32-position blocks (a contiguous range of 128-position tiles) for ALL 32 high-band pairs, all 4
+//     heads and the low band.  The 8 x NKS folded high-band A fragments (256 registers at R = 128) are MFMA-only operands
+//     and live in AGPRs for the whole kernel; the block's NKS X fragments are read from LDS ONCE and feed 9 M-blocks
+//     (8 high + the low band's stage 2): one ds_read_b128 per 9 MFMAs instead of one per MFMA.
+//   * a lane holds one position; the sum over the pairs is a chain of FMAs in that lane (two accumulators per head), one
+//     v_permlane32_swap per head pair finishes it and the fp16 scores leave through a buffer store: no cross-wave
+//     reduction, no partial sums in LDS.
+//   * nothing in the main loop is shared between waves: every wave stages its own X blocks (LDS-DMA into a private
+//     two-slot ring, the slot is free as soon as its fragments are in registers, so a block has two block times to land),
+//     builds its own per-tile low-band weights W (stage 1, from the folded [P|Q]_low fragments all waves share read-only in
+//     LDS) and keeps them in a private 8 KB image.  No barrier after the prologue.
+//   * the prologue is cooperative: every wave folds the query into a quarter of the fragments, the folded fragments go
+//     through LDS once (the high ones through the space the rings use later).
+// Per 32-position block and wave: 8 NKS + NKS big MFMAs (+ 8 NKS small ones per tile in the tile's last block), 256 + 16
+// VALU of rotation work, 2 NKS LDS reads; at R = 128 about 6.3 issued instructions per big MFMA -- what one wave can
+// issue in a matrix-pipe slot (tools/ubench_issue.hip).
+//
+// Inline-asm MFMAs pin the operand banks (A in AGPRs, accumulators in VGPRs) and the issue order; hipcc cannot see the
+// hazards of an asm MFMA, they are met by construction: an accumulator is first read by the VALU at least one full MFMA
+// (32 cycles) plus four VALU operations after its last MFMA was issued (tools/ubench_mfma_hazard.hip: 6 wait states are
+// enough), no MFMA source is VALU-written, dependent MFMAs use the SrcC = vDst forwarding.
+#pragma once
+#include "abx_rope2_kernel.h"
+
+namespace {
+
+constexpr int ABX3_THREADS = 256;
+
+template <int NKS>
+struct Abx3Lds {
+  static constexpr int BLK = 32 * 32 * NKS;        // one 32-position X block image: 32 rows of RB = 32 NKS bytes
+  static constexpr int LOWF = 8 * NKS * 1024;      // folded [P|Q]_low fragments [rb][h][cs][lane] (shared, read-only after the prologue)
+  static constexpr int WIMG = NKS * 1024;          // one W image [ks][hiA 2][m 32][8 fp16]
+  static constexpr int HIF = 8 * NKS * 1024;       // folded high fragments [mb][ks][lane] (prologue only)
+  static constexpr int OFF_LOWF = 0;
+  static constexpr int OFF_X0 = LOWF;              // ring slot 0 of the 4 waves
+  static constexpr int OFF_X1 = OFF_X0 + 4 * BLK;  // ring slot 1
+  static constexpr int OFF_W = OFF_X1 + 4 * BLK;   // W images of the 4 waves
+  static constexpr int OFF_HIF = OFF_X1;           // prologue: aliases [slot 1 | W images] = 8 NKS KB exactly
+  static constexpr int OFF_Q = OFF_X1;             // prologue, before the high fold: the query as (q_i, q_{i+64}) pairs, 1 KB
+  static constexpr int TOTAL = OFF_W + 4 * WIMG;
+  static_assert(4 * BLK + 4 * WIMG == HIF, "the folded high fragments alias ring slot 1 + the W images");
+};
+constexpr int abx3_smem(int nks) { return 8 * nks * 1024 + 8 * 32 * 32 * nks + 4 * nks * 1024; }
+
+// a.x * b.x + a.y * b.y in fp32 (exact products, one rounding).  (The builtin: hipcc selects v_dot2c_f32_f16 + a v_mov for its
+// accumulator.  An inline-asm v_dot2_f32_f16 with an inline 0 saves the v_mov and returns garbage: on gfx950 a DOT result needs
+// 3 wait states before another VALU reads it, which hipcc only inserts for instructions it can see -- measured, round 5.)
+static __device__ __forceinline__ float abx3_dot2(unsigned a, unsigned b) {
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, a), __builtin_bit_cast(h16x2, b), 0.f, false);
+}
+
+template <int I, int N, class F>
+static __device__ __forceinline__ void abx3_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    abx3_for<I + 1, N>(f);
+  }
+}
+
+// dbg (TIMING): [workgroup][wave 4][64] s_memtime stamps: 0 start, 1 loads issued, 2 RoPE init, 3 low fold, 4 high fold,
+// 5 fragments in AGPRs, 6 first W image, 7 first block landed, 8.. start of every block, then drain start, end
+template <int NKS, bool TIMING = false>
+__global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void abx_rope3_kernel(AbxParams p) {
+  using Geo = LdsGeom<NKS>;
+  using M = Abx3Lds<NKS>;
+  constexpr int CPS = 8 / NKS;                     // epilogue chunks per MFMA slot (an M-block has NKS slots, its epilogue 8 chunks)
+  constexpr int FPW = 2 * NKS;                     // fragments a wave folds (of the 8 NKS high and the 8 NKS low ones)
+  constexpr int WD = NKS < 4 ? NKS : 4;            // depth of the stage-2 A-fragment ring
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>(smem);
+  typedef __attribute__((address_space(3))) h16x8 lds_h16x8;
+  typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+  typedef __attribute__((address_space(3))) unsigned lds_u32;
+  typedef __attribute__((address_space(3))) h16x4 lds_h16x4;
+  typedef __attribute__((address_space(3))) h16 lds_h16;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 31, hi = lane >> 5;
+  const int g = blockIdx.x % p.G;
+  const int cidx = blockIdx.x / p.G;
+  int stamp_i = 0;
+  auto stamp = [&]() {
+    if (TIMING) {
+      const unsigned long long t = __builtin_readcyclecounter();
+      if (lane == 0 && stamp_i < 64) p.dbg[((size_t)blockIdx.x * 4 + w) * 64 + stamp_i] = t;
+      ++stamp_i;
+    }
+  };
+  stamp();  // 0
+
+  // ---- tiles of this wave: the full tiles dealt evenly over the 4 nch waves of the group, the partial tail tile to the last
+  const int nwv = 4 * p.nch;
+  const int wv = cidx * 4 + w;
+  const int nt_full = p.L / TL;
+  const int base = nt_full / nwv, rem = nt_full % nwv;
+  const int tile0 = wv * base + min(wv, rem);
+  const bool has_tail = (p.L % TL) != 0 && wv == nwv - 1;
+  const int nfull = base + (wv < rem ? 1 : 0);
+  const int ntile = nfull + (has_tail ? 1 : 0);
+  const int tail_nb = has_tail ? (p.L % TL + 31) / 32 : 0;
+  const int nblk = 4 * nfull + tail_nb;            // 32-position blocks of this wave: rows tile0 * 128 + 32 b
+
+  // ---- X staging: LDS-DMA, one 1 KB piece = RPP rows per instruction, the XOR swizzle in the lane's source offset
+  const h16* xg = p.x + (int64_t)g * p.sx_g;
+  u32x4 xrs;
+  {
+    const unsigned long long xb = reinterpret_cast<unsigned long long>(xg);
+    xrs[0] = __builtin_amdgcn_readfirstlane((unsigned)xb);
+    xrs[1] = __builtin_amdgcn_readfirstlane((unsigned)(xb >> 32));
+    xrs[2] = __builtin_amdgcn_readfirstlane((unsigned)(((int64_t)(p.L - 1) * p.sx_l + 16 * NKS) * 2));
+    xrs[3] = 0x00020000u;
+  }
+  constexpr int RPP = 64 / Geo::CPR;               // rows per piece
+  constexpr int NV = NKS >= 4 ? NKS / 2 : 1;       // distinct swizzle phases of a piece (piece k: phase k % NV)
+  const unsigned row_bytes = __builtin_amdgcn_readfirstlane((unsigned)(p.sx_l * 2));
+  unsigned dvoff[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v)
+    dvoff[v] = (unsigned)((lane / Geo::CPR) * p.sx_l * 2 + Geo::swz(v * RPP + lane / Geo::CPR, lane % Geo::CPR) * 16);
+  const int row00 = tile0 * TL;
+  const int blk_last = max(nblk - 1, 0);
+  // piece k of block b into ring slot `slot` (blocks past the wave's range re-read its last block: harmless, keeps the
+  // vmcnt bookkeeping uniform)
+  auto dma_piece = [&](int b, int slot, int k) {
+    const int bb = min(b, blk_last);
+    const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)(row00 + 32 * bb + k * RPP) * row_bytes);
+    const unsigned dst = (unsigned)((slot ? M::OFF_X1 : M::OFF_X0) + w * M::BLK + k * 1024);
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds"
+        :
+        : "s"(dst), "v"(dvoff[k % NV]), "s"(xrs), "s"(soff)
+        : "memory");
+  };
+  if (nblk > 0) {
+#pragma unroll
+    for (int k = 0; k < NKS; ++k) dma_piece(0, 0, k);
+  }
+
+  // stage 1 uses 8 of the 16 MFMA columns: lanes k + 8 load the coefficients of lane k, compute the same W values and store
+  // them to the same LDS words (no exec masking, no zero fill)
+  const u32x4* tab0 = p.rope_tab + (int64_t)(p.tab_tile0 + tile0) * 64;      // (uniform) this wave's first tile: 2 x 32 u32x4 per tile
+  const unsigned tab_lane = (unsigned)(((lane >> 4) * 8 + (lane & 7)) * 16);  // this lane's 16 bytes of a coefficient fragment
+  h16x8 cf0[2];
+#pragma unroll
+  for (int cs = 0; cs < 2; ++cs) {
+    u32x4 v = u32x4{0u, 0u, 0u, 0u};
+    if (ntile > 0) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(tab0 + cs * 32) + tab_lane);
+    cf0[cs] = *reinterpret_cast<h16x8*>(&v);
+  }
+  // ---- this wave's share of the fragments first (the bulk: nothing waits for them for a while): high f = mb NKS + j
+  //      (memory order [mb][j]), low f = rb 8 + h 2 + cs
+  const u32x4* bh_base = p.bfrag2 + ((int64_t)g * 8 * NKS + w * FPW) * 64 + lane;
+  const u32x4* bl_base = p.bfrag2 + (int64_t)p.G * 8 * NKS * 64 + ((int64_t)g * NKS * 8 + w * FPW) * 64 + lane;
+  u32x4 hraw[FPW], lraw[FPW];
+#pragma unroll
+  for (int t = 0; t < FPW; ++t) lraw[t] = bl_base[(int64_t)t * 64];
+#pragma unroll
+  for (int t = 0; t < FPW; ++t) hraw[t] = bh_base[(int64_t)t * 64];
+
+  // ---- small loads: the query, frequencies, the first tile's coefficients, the RoPE start tables
+  h16 qv[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int idx = tid + ABX3_THREADS * e;
+    qv[e] = p.a[(int64_t)(g * 4 + (idx >> 7)) * p.sa_h + (int64_t)(idx & 127) * p.sa_d];
+  }
+  // lane (n, hi) holds the 16 high-band pairs i = 4 mb + 2 j + hi, q = 2 mb + j, of one position per block
+  float fr[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) fr[q] = p.inv_freq[4 * (q >> 1) + 2 * (q & 1) + hi];
+  const float psimax = 64.0f * p.inv_freq[ABX2_I0];
+  stamp();  // 1
+
+  // the query to LDS as (q_i, q_{i+64}) pairs
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int idx = tid + ABX3_THREADS * e;
+    const int hh = idx >> 7, d = idx & 127;
+    *(lds_h16*)(uintptr_t)(lds0 + (unsigned)(M::OFF_Q + ((hh * 64 + (d & 63)) * 2 + (d >> 6)) * 2)) = qv[e];
+  }
+
+  stamp();  // 2
+
+  __syncthreads();                                 // #1: the query is in LDS
+  asm volatile("" : "+v"(cf0[0]), "+v"(cf0[1]));   // (hipcc's wait for these loads goes here, where nothing else is in flight)
+
+  // ---- (q_i, q_{i+64}) of this lane's rows in the two high M-blocks it folds
+  unsigned qp[2];
+  {
+    const int m = lane & 31;
+    const int hh = 2 * ((m >> 3) & 1) + (m & 1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const int i = 4 * (2 * w + s) + 2 * (m >> 4) + ((m >> 2) & 1);
+      qp[s] = *(const lds_u32*)(uintptr_t)(lds0 + (unsigned)(M::OFF_Q + (hh * 64 + i) * 4));
+    }
+  }
+  // ---- low fold: a register holds (B[r,i], B[r,i+64]) -> (P[r,i], Q[r,i]) (v_dot2_f32_f16: exact products, one rounding)
+  {
+    const int qd = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < FPW; ++t) {
+      const int f = w * FPW + t;
+      const int h4 = (f >> 1) & 3, cs2 = t & 1;
+      const u32x4 qq = *(const lds_u32x4*)(uintptr_t)(lds0 + (unsigned)(M::OFF_Q + (h4 * 64 + ABX2_I0 + 16 * cs2 + 4 * qd) * 4));
+      u32x4 own = lraw[t];
+      u32x4 res;
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) {
+        // (element -> scalar -> bit_cast: hipcc 7.2 folds __builtin_bit_cast(h16x2, vec[e4]) to element 0 for every e4)
+        const unsigned qe = qq[e4], oe = own[e4];
+        const h16x2 cp = __builtin_bit_cast(h16x2, qe);                 // (q_i, q_{i+64})
+        h16x2 cq;
+        cq[0] = cp[1];
+        cq[1] = -cp[0];                                                  // (q_{i+64}, -q_i)
+        const float r0 = abx3_dot2(oe, __builtin_bit_cast(unsigned, cp));
+        const float r1 = abx3_dot2(oe, __builtin_bit_cast(unsigned, cq));
+        h16x2 r2;
+        r2[0] = (h16)r0;
+        r2[1] = (h16)r1;
+        res[e4] = __builtin_bit_cast(unsigned, r2);
+      }
+      *(lds_u32x4*)(uintptr_t)(lds0 + (unsigned)(M::OFF_LOWF + (f * 64 + lane) * 16)) = res;
+    }
+  }
+  // exact-angle (cos, sin) of: the wave's first tile start (T1), this lane's offset n, the one-block-early start of M-block 7
+  // (its epilogue runs during the NEXT block) and the 32-position step (T2, abx2_rope_start_kernel)
+  const f32x4* t1p = reinterpret_cast<const f32x4*>(p.rope_t1 + ((int64_t)(p.tab_tile0 + (ntile > 0 ? tile0 : 0)) * 2 + hi) * 32);
+  const f32x4* t2n = reinterpret_cast<const f32x4*>(p.rope_t2 + (n * 2 + hi) * 32);
+  const f32x4* t2m = reinterpret_cast<const f32x4*>(p.rope_t2 + ((32 - n) * 2 + hi) * 32);
+  const f32x4* t2s = reinterpret_cast<const f32x4*>(p.rope_t2 + (32 * 2 + hi) * 32);
+  f32x4 vt1[8], vt2[8], vts[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    vt1[k] = t1p[k];
+    vt2[k] = t2n[k];
+    vts[k] = t2s[k];
+  }
+  const f32x4 vtm = t2m[7];                        // pairs q = 14, 15
+  stamp();  // 3
+  __syncthreads();                                 // #2: nobody reads the query any more (the high fragments overwrite it)
+
+  // ---- high fold (abx_rope_kernel FOLD): row (pair, u, head) of an M-block: P = q_i B_i + q_{i+64} B_{i+64} (u = 0),
+  //      Q = q_{i+64} B_i - q_i B_{i+64} (u = 1); the (d, d + 64) partner row sits in lane ^ 2
+  {
+    const int u = (lane >> 1) & 1;
+#pragma unroll
+    for (int t = 0; t < FPW; ++t) {
+      const int s = t / NKS, j = t % NKS;
+      const int mb = 2 * w + s;
+      const int ks = (j + (mb >= 4 ? NKS / 2 : 0)) % NKS;              // (abx2_prepare_b_kernel: waves 4-7 store half a turn ahead)
+      const h16x2 q2 = __builtin_bit_cast(h16x2, qp[s]);
+      h16x2 coef;
+      coef[0] = u ? -q2[0] : q2[0];
+      coef[1] = q2[1];
+      u32x4 own = hraw[t];
+      u32x4 res;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned ow = own[e];
+        const unsigned par = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ow, 0x4E, 0xF, 0xF, false);   // lane ^ 2
+        const unsigned lo2 = __builtin_amdgcn_perm(par, ow, 0x05040100u);
+        const unsigned hi2 = __builtin_amdgcn_perm(par, ow, 0x07060302u);
+        const float r0 = abx3_dot2(lo2, __builtin_bit_cast(unsigned, coef));
+        const float r1 = abx3_dot2(hi2, __builtin_bit_cast(unsigned, coef));
+        h16x2 r2;
+        r2[0] = (h16)r0;
+        r2[1] = (h16)r1;
+        res[e] = __builtin_bit_cast(unsigned, r2);
+      }
+      *(lds_u32x4*)(uintptr_t)(lds0 + (unsigned)(M::OFF_HIF + ((mb * NKS + ks) * 64 + lane) * 16)) = res;
+    }
+  }
+  // ---- RoPE state of this lane: (cs, sn)[q] = cos, sin of the exact angle of position n of the wave's first block -- one
+  //      complex product per pair; M-block 7's pairs start one block early; (rc, rs) = the step of 32 positions
+  float rc[16], rs[16], cs[16], sn[16];
+  const float lf0 = (float)(p.pos0 + tile0 * TL + n);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const float ct = vt1[q >> 1][2 * (q & 1)], st = vt1[q >> 1][2 * (q & 1) + 1];
+    rc[q] = vts[q >> 1][2 * (q & 1)];
+    rs[q] = vts[q >> 1][2 * (q & 1) + 1];
+    if (q < 14) {
+      const float cn = vt2[q >> 1][2 * (q & 1)], sq = vt2[q >> 1][2 * (q & 1) + 1];
+      cs[q] = fmaf(ct, cn, -(st * sq));
+      sn[q] = fmaf(st, cn, ct * sq);
+    } else {                                       // angle of (tile start) - (32 - n) f
+      const float cm = vtm[2 * (q & 1)], sm = vtm[2 * (q & 1) + 1];
+      cs[q] = fmaf(ct, cm, st * sm);
+      sn[q] = fmaf(st, cm, -(ct * sm));
+    }
+  }
+  stamp();  // 4
+  __syncthreads();                                 // #3: all folded fragments are in LDS
+
+  // ---- every wave takes ALL high fragments: 8 NKS AGPR quads, MFMA-only operands from here on
+  h16x8 bf[8][NKS];
+  {
+    const unsigned hsrc = lds0 + (unsigned)(M::OFF_HIF + lane * 16);
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks)             // (LDS -> AGPR directly; the asm order keeps the wait below behind the loads)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(bf[mb][ks]) : "v"(hsrc), "n"((mb * NKS + ks) * 1024));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  stamp();  // 5
+  __syncthreads();                                 // #4: ring slot 1 and the W images are free
+
+  if (nblk <= 0) return;                           // (no barrier below this line)
+
+#pragma unroll
+  for (int k = 0; k < NKS; ++k) dma_piece(1, 1, k);
+
+  // ---- LDS addresses of this lane
+  // X fragment of k-step ks: row n, 16-byte chunk swz(n, 2 ks + hi) (slot 0; slot 1 = + 4 BLK).  The chunk index is
+  // (2 ks + hi) ^ f(n): k-step ks flips bits 5.. of the k-step-0 address, which the row base (a multiple of RB) leaves clear
+  const unsigned fa0 = lds0 + (unsigned)(M::OFF_X0 + w * M::BLK + n * Geo::RB + Geo::swz(n, hi) * 16);
+  const unsigned lowa = lds0 + (unsigned)(M::OFF_LOWF + lane * 16);                              // + f KB
+  const unsigned w_rd = lds0 + (unsigned)(M::OFF_W + w * M::WIMG + (hi * 32 + n) * 16);          // + ks KB
+  // stage-1 result of r-block rb, head h: lane (k, qd) holds W_h[k][16 rb + 4 qd + j] -> image [ks = rb][hiA = qd >> 1][m = 8 h + k][e = 4 (qd & 1) + j]
+  const unsigned w_st = lds0 + (unsigned)(M::OFF_W + w * M::WIMG + ((lane >> 5) * 32 + (lane & 7)) * 16 + 8 * ((lane >> 4) & 1));
+  auto read_x = [&](int ks, int slot) {
+    return *(const lds_h16x8*)(uintptr_t)((fa0 ^ (unsigned)(ks << 5)) + (unsigned)(slot * 4 * M::BLK));
+  };
+  auto read_w = [&](int ks) { return *(const lds_h16x8*)(uintptr_t)(w_rd + (unsigned)(ks * 1024)); };
+  auto read_lowf = [&](int f) { return *(const lds_h16x8*)(uintptr_t)(lowa + (unsigned)(f * 1024)); };
+  auto write_w = [&](int rb, int h4, const h16x4& v) { *(lds_h16x4*)(uintptr_t)(w_st + (unsigned)(rb * 1024 + h4 * 128)) = v; };
+
+  // ---- W image of the first tile (stage 1, plain form): D = [P|Q](16 latent columns x 64) . coef(64 x 16 terms); two fragment
+  //      sets alternate (the next r-block's fragments are requested before this one's MFMAs), the four first halves of an
+  //      r-block before the four second halves (no dependent pair back to back)
+  {
+    h16x8 lfa[8], lfb2[8];
+    auto load8 = [&](h16x8 (&lf)[8], int rb) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) lf[i] = read_lowf(rb * 8 + i);
+    };
+    auto rblock = [&](const h16x8 (&lf)[8], int rb) {
+      f32x4 wa4[4];
+#pragma unroll
+      for (int h4 = 0; h4 < 4; ++h4) wa4[h4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lf[2 * h4], cf0[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+      for (int h4 = 0; h4 < 4; ++h4) wa4[h4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lf[2 * h4 + 1], cf0[1], wa4[h4], 0, 0, 0);
+#pragma unroll
+      for (int h4 = 0; h4 < 4; ++h4) {
+        h16x4 wpk;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wpk[j] = (h16)wa4[h4][j];
+        write_w(rb, h4, wpk);
+      }
+    };
+    load8(lfa, 0);
+#pragma unroll
+    for (int rb = 0; rb < NKS; rb += 2) {
+      load8(lfb2, rb + 1);
+      rblock(lfa, rb);
+      if (rb + 2 < NKS) load8(lfa, rb + 2);
+      rblock(lfb2, rb + 1);
+    }
+  }
+  stamp();  // 6
+
+  // scores leave through a buffer store (invalid lanes get an out-of-range offset the hardware drops)
+  const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
+  const unsigned obase = (unsigned)(((int64_t)(g * 4 + hi) * p.so_h + row00 + n) * 2);          // head hi (+ 2 mb), position of block 0
+  const unsigned ohead2 = (unsigned)(2 * p.so_h * 2);
+
+  // ---- main-loop state
+  h16x8 xf[NKS], wfr[WD];
+  // two accumulator sets: phase k of block B (k = 0: the low band's stage 2, k = 1..8: high M-blocks 0..7) accumulates into
+  // set (9 B + k) & 1 while the epilogue of the phase before reads the other one (36 phases per tile: the roles repeat)
+  f32x16 accA, accB;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) accB[e] = 0.f;      // the first block runs the (empty) epilogue of "block -1"
+  float pc[4], ps[4];                              // per head: cos-side and sin-side partial sums of the current block
+#pragma unroll
+  for (int s = 0; s < 4; ++s) pc[s] = ps[s] = 0.f;
+  float lfe = lf0 - 32.0f;                         // position (of lane n) of the block whose epilogues are running
+  float ang_n = lfe * fr[14];
+  float lo_cur = fmaf(lfe, fr[14], -ang_n);        // residual of the oracle's fp32 angle of the next pair to be rotated
+  h16x8 cfr[2];                                    // coefficients of the next tile (stage-1 B operand)
+  cfr[0] = cfr[1] = cf0[0];
+
+  // chunk c (0..7) of the RoPE epilogue of high M-block mbp held in `ac`; its pairs q = 2 mbp + j, j = 0, 1:
+  //   c = 0, 2 (j = 0, 1): cos/sin at the oracle's fp32-rounded angle fl(l f) (exact angle = ang + lo, first order in lo), start of
+  //                        the next pair's residual
+  //   c = 1, 3: advance the exact-angle state by 32 positions, finish the next residual
+  //   c = 4, 5 / 6, 7: the two head pairs of j = 0 / 1 -- the only chunks that read the accumulators: they sit in the second
+  //                    half of the M-block's slots, at least one full MFMA after the accumulators' last MFMA whatever hipcc
+  //                    hoists inside a slot (with NKS < 8 a slot carries several chunks)
+  float cc[2] = {0.f, 0.f}, ss[2] = {0.f, 0.f};
+  auto epi_chunk = [&](auto mbp_c, auto c_c, const f32x16& ac) {
+    constexpr int mbp = decltype(mbp_c)::value, c = decltype(c_c)::value;
+    if (c < 4) {
+      constexpr int j = c >> 1;
+      constexpr int q = 2 * mbp + j, qn = (q + 1) & 15;
+      if ((c & 1) == 0) {
+        if (q == 15) lfe += 32.0f;                 // pair 0 comes next: it belongs to the following block
+        cc[j] = fmaf(lo_cur, sn[q], cs[q]);
+        ss[j] = fmaf(-lo_cur, cs[q], sn[q]);
+        ang_n = lfe * fr[qn];
+      } else {
+        const float m1 = cs[q] * rc[q];
+        const float m2 = sn[q] * rc[q];
+        lo_cur = fmaf(lfe, fr[qn], -ang_n);
+        const float c2 = fmaf(-sn[q], rs[q], m1);
+        sn[q] = fmaf(cs[q], rs[q], m2);
+        cs[q] = c2;
+      }
+    } else {
+      constexpr int j = (c - 4) >> 1, h1 = (c - 4) & 1;
+      pc[2 * h1] = fmaf(cc[j], ac[8 * j + 4 * h1], pc[2 * h1]);
+      ps[2 * h1] = fmaf(ss[j], ac[8 * j + 4 * h1 + 2], ps[2 * h1]);
+      pc[2 * h1 + 1] = fmaf(cc[j], ac[8 * j + 4 * h1 + 1], pc[2 * h1 + 1]);
+      ps[2 * h1 + 1] = fmaf(ss[j], ac[8 * j + 4 * h1 + 3], ps[2 * h1 + 1]);
+    }
+  };
+
+  // finish block bp (its sums are in pc / ps): lanes n and n + 32 hold complementary pairs and polynomial terms of the same
+  // position: one half swap per head pair, then lane (n, hi) holds head 2 mb + hi
+  auto finalize = [&](int bp) {
+    const bool ok = bp >= 0 && row00 + 32 * bp + n < p.L;
+    const unsigned off0 = ok ? obase + (unsigned)(bp * 64) : 0xFFFFFFF0u;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const float p0 = pc[2 * mb] + ps[2 * mb], p1 = pc[2 * mb + 1] + ps[2 * mb + 1];
+      auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(p0), __float_as_uint(p1), false, false);
+      const float sc = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+      const unsigned off = ok ? off0 + (unsigned)mb * ohead2 : 0xFFFFFFF0u;
+      __builtin_amdgcn_raw_buffer_store_b16(__builtin_bit_cast(short, (h16)sc), orsrc, off, 0, 0);
+    }
+  };
+
+#define ABX3_MFMA_A0(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(ACC) : "a"(A), "v"(B))
+#define ABX3_MFMA_A(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "a"(A), "v"(B))
+#define ABX3_MFMA_V0(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(ACC) : "v"(A), "v"(B))
+#define ABX3_MFMA_V(ACC, A, B) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
+#define ABX3_MFMA_S0(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(ACC) : "v"(A), "v"(B))
+#define ABX3_MFMA_S(ACC, A, B) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(ACC) : "v"(A), "v"(B))
+#define ABX3_IC(X) std::integral_constant<int, (X)> {}
+
+  // ---- one 32-position block: 9 phases of NKS MFMA slots.  B = block of the tile (ring slot B & 1, polynomial argument,
+  //      accumulator roles), b = block of the wave, tnext = tile (of the wave) whose coefficients block 1 requests.
+  //      S1: stage 1 of the NEXT tile rides in this block, one r-block (8 small MFMAs) as a burst in front of an M-block's first
+  //      MFMA: the big MFMAs of an M-block are a dependent chain on one accumulator, and anything that enters the matrix pipe
+  //      between two of them costs ~35 cycles on top of its own (measured: 64 small MFMAs spread one per slot made the block
+  //      3300 cycles longer instead of 1024); an M-block's first MFMA starts a new chain, so the burst costs its 128 cycles.
+  //      The 8 low fragments of a burst are requested in the last slots of the phase before; its results are rounded and stored
+  //      two slots later -- a result of an asm MFMA is never read before the slot AFTER the next one (whatever hipcc hoists
+  //      inside a slot, a whole slot with its 32-cycle MFMA lies in between).
+  auto block = [&](auto B_c, auto S1_c, int b, int tnext) {
+    constexpr int B = decltype(B_c)::value;
+    constexpr bool S1 = decltype(S1_c)::value;
+    constexpr int SL = B & 1;
+    constexpr int PH0 = 9 * B;                       // phase number of this block's stage 2
+    constexpr int PSTEP = 8 / NKS;                   // r-block r of stage 1 sits in front of phase 1 + r PSTEP
+    constexpr int LSLOTS = NKS < 4 ? NKS : 4;        // its fragments are requested in the last LSLOTS slots of the phase before,
+    constexpr int LPS = 8 / LSLOTS;                  // LPS per slot
+    stamp();
+    // stage-2 polynomial weights of this block: position d = 32 B + n of the tile, terms k = 4 hi + c
+    float pw[4];
+    {
+      const float tau = (float)(2 * (32 * B + n) + 1 - TL) * (1.0f / TL);
+      const float t = tau * psimax;
+      const float t2 = t * t;
+      pw[0] = hi ? t2 * t2 * (1.0f / 24.0f) : 1.0f;
+      pw[1] = pw[0] * t * (hi ? 0.2f : 1.0f);
+      pw[2] = pw[1] * t * (hi ? (1.0f / 6.0f) : 0.5f);
+      pw[3] = pw[2] * t * (hi ? (1.0f / 7.0f) : (1.0f / 3.0f));
+    }
+    h16x8 lf8[8];                                    // stage 1 (S1): the low fragments of the next burst
+    f32x4 wa[4];                                     //               its four heads
+    // slot `ks` of phase `ph` (0 = stage 2, 1..8 = M-blocks 0..7), after the slot's big MFMA: the stage-1 work of that slot
+    auto s1_slot = [&](auto ph_c, auto ks_c) {
+      constexpr int ph = decltype(ph_c)::value, ks = decltype(ks_c)::value;
+      if (!S1) return;
+      // fragments of the burst in front of phase ph + 1
+      if (ph + 1 >= 1 && ph + 1 <= 8 && (ph + 1 - 1) % PSTEP == 0 && ks >= NKS - LSLOTS) {
+        constexpr int r = (ph + 1 - 1) / PSTEP;
+        constexpr int i0 = (ks - (NKS - LSLOTS)) * LPS;
+#pragma unroll
+        for (int i = 0; i < LPS; ++i) lf8[i0 + i] = read_lowf(r * 8 + i0 + i);
+      }
+      // results of the burst two slots ago (slot 2 of its phase, or slot 0 of the next phase at NKS = 2)
+      constexpr int gs = ph * NKS + ks - 2;          // global slot of the burst
+      if (gs >= NKS && gs % NKS == 0 && (gs / NKS - 1) % PSTEP == 0) {
+        constexpr int r = (gs / NKS - 1) / PSTEP;
+#pragma unroll
+        for (int h4 = 0; h4 < 4; ++h4) {
+          h16x4 wpk;
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) wpk[jj] = (h16)wa[h4][jj];
+          write_w(r, h4, wpk);
+        }
+      }
+    };
+    // ---- phase 0, the low band's stage 2: acc = W . x; in its gaps the epilogue of the PREVIOUS block's M-block 7
+    {
+      f32x16& acN = (PH0 & 1) ? accB : accA;
+      const f32x16& acP = (PH0 & 1) ? accA : accB;
+      abx3_for<0, NKS>([&](auto ks_c) {
+        constexpr int ks = decltype(ks_c)::value;
+        if (ks == 0) ABX3_MFMA_V0(acN, wfr[0], xf[0]);
+        else ABX3_MFMA_V(acN, wfr[ks % WD], xf[ks]);
+        abx3_for<0, CPS>([&](auto i_c) { epi_chunk(ABX3_IC(7), ABX3_IC(ks * CPS + decltype(i_c)::value), acP); });
+        if (ks + WD < NKS) wfr[ks % WD] = read_w(ks + WD);
+        s1_slot(ABX3_IC(0), ks_c);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    }
+    // ---- phases 1..8, M-blocks 0..7: in the gaps of M-block 0 the previous block is finished and stored, then the polynomial
+    //      of this block's low band, and the DMA pieces of block b + 2 go into this block's ring slot (its fragments are all in
+    //      registers); in the gaps of M-block mb >= 1 the epilogue of M-block mb - 1
+    abx3_for<0, 8>([&](auto mb_c) {
+      constexpr int mb = decltype(mb_c)::value;
+      f32x16& acN = ((PH0 + 1 + mb) & 1) ? accB : accA;
+      const f32x16& acP = ((PH0 + 1 + mb) & 1) ? accA : accB;
+      abx3_for<0, NKS>([&](auto ks_c) {
+        constexpr int ks = decltype(ks_c)::value;
+        if (mb == 7 && ks == 0) {
+          // block b + 1 has landed: only the NKS pieces of block b + 2 (issued above; in block 1 also the two coefficient
+          // loads behind them) may still be in flight
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B == 1 ? NKS + 2 : NKS) : "memory");
+          if (B == 2) asm volatile("" : "+v"(cfr[0]), "+v"(cfr[1]));
+        }
+        constexpr bool BURST = S1 && mb % PSTEP == 0;  // this phase opens with the stage-1 burst of r-block mb / PSTEP
+        if (BURST && ks == 0) {
+          // 4 heads x (cs 0, cs 1): the four first halves with the phase's four accumulator-free epilogue chunks between them (a
+          // lone wave issues nothing while an MFMA waits for the pipe: the 16-cycle shadows would stay empty), then the second
+          // halves -- four MFMAs behind their first halves, no dependent pair back to back
+          abx3_for<0, 4>([&](auto h_c) {
+            constexpr int h4 = decltype(h_c)::value;
+            ABX3_MFMA_S0(wa[h4], lf8[2 * h4], cfr[0]);
+            if (mb == 0) {
+              if (h4 == 0) finalize(b - 1);
+            } else {
+              epi_chunk(ABX3_IC(mb - 1), h_c, acP);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          });
+#pragma unroll
+          for (int h4 = 0; h4 < 3; ++h4) ABX3_MFMA_S(wa[h4], lf8[2 * h4 + 1], cfr[1]);
+          // (the burst's last MFMA: 8 wait states, so that a copy hipcc might place behind the burst reads finished results)
+          asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\ts_nop 7" : "+v"(wa[3]) : "v"(lf8[7]), "v"(cfr[1]));
+        }
+        if (mb == 7 && ks == NKS - 1) {
+          // the block's last MFMA: hipcc may copy live accumulators at the block's end (loop edges); 11 wait states make
+          // the result readable by then
+          if (ks == 0) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0\n\ts_nop 7\n\ts_nop 2" : "=&v"(acN) : "a"(bf[mb][ks]), "v"(xf[ks]));
+          else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0\n\ts_nop 7\n\ts_nop 2" : "+v"(acN) : "a"(bf[mb][ks]), "v"(xf[ks]));
+        } else if (ks == 0) {
+          ABX3_MFMA_A0(acN, bf[mb][0], xf[0]);
+        } else {
+          ABX3_MFMA_A(acN, bf[mb][ks], xf[ks]);
+        }
+        if (mb == 0) {
+          abx3_for<0, CPS>([&](auto i_c) {
+            constexpr int item = ks * CPS + decltype(i_c)::value;
+            if (item == 0 && !BURST) finalize(b - 1);
+            if (item >= 4) {                         // (second half of the slots: the stage-2 accumulators are complete)
+              constexpr int hh = item - 4;           // low band of head hh: terms k = 4 hi + c of this lane
+              pc[hh] = fmaf(pw[0], acP[4 * hh], pw[1] * acP[4 * hh + 1]);
+              ps[hh] = fmaf(pw[2], acP[4 * hh + 2], pw[3] * acP[4 * hh + 3]);
+            }
+          });
+          dma_piece(b + 2, SL, ks);
+          if (B == 1 && ks == NKS - 1) {
+            // coefficients of the next tile (its stage 1 runs in this tile's last block): requested BEHIND this block's DMA
+            // pieces -- the vmcnt(NKS + 2) of this block leaves them in flight, the vmcnt(NKS) of the next block covers them:
+            // two block times for a read that misses every cache
+            const u32x4* src = tab0 + (int64_t)tnext * 64;             // (uniform: scalar base + the lane's offset)
+            asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:512"
+                         : "=&v"(cfr[0]), "=&v"(cfr[1])
+                         : "v"(tab_lane), "s"(src)
+                         : "memory");
+          }
+        } else {
+          abx3_for<0, CPS>([&](auto i_c) {
+            constexpr int c = ks * CPS + decltype(i_c)::value;
+            if (!(BURST && c < 4)) epi_chunk(ABX3_IC(mb - 1), ABX3_IC(c), acP);   // (chunks 0..3 of a burst phase ran inside the burst)
+          });
+        }
+        s1_slot(ABX3_IC(mb + 1), ks_c);
+        if (mb == 7) {
+          xf[ks] = read_x(ks, SL ^ 1);                               // the next block's fragments
+          constexpr int wi = ks >= NKS - WD ? ks - (NKS - WD) : 0;
+          if (ks >= NKS - WD) wfr[wi] = read_w(wi);                  // and the first stage-2 A fragments
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    });
+  };
+
+  // ---- first block: its fragments
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NKS) : "memory");
+  stamp();  // 7
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) xf[ks] = read_x(ks, 0);
+#pragma unroll
+  for (int i = 0; i < WD; ++i) wfr[i] = read_w(i);
+
+  // ---- tiles of 4 blocks; the partial tail tile leaves through a side exit.  Stage 1 always runs in a tile's last block (after
+  //      the wave's last full tile it builds the image of the tail tile, or one nobody reads)
+  int b = 0, tt = 0;
+  do {
+    const int tnext = min(tt + 1, ntile - 1);
+    block(ABX3_IC(0), std::false_type{}, b, tnext);
+    if (++b == nblk) break;
+    block(ABX3_IC(1), std::false_type{}, b, tnext);
+    if (++b == nblk) break;
+    block(ABX3_IC(2), std::false_type{}, b, tnext);
+    if (++b == nblk) break;
+    block(ABX3_IC(3), std::true_type{}, b, tnext);
+    ++b;
+    ++tt;
+  } while (b < nblk);
+  // ---- drain: the epilogue of the last block's M-block 7, then its scores
+  stamp();
+  // (the last block's M-block 7 sits in set (9 B + 8) & 1 = B & 1: accB after an odd B, accA after an even one)
+  if ((b - 1) & 1) abx3_for<0, 8>([&](auto c_c) { epi_chunk(ABX3_IC(7), c_c, accB); });
+  else abx3_for<0, 8>([&](auto c_c) { epi_chunk(ABX3_IC(7), c_c, accA); });
+  finalize(b - 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the re-read pieces of the last blocks: nothing may land in LDS after the wave ends)
+  stamp();
+#undef ABX3_MFMA_A0
+#undef ABX3_MFMA_A
+#undef ABX3_MFMA_V0
+#undef ABX3_MFMA_V
+#undef ABX3_MFMA_S0
+#undef ABX3_MFMA_S
+#undef ABX3_IC
+}
+
+}  // namespace

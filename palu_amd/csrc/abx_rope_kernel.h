@@ -39,6 +39,9 @@ int palu_abx2_try_launch(const void* params, int nwg, int bits, hipStream_t stre
 int palu_abx2_try_launch_windows(const void* params, int nwg, int bits, void* scratch, int64_t acc_ld, hipStream_t stream);
 size_t palu_abx2_frag_bytes(int H, int G, int R);   // 0 when the shape is not covered
 int palu_abx2_prepare_b(const void* b, int64_t sb_h, int64_t sb_r, int64_t sb_d, int H, int G, int R, void* frag2, hipStream_t stream);
+// position-split form of the two-band kernel (abx_rope3.hip, abx_rope3_kernel.h): fp16 latents, one launch (no column
+// windows); `params` as for palu_abx2_try_launch with the coefficient table filled in, nks = R / 16
+int palu_abx3_launch(const void* params, int nks, hipStream_t stream);
 
 namespace {
 
@@ -82,6 +85,10 @@ struct AbxParams {
   const u32x4* bfrag2;
   const u32x4* rope_tab;
   int tab_tile0;
+  // position-split kernel (abx_rope3_kernel.h): exact-angle RoPE start tables that follow the coefficient tiles in the same
+  // table (abx2_rope_start_kernel): rope_t1 [tile][hi 2][q 16] (cos, sin)(128 tile f_i), rope_t2 [n 0..32][hi][q] (cos, sin)(n f_i)
+  const float* rope_t1;
+  const float* rope_t2;
 };
 
 // heads per workgroup = 2*NMB; each MFMA M-block carries 2 heads x 8 pairs x {i, i+64}

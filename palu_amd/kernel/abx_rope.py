@@ -68,6 +68,27 @@ def one_band():
                        "palu_rope_table_register")
 
 
+@contextlib.contextmanager
+def pair_split():
+    """Run the enclosed launches on the pair-split form of the two-band kernel (csrc/abx_rope2_kernel.h) instead of the
+    position-split one (csrc/abx_rope3_kernel.h) -- A/B measurements and cross-checks.  Process-wide."""
+    old = _lib.lib.palu_abx_set_position_split(0)
+    try:
+        yield
+    finally:
+        _lib.lib.palu_abx_set_position_split(old)
+
+
+@contextlib.contextmanager
+def position_split(min_tiles: int = 1):
+    """Run the enclosed launches on the position-split kernel wherever the shape allows (default: from 3 tiles per wave on)."""
+    old = _lib.lib.palu_abx_set_position_split(int(min_tiles))
+    try:
+        yield
+    finally:
+        _lib.lib.palu_abx_set_position_split(old)
+
+
 def set_fold(enable: bool) -> bool:
     """Numerics switch of the fast path (palu_abx_set_fold): True (default) folds q into the B
     fragments (one extra fp16 operand rounding, fewer VALU ops); False keeps q in fp32."""

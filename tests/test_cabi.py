@@ -58,7 +58,8 @@ def test_host_only_entry_points_work_without_gpu():
     # 4 heads per group at R in {32, 64, 128}: the fragments of both score kernels (one-band | two-band)
     assert _lib.lib.palu_abx_bfrag_bytes(32, 8, 128) == 2 * 32 * 128 * 128 * 2
     assert _lib.lib.palu_abx_bfrag_bytes(16, 8, 128) == 16 * 128 * 128 * 2       # other group sizes: one-band only
-    assert _lib.lib.palu_rope_table_bytes(1 << 18) == 2048 * 1024                # 1 KB per 128-position tile
+    # 1 KB of low-band coefficients + 256 B of exact-angle start values per 128-position tile, 33 x 256 B of in-block offsets
+    assert _lib.lib.palu_rope_table_bytes(1 << 18) == 2048 * (1024 + 256) + 33 * 256
     assert _lib.lib.palu_abx_bfrag_bytes(32, 8, 512) == 2 * 32 * 512 * 128 * 2   # + one two-band set per 128-column window
     assert _lib.lib.palu_abx_bfrag_bytes(32, 5, 128) == 0                       # H % G != 0
     assert _lib.lib.palu_pv_workspace_bytes(32, 8, 2048, 96) > 0

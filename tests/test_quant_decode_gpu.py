@@ -242,14 +242,20 @@ def test_quantised_kernels_full_size(bits, R, Rv, L):
     properties; the oracle cannot hold these sizes in seconds)."""
     from palu_amd import _lib
     from palu_amd.kernel import quant as q
-    from palu_amd.kernel.abx_rope import abx, prepare_b, rope_inv_freq
+    from palu_amd.kernel.abx_rope import abx, pair_split, prepare_b, rope_inv_freq
     H, G = 32, 8
     g = torch.Generator(device=DEV).manual_seed(bits)
     a = torch.randn(H, 1, 128, dtype=torch.float16, device=DEV, generator=g)
     b = (torch.randn(H, R, 128, device=DEV, generator=g) / math.sqrt(R)).half()
     x = torch.randn(G, L, R, dtype=torch.float16, device=DEV, generator=g)
     codes, meta, deq = q.quantize_pack(x, bits, want_dequant=True)
-    ref = abx(a, b, deq)
+    # (round 5: at this size fp16 latents take the position-split form of the two-band kernel, which sums a position's RoPE
+    # pairs in another order; the packed kernels are the pair-split form: bit identity is with THAT form on the same rows,
+    # and the default fp16 launch agrees with it to rounding)
+    with pair_split():
+        ref = abx(a, b, deq)
+    dflt = abx(a, b, deq)
+    assert (dflt.float() - ref.float()).abs().max().item() <= 1e-3 * ref.float().abs().max().item()
     out = torch.empty(H, 1, L, dtype=torch.float16, device=DEV)
     frag, inv = prepare_b(b, G), rope_inv_freq(x.device)
     _lib.check(_lib.lib.palu_abx_rope_q(a.data_ptr(), a.stride(0), a.stride(2), frag.data_ptr(), codes.data_ptr(),
