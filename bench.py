@@ -13,9 +13,13 @@ fused reconstruct-K/RoPE/q.K^T (abx) -> softmax + latent P.V -> o_proj GEMV, i.e
 kernel/palu_attention.py:147-263 through the C ABI (palu_decode_step_f16).
 
 N > 1: head-group parallel (strong scaling of the same step): rank r owns G/N groups; one RCCL collective per
-step -- `--oproj sharded` (default): every rank multiplies its context slice by its 1/N column block of W_o' and
-the ranks all-reduce the [hidden] fp32 partials (16 KiB); `--oproj replicated`: all-gather of the [H/N*Rv] fp16
-slices and the full o_proj on every rank.  `collective_us` is the collective alone (CUDA events, max over ranks).
+step -- `--oproj replicated` (default, BASELINE.json config 5's wording): all-gather of the [H/N*Rv] fp16 context
+slices and the full o_proj on every rank; `--oproj sharded`: every rank multiplies its context slice by its 1/N
+column block of W_o' and the ranks all-reduce the [hidden] fp32 partials (16 KiB).  The other form is timed beside
+the headline one (`oproj_alt`).  `collective_us` is the collective alone (CUDA events, max over ranks).
+`python bench.py --gpus N` without torch.distributed.run spawns its N ranks itself (one JSON line from rank 0).
+`--dry_plan`: the sharding plan, the weight shards and the step's collective at the real message sizes over gloo on
+the CPU -- no kernels (a multi-process plumbing check that runs without GPUs).
 
 Prints ONE JSON line (rank 0).  `value` = decode-step microseconds (lower is better); `roofline` is the
 dominant kernel of the step by measured time, `roofline_abx` the fused score kernel the north star
@@ -461,6 +465,75 @@ def bench_c5_slice(steps, dev):
             "fused_attention_core": bool(_lib.lib.palu_decode_attn_preferred(4, 1, L, Rk, Rv, D))}
 
 
+def executed_two_band_flops(Rk, L):
+    """Matrix flops the two-band score kernels EXECUTE per launch: per 128-position tile and latent group
+    36 NKS v_mfma_f32_32x32x16_f16 (8 high-band M-blocks + the low band's stage 2, NKS = R / 16 k-steps, 4 blocks of 32
+    positions) and 8 NKS v_mfma_f32_16x16x32_f16 (stage 1)."""
+    nks = Rk // 16
+    tiles = (L + 127) // 128
+    return G * tiles * (36 * nks * 2 * 32 * 32 * 16 + 8 * nks * 2 * 16 * 16 * 32)
+
+
+def dry_plan(args, world, rank):
+    """`--dry_plan`: everything of an N-rank run that needs no GPU -- the sharding plan, the weight shards of both o_proj
+    forms (shapes and that the shards tile the full weights), and the step's collective at the real message sizes over
+    gloo -- then rank 0 prints ONE JSON line with the contract's keys (value = null: nothing was timed)."""
+    import torch.distributed as dist
+    from palu_amd.kernel import head_parallel as hp
+    rank_k, rank_v, Lp = args.rank_k, args.rank_v, args.prompt_len
+    Rk, Rv = rank_k // G, rank_v // G
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    plan = hp.make_plan(world, rank, H, G, D, Rk, Rv)
+    torch.manual_seed(1234)
+    hid = 256                                           # (the plan does not depend on the hidden size: small weights)
+    full = {"wq": torch.randn(H * D, hid).half(), "vt_k": torch.randn(rank_k, hid).half(), "vt_v": torch.randn(rank_v, hid).half(),
+            "b": torch.randn(H, Rk, D).half(), "wo": torch.randn(hid, H * Rv).half()}
+    shapes = {}
+    for form in ("replicated", "sharded"):
+        w = hp.shard_weights(plan, full, oproj=form)
+        shapes[form] = {k: list(v.shape) for k, v in w.items()}
+        assert w["wq"].shape[0] == plan.heads_local * D and w["b"].shape[0] == plan.heads_local
+        assert w["vt_k"].shape[0] == plan.groups_local * Rk and w["vt_v"].shape[0] == plan.groups_local * Rv
+        assert w["wo"].shape[1] == (H * Rv if form == "replicated" else plan.heads_local * Rv)
+    checks = {"world": world}
+    if world > 1:
+        # the collective of each form at the step's real message size
+        ctx = torch.full((plan.heads_local * Rv,), float(rank + 1), dtype=torch.float16)
+        allc = torch.empty(H * Rv, dtype=torch.float16)
+        hp.DistExchange(None).all_gather_into(allc, ctx)
+        ok_g = all(float(allc[r * plan.heads_local * Rv]) == r + 1 for r in range(world))
+        part = torch.full((HIDDEN,), float(rank + 1), dtype=torch.float32)
+        hp.DistExchange(None).all_reduce_sum_(part)
+        ok_r = float(part[0]) == world * (world + 1) / 2
+        # the shards tile the full weight: the sum over ranks of the sharded o_proj partials equals the replicated product
+        c_full = torch.randn(H * Rv, generator=torch.Generator().manual_seed(7)).half()
+        mine = (hp.shard_weights(plan, full, "sharded")["wo"].float()
+                @ c_full[plan.head0 * Rv:(plan.head0 + plan.heads_local) * Rv].float())
+        dist.all_reduce(mine)
+        ok_w = bool(torch.allclose(mine, full["wo"].float() @ c_full.float(), rtol=1e-4, atol=1e-2))
+        checks.update({"all_gather_ok": ok_g, "all_reduce_ok": ok_r, "sharded_oproj_sums_to_replicated": ok_w,
+                       "all_gather_message_bytes": plan.heads_local * Rv * 2, "all_reduce_message_bytes": HIDDEN * 4})
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({
+            "metric": baseline_metric(rank_k, Lp), "value": None, "unit": "us", "n_gpus": world, "steps": 0, "warmup": 0,
+            "ms_per_step": None, "higher_is_better": False, "scaling": "strong", "vs_baseline": None, "dtype": "f16",
+            "data": "synthetic", "dry_plan": True,
+            "config": {"workload": "dry plan (no kernels): head-group sharding of rank_k=%d rank_v=%d prompt_len=%d over %d ranks"
+                                   % (rank_k, rank_v, Lp, world),
+                       "parallelism": "head-group x%d, oproj=%s" % (world, args.oproj)},
+            "plan": {"groups_local": plan.groups_local, "heads_local": plan.heads_local, "ctx_local": plan.ctx_local,
+                     "cache_rows_per_rank": plan.groups_local * (Lp + 1), "shards": shapes},
+            "checks": checks}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    bad = [k for k, v in checks.items() if v is False]
+    if bad:
+        raise SystemExit("dry plan failed: %s" % bad)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -470,7 +543,7 @@ def main():
     ap.add_argument("--rank_v", type=int, default=3072)
     ap.add_argument("--prompt_len", type=int, default=65536)
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--oproj", choices=("replicated", "sharded"), default="sharded",
+    ap.add_argument("--oproj", choices=("replicated", "sharded"), default="replicated",
                     help="N > 1: all-gather + replicated o_proj, or column-sharded o_proj + all-reduce of the [hidden] partials")
     ap.add_argument("--exchange", choices=("rccl", "p2p"), default="rccl",
                     help="N > 1: the step's one collective through RCCL (torch.distributed) or through the one-shot "
@@ -480,14 +553,28 @@ def main():
     ap.add_argument("--no_extra_configs", action="store_true", help="skip the config 3/4/5 sub-records")
     ap.add_argument("--no_model32", action="store_true", help="skip the whole-model (32-layer) decode sub-record")
     ap.add_argument("--cpu_sample_len", type=int, default=0, help="positions used for the CPU baseline (0 = full)")
+    ap.add_argument("--dry_plan", action="store_true",
+                    help="no kernels: sharding plan + weight shards + the step's collective over gloo on the CPU, one JSON line")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: spawn the N ranks (one per GPU) and hand their output through
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit("--gpus %d does not match WORLD_SIZE=%d" % (args.gpus, world))
+    if args.dry_plan:
+        return dry_plan(args, world, rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -512,6 +599,11 @@ def main():
             "b": (torch.randn(H, Rk, D, device=dev) * Rk ** -0.5).half(),
             "wo": (torch.randn(HIDDEN, H * Rv, device=dev) * 0.01).half()}
     w = {k: (v.contiguous() if k != "wo" else v) for k, v in hp.shard_weights(plan, full, oproj=args.oproj).items()}
+    alt_oproj = "sharded" if args.oproj == "replicated" else "replicated"
+    w_alt = None
+    if world > 1:            # the step's other collective form, timed beside the headline one
+        w_alt = dict(w)
+        w_alt["wo"] = hp.shard_weights(plan, full, oproj=alt_oproj)["wo"]
     del full
     Gl = plan.groups_local
     k_cache = torch.randn(Gl, cap, Rk, device=dev, dtype=torch.float16)       # run_latency_attention.py:62-63
@@ -578,6 +670,18 @@ def main():
     best = min(ab, key=lambda k_: ab[k_]["device_us"])
     us_step = ab[best]["device_us"]
     coll_us = None
+    alt_rec = None
+    if world > 1 and w_alt is not None:
+        dec_alt = hp.HeadParallelDecoder(plan, w_alt, k_cache, v_cache, HIDDEN, exchange=p2p if args.exchange == "p2p" else None)
+        walls, evs = time_reps(lambda: dec_alt.step(hidden, Lp, Lp), args.steps, args.warmup, sync, reps=3)
+        t = torch.tensor([walls, evs], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        alt_rec = {"oproj": alt_oproj, "launch": "direct",
+                   "message": ("all-reduce of [hidden] fp32 (16 KiB)" if dec_alt.oproj_sharded else
+                               "all-gather of [H/N * Rv] fp16 slices (%d B per rank)" % (plan.heads_local * Rv * 2)),
+                   "device_us": round(_median(t[1].tolist()) * 1e3 / args.steps, 2),
+                   "host_wall_us": round(_median(t[0].tolist()) * 1e3 / args.steps, 2)}
+        del dec_alt
     if world > 1:
         # collective-only latency: CUDA events around the step's one collective, median over 50 steps, max over ranks
         ts = []
@@ -683,7 +787,7 @@ def main():
                        "parallelism": ("head-group x%d + %s %s" % (world, "RCCL" if args.exchange == "rccl" else "one-shot P2P exchange", "all-gather, replicated o_proj" if args.oproj == "replicated"
                                                                        else "column-sharded o_proj + all-reduce of [hidden] fp32"))
                        if world > 1 else "single GPU",
-                       "kernels_per_step": 5 if world == 1 else 6,
+                       "kernels_per_step": 5 if world == 1 else 6,   # qkv, abx, softmax.PV partials, merge, o_proj (+ the collective)
                        "launch": ("hipGraph replay of the captured step" if best == "graph_replay" else "direct launches")
                                  + " (the faster of the forms in launch_ab)",
                        "timing": "value = median over %d repetitions of the device-event time of exactly --steps steps "
@@ -694,6 +798,7 @@ def main():
             "host_wall_us": ab[best]["host_wall_us"],
             "p20_us": ab[best]["device_us_p20"], "p80_us": ab[best]["device_us_p80"],
             "collective_us": None if coll_us is None else round(coll_us, 2),
+            "oproj_alt": alt_rec,
             "collective": None if world == 1 else {
                 "in_step": args.exchange, "in_step_us": round(coll_us, 2), "alone_back_to_back": other_name,
                 "alone_back_to_back_us": None if other_us is None else round(other_us, 2),
@@ -716,27 +821,68 @@ def main():
             rec["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": kern[dom]["hbm_GBps"], "peak": HBM_PEAK_GBPS,
                                "unit": "GB/s", "frac": kern[dom]["hbm_frac"], "traffic": traffic,
                                "traffic_source": tsrc if traffic is not None else None}
-            ab, af = alg["abx"]
-            # the same launch on the one-band kernel (coefficient tables out of the registry), same box, same loop
-            from palu_amd.kernel.abx_rope import one_band
+            ab_, af = alg["abx"]
+            # the same launch on the other score kernels, same box, same loop: the one-band kernel (coefficient tables out
+            # of the registry) and the pair-split form of the two-band kernel
+            from palu_amd.kernel.abx_rope import one_band, pair_split
             two_band = bool(lib.palu_abx_two_band_selected(inv.data_ptr(), H, G, L, Rk, 0))
+            split = bool(lib.palu_abx_position_split_selected(inv.data_ptr(), H, G, L, Rk, 0))
             with one_band():
                 _, kms1 = time_loop(k_abx, n, 10, torch.cuda.synchronize, reps=5)
-            rec["roofline_abx"] = {"kernel": "abx_rope2_kernel (two-band)" if two_band else "abx_rope_kernel (one-band)",
-                                   "one_band_kernel_us": round(kms1 * 1e3 / n, 2),
-                                   "flops_note": "achieved = ALGORITHMIC flops (2*H*L*R*D + 5*H*L*D, SURVEY 8(d)) / time; the "
-                                                 "two-band kernel executes 320 of every 512 MFMAs of that count (low RoPE band "
-                                                 "as a per-tile polynomial, DESIGN 4.1)",
-                                   "bound": "mfma", "achieved": kern["abx"]["tflops"],
-                                   "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                   "frac": round(kern["abx"]["tflops"] / MFMA_PEAK_TFLOPS, 4),
-                                   "hbm_achieved_GBps": kern["abx"]["hbm_GBps"], "hbm_frac": kern["abx"]["hbm_frac"],
-                                   "traffic": None if traffic is None else json.load(open(tf)).get("abx"),
-                                   "measured_power_wall_TFLOPs": MFMA_WALL_TFLOPS,
-                                   "frac_of_power_wall": round(kern["abx"]["tflops"] / MFMA_WALL_TFLOPS, 4),
-                                   "note": "arithmetic intensity gs*D=512 flop/B > ridge: MFMA-bound (SURVEY F4); the "
-                                           "power wall is what an MFMA-only random-operand fp16 stream sustains on "
-                                           "this part (profiles/r02_ubench_issue_pmc_clock.txt: 1.69 GHz at 92 % MFMA busy)"}
+            with pair_split():
+                _, kms2 = time_loop(k_abx, n, 10, torch.cuda.synchronize, reps=5)
+            ex_f = executed_two_band_flops(Rk, L) if two_band else af
+            us_abx = kern["abx"]["us"]
+            pmc = {}
+            if os.path.exists(tf):
+                pmc = json.load(open(tf))
+            rec["roofline_abx"] = {
+                "kernel": ("abx_rope3_kernel (two-band, position-split)" if split else
+                           "abx_rope2_kernel (two-band, pair-split)" if two_band else "abx_rope_kernel (one-band)"),
+                "one_band_kernel_us": round(kms1 * 1e3 / n, 2), "pair_split_kernel_us": round(kms2 * 1e3 / n, 2),
+                "bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_PEAK_TFLOPS,
+                # contract fields: ALGORITHMIC flops (2*H*L*R*D + 5*H*L*D) / time
+                "achieved": kern["abx"]["tflops"], "frac": round(kern["abx"]["tflops"] / MFMA_PEAK_TFLOPS, 4),
+                # what the matrix pipe actually does: the two-band kernels execute 36 NKS big + 8 NKS small MFMAs per tile
+                # and group (320 of every 512 MFMA-equivalents of the algorithmic count)
+                "executed_flops": ex_f, "executed_tflops": round(ex_f / us_abx * 1e-6, 1),
+                "mfma_frac_executed": round(ex_f / us_abx * 1e-6 / MFMA_PEAK_TFLOPS, 4),
+                "measured_power_wall_TFLOPs": MFMA_WALL_TFLOPS,
+                "frac_of_power_wall": round(ex_f / us_abx * 1e-6 / MFMA_WALL_TFLOPS, 4),
+                "mfma_busy": pmc.get("abx_mfma_busy"), "clock_GHz": pmc.get("abx_clock_GHz"),
+                "socket_power_W": pmc.get("abx_socket_power_W"),
+                "pmc_source": pmc.get("abx_pmc_source"),
+                "hbm_achieved_GBps": kern["abx"]["hbm_GBps"], "hbm_frac": kern["abx"]["hbm_frac"],
+                "traffic": pmc.get("abx"),
+                "note": "arithmetic intensity gs*D = 512 flop/B > ridge: matrix-pipe work (SURVEY F4).  frac_of_power_wall and "
+                        "mfma_frac_executed count EXECUTED flops; the power wall is what an MFMA-only random-operand fp16 "
+                        "stream sustains on this part (profiles/r02_ubench_issue_pmc_clock.txt: 1.69 GHz at 92 % MFMA busy); "
+                        "mfma_busy / clock / socket power come from committed profiler and rocm-smi runs of this command "
+                        "(pmc_source), not from this run"}
+            # the reference's own bench points (run_latency_kernel.py:11-12: 4k / 16k / 64k / 256k cached positions), fp16,
+            # with the kernel each length selects
+            sweep = []
+            for Ls in (4096, 16384, 65536, 262144):
+                try:
+                    xs = torch.randn(G, Ls, Rk, device=dev, dtype=torch.float16)
+                    so = torch.empty(H, Ls, dtype=torch.float16, device=dev)
+
+                    def k_s():
+                        _lib.check(lib.palu_abx_rope_f16(q_buf.data_ptr(), D, 1, dec.frag.data_ptr(), xs.data_ptr(), xs.stride(0),
+                                                         xs.stride(1), so.data_ptr(), so.stride(0), H, G, Ls, Rk, D,
+                                                         inv.data_ptr(), 0, s()), "abx")
+                    _, kms = time_loop(k_s, 30, 5, torch.cuda.synchronize, reps=3)
+                    tb = bool(lib.palu_abx_two_band_selected(inv.data_ptr(), H, G, Ls, Rk, 0))
+                    sp = bool(lib.palu_abx_position_split_selected(inv.data_ptr(), H, G, Ls, Rk, 0))
+                    bs = 2 * G * Ls * Rk + 2 * H * Rk * D + 2 * H * D + 2 * H * Ls
+                    sweep.append({"L": Ls, "us": round(kms * 1e3 / 30, 2),
+                                  "kernel": "two-band position-split" if sp else "two-band pair-split" if tb else "one-band",
+                                  "hbm_frac": round(bs / (kms * 1e3 / 30) * 1e-3 / HBM_PEAK_GBPS, 4)})
+                    del xs, so
+                except Exception as e:                      # noqa: BLE001
+                    sweep.append({"L": Ls, "error": repr(e)[:120]})
+            rec["abx_sweep"] = sweep
+            torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             cl = args.cpu_sample_len or L
             t0 = time.perf_counter()
@@ -747,6 +893,13 @@ def main():
                                              "the same shapes, %d cached positions, min / median of 3 timed runs after 1 "
                                              "warm-up; host %s" % (cl, _cpu_model()),
                                    "seconds_spent": round(time.perf_counter() - t0, 1)}
+            # BASELINE.md section 3 / configs[0]: the reference's own CPU-runnable case (rank_k 256, rank_v 768, gs 4, 2048 cached
+            # positions), the same port, timed beside the headline configuration's
+            c1_min, c1_med, _, _ = cpu_baseline(256, 768, 2048 + 1)
+            rec["cpu_baseline_c1"] = {"value": round(c1_min, 1), "median": round(c1_med, 1), "unit": "us",
+                                      "cores": torch.get_num_threads(), "kind": "port",
+                                      "sample": "oracle.decode_step at BASELINE configs[0] (rank_k=256 rank_v=768 gs=4 "
+                                                "prompt_len=2048 fp16), min / median of 3 timed runs after 1 warm-up"}
             # parity of the HIP step against the oracle output just computed, same inputs, full size
             pmax, pscale = gpu_step_parity(cpu_in, cpu_out, cl)
             rec["parity_max_abs"] = round(pmax, 6)

@@ -86,9 +86,9 @@ int palu_abx_rope_f16(const void* a, int64_t sa_h, int64_t sa_d,
  *   [pos_first, pos_first + npos), pos_first % 128 == 0;
  *   palu_rope_table_register ties it to the DEVICE POINTER the caller passes as `inv_freq` (the registry key; the table
  *   must stay alive while registered; inv_freq_32 = the host value of inv_freq[32], which bounds the band's angles).
- * A launch takes the two-band kernel when a registered table covers its positions, pos0 % 128 == 0, pos0 + L <= 2^18 and
- * inv_freq[32] * (pos0 + L) < 2048 rad (the band uses the exact angle l*f; the oracle's fp32 rounding of l*f is <= 2^-14 rad
- * there) and 64 * inv_freq[32] <= 0.7 rad (the polynomial's remainder: theta >= ~8400 at head_dim 128); otherwise, or with PALU_ABX_TWO_BAND=0 in the environment, it runs the one-band kernel -- same results within
+ * A launch takes the two-band kernel when a registered table covers its positions, pos0 % 128 == 0, pos0 + L <= 2^18 + 4096 and
+ * inv_freq[32] * (pos0 + L) < 2700 rad (the band uses the exact angle l*f; the oracle's fp32 rounding of l*f is <= 2^-13 rad
+ * there, measured at 262 145 positions: error and rms at the oracle's own level) and 64 * inv_freq[32] <= 0.7 rad (the polynomial's remainder: theta >= ~8400 at head_dim 128); otherwise, or with PALU_ABX_TWO_BAND=0 in the environment, it runs the one-band kernel -- same results within
  * the oracle's own fp16 rounding.  palu_abx_two_band_selected reports the decision for a launch. */
 size_t palu_rope_table_bytes(int npos);
 int palu_rope_table_build(const float* inv_freq, int pos_first, int npos, void* table, palu_stream_t stream);
@@ -103,6 +103,7 @@ int palu_abx_two_band_selected(const float* inv_freq, int H, int G, int L, int R
  * starts there), n >= 1 = from n tiles per wave on (1 = whenever the shape allows); returns the previous setting.
  * Process-wide, for A/B measurements. */
 int palu_abx_set_position_split(int enable);
+int palu_abx_position_split_selected(const float* inv_freq, int H, int G, int L, int R, int pos0);
 size_t palu_abx_scratch_bytes(int H, int G, int L, int R);
 int palu_abx_rope_ws_f16(const void* a, int64_t sa_h, int64_t sa_d, const void* bfrag,
                          const void* x, int64_t sx_g, int64_t sx_l, void* out, int64_t so_h,
@@ -391,7 +392,8 @@ int palu_prefill_attn_f16(const void* q, int64_t sq_h, int64_t sq_t, const void*
  * reference materialises the full K and the [H, T, T] scores, palu_attention.py:199-205): k / vt hold the kv positions
  * [kv0, kv0 + Tk) only; past_rel = (absolute position of query row 0) - kv0, negative when the panel starts behind the first
  * query.  The online-softmax state of every (head, query) travels between the launches in fp32: state_o [H][Tq][Rv]
- * (un-normalised context), state_ml [H][Tq][8] (running maximum + partial sums); palu_prefill_state_bytes(H, Tq, Rv, 0 / 1)
+ * (un-normalised context), state_ml [Rv / 32][H][Tq][8] (running maximum + partial sums, one slice per column block a launch
+ * may split a query tile into); palu_prefill_state_bytes(H, Tq, Rv, 0 / 1)
  * gives their sizes.  first != 0: start from the empty state (the buffers need no initialisation); last != 0: normalise and
  * write `out` instead of the state.  The panels of one (query chunk, head set) run in ascending kv order on one stream. */
 int palu_prefill_attn_panel_f16(const void* q, int64_t sq_h, int64_t sq_t, const void* k, int64_t sk_h, int64_t sk_t,

@@ -48,6 +48,7 @@ SIGNATURES = {
     "palu_rope_table_unregister": (i32, [vp]),
     "palu_abx_two_band_selected": (i32, [vp, i32, i32, i32, i32, i32]),
     "palu_abx_set_position_split": (i32, [i32]),
+    "palu_abx_position_split_selected": (i32, [vp, i32, i32, i32, i32, i32]),
     "palu_abx_scratch_bytes": (sz, [i32, i32, i32, i32]),
     "palu_abx_rope_ws_f16": (i32, [vp, i64, i64, vp, vp, i64, i64, vp, i64, i32, i32, i32, i32, i32, vp, i32, vp, vp]),
     "palu_abx_rope_shared_f16": (i32, [vp, i64, i64, vp, vp, i64, i64, vp, i64, i32, i32, i32, i32, i32, vp, i32, vp]),

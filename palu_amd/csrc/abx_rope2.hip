@@ -160,15 +160,20 @@ extern "C" int palu_rope_table_unregister(const float* inv_freq) {
 extern "C" int palu_abx_two_band_selected(const float* inv_freq, int H, int G, int L, int R, int pos0) {
   if (!two_band_enabled() || !palu_abx2_frag_bytes(H, G, R) || L <= 0 || pos0 < 0 || pos0 % TL) return 0;
   if (R > 128 && ((int64_t)L + 3 * 128) * R * 2 >= ((int64_t)1 << 31)) return 0;
-  if ((int64_t)pos0 + L > 262144) return 0;
+  // positions: the high band corrects the oracle's fp32 angle rounding to first order in the residual (<= 2^-6 rad below 2^19:
+  // the neglected term stays below 1.3e-4 on the highest-frequency pair alone); the tables hold 2^18 + 4096 positions -- a
+  // 256k prompt and what a generation appends
+  if ((int64_t)pos0 + L > 266240) return 0;
   std::lock_guard<std::mutex> lk(g_tab_mutex);
   for (const auto& t : g_tabs)
     if (t.inv_freq == inv_freq) {
       const int first = pos0 / TL, last = (pos0 + L + TL - 1) / TL;
       // psi_max = 64 f_32 <= 0.7 rad keeps the degree-7 Taylor remainder below 0.7^8 / 8! = 1.4e-6 (theta >= ~8400 at D = 128);
-      // f_32 (pos0 + L) < 2048 rad keeps the oracle's fp32 rounding of the band's angles below 2^-14 rad
+      // f_32 (pos0 + L) < 2700 rad: the low band uses the exact angle l f, the oracle rounds l f to fp32 first -- <= 2^-13 rad
+      // below 4096 rad, on the band's highest frequency only.  Measured at the end of a 262 145-position cache (2621 rad,
+      // tests/test_two_band_gpu.py::test_two_band_at_256k_positions): error vs fp64 and rms at the oracle's own level
       return first >= t.tile_first && last <= t.tile_first + t.ntiles && 64.0f * t.f_low <= 0.7f &&
-             t.f_low * (float)(pos0 + L) < 2048.0f;
+             t.f_low * (float)(pos0 + L) < 2700.0f;
     }
   return 0;
 }
@@ -180,6 +185,15 @@ extern "C" int palu_abx_set_position_split(int enable) {
   g_position_split = enable ? 1 : 0;
   if (enable > 0) g_split_min_tiles = enable;        // (1 = whenever the shape allows, n = from n tiles per wave on)
   return o;
+}
+
+// 1 when an fp16 launch with these positions takes the position-split form (introspection for tests and the bench)
+extern "C" int palu_abx_position_split_selected(const float* inv_freq, int H, int G, int L, int R, int pos0) {
+  if (!(R == 32 || R == 64 || R == 128) || !palu_abx_two_band_selected(inv_freq, H, G, L, R, pos0)) return 0;
+  AbxParams p = {};
+  p.G = G;
+  p.L = L;
+  return position_split_preferred(p) ? 1 : 0;
 }
 
 static unsigned long long* g_abx2_dbg = nullptr;
@@ -238,6 +252,11 @@ int palu_abx2_try_launch_windows(const void* params, int nwg, int bits, void* sc
   for (int i = 0; i < nw; ++i)
     if (!palu_abx_two_band_selected(p0.inv_freq, p0.H, p0.G, p0.L, wdt[i], p0.pos0)) return PALU_ABX2_SKIP;
   if (bits == 0 && ((int64_t)p0.L + 3 * 128) * p0.sx_l * 2 >= ((int64_t)1 << 31)) return PALU_ABX2_SKIP;
+  // a padded last window of fp16 rows (96 valid of 128 columns) over-reads into what follows a row and multiplies it by zero
+  // fragment rows: fine while that is the next row's (finite) latents, i.e. rows packed back to back -- behind a wider row
+  // stride sits padding nobody initialised (0 x NaN = NaN): those launches take the one-band kernel's masked staging
+  for (int i = 0; i < nw; ++i)
+    if (bits == 0 && val[i] != wdt[i] && p0.sx_l != p0.R) return PALU_ABX2_SKIP;
   const u32x4* frag = p0.bfrag2;
   int c0 = 0;
   for (int i = 0; i < nw; ++i) {

@@ -11,6 +11,11 @@
 // slot it overwrites in exchange e+2 is no longer being read.  The epoch lives in the buffer and is advanced by the kernel
 // itself, so a captured hipGraph replays correctly.  The reference has no collective (it is single-GPU); RCCL through
 // torch.distributed stays available as the baseline (palu_amd/kernel/head_parallel.py: DistExchange).
+// The buffer is UNCACHED device memory (hipExtMallocWithFlags, hipDeviceMallocUncached; fine-grained as the fallback): a
+// running kernel polls flags and then reads slots that PEER GPUs write over xGMI -- ordinary (coarse-grained) hipMalloc
+// memory gives no coherence inside a kernel (the owner's L2 may keep serving stale lines), which is why RCCL allocates its
+// flags and staging buffers the same way.  A wait that times out poisons the output (all-ones bytes = NaN in fp16 / fp32)
+// instead of reducing whatever the slots hold.
 #include <string.h>
 
 #include "palu_common.h"
@@ -39,8 +44,9 @@ __global__ __launch_bounds__(EX_THREADS) void exchange_kernel(ExParams p) {
   const int tid = threadIdx.x;
   char* mine = p.peers[p.rank];
   unsigned* ctrl = reinterpret_cast<unsigned*>(mine);
-  __shared__ unsigned e_sh;
+  __shared__ unsigned e_sh, timeout_sh;
   if (tid == 0) {
+    timeout_sh = 0u;
     const unsigned e = ctrl[0] + 1;    // only this rank's exchange kernels touch its epoch word, one at a time (stream order)
     ctrl[0] = e;
     e_sh = e;
@@ -70,15 +76,20 @@ __global__ __launch_bounds__(EX_THREADS) void exchange_kernel(ExParams p) {
       __builtin_amdgcn_s_sleep(8);
       if (++spins > p.max_spin) {          // a peer never arrived: report instead of hanging the GPU
         ctrl[1] = e;
+        timeout_sh = 1u;
         break;
       }
     }
   }
   __syncthreads();
   __threadfence_system();
-  // 4. the n slots of my buffer -> out
+  // 4. the n slots of my buffer -> out (poison after a timed-out wait: the slots of the missing peers hold old data)
   const char* data = mine + EX_DATA_OFF + (size_t)par * p.n * p.slot_bytes;
-  if (p.mode == 0) {
+  if (timeout_sh) {
+    const u32x4 bad = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    const size_t nout = p.mode == 0 ? nchunk * p.n : nchunk;
+    for (size_t i = tid; i < nout; i += EX_THREADS) reinterpret_cast<u32x4*>(p.out)[i] = bad;
+  } else if (p.mode == 0) {
     for (int q = 0; q < p.n; ++q) {
       const u32x4* s = reinterpret_cast<const u32x4*>(data + (size_t)q * p.slot_bytes);
       u32x4* d = reinterpret_cast<u32x4*>(p.out + (size_t)q * p.bytes);
@@ -104,8 +115,13 @@ extern "C" size_t palu_exchange_bytes(int nranks, size_t slot_bytes) {
 // Setup (not part of a step; allocates): zero-initialised device memory that other processes can map.
 extern "C" int palu_exchange_alloc(size_t bytes, void** ptr) {
   PALU_REQUIRE(ptr && bytes > 0, PALU_ERR_ARG, "exchange_alloc: bad arguments");
-  hipError_t e = hipMalloc(ptr, bytes);
-  PALU_REQUIRE(e == hipSuccess, PALU_ERR_LAUNCH, "exchange_alloc: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  hipError_t e = hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocUncached);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    e = hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocFinegrained);
+  }
+  PALU_REQUIRE(e == hipSuccess, PALU_ERR_LAUNCH, "exchange_alloc: hipExtMallocWithFlags(%zu, uncached / fine-grained) failed: %s", bytes,
+               hipGetErrorString(e));
   e = hipMemset(*ptr, 0, bytes);
   PALU_REQUIRE(e == hipSuccess, PALU_ERR_LAUNCH, "exchange_alloc: hipMemset failed: %s", hipGetErrorString(e));
   e = hipDeviceSynchronize();

@@ -39,8 +39,12 @@ struct PfParams {
                       // first), 2 eight heads at a time, one per XCD, heavy tiles first (default beyond 2048 workgroups)
   // kv PANELS (palu_prefill_attn_panel_f16): k / vt hold the kv positions [kv0, kv0 + Tk) only and `past` is RELATIVE to the
   // panel (past_abs - kv0, may be negative: the whole causal logic is in panel-local indices).  The online-softmax state of
-  // every (head, query) is carried from panel to panel in fp32: st_o [H][Tq][Rv] (un-normalised O), st_ml [H][Tq][8]
-  // (running maximum, then the partial sums of the lanes / waves that share a query).  first: start from the empty state;
+  // every (head, query) is carried from panel to panel in fp32: st_o [H][Tq][Rv] (un-normalised O), st_ml [Z][H][Tq][8]
+  // (running maximum, then the partial sums of the lanes / waves that share a query; one slice per column block blockIdx.z:
+  // the workgroups that split a query tile's latent columns over z all compute the same (m, l) and used to share ONE entry,
+  // read at the start and overwritten at the end of the same launch -- a z-block could read what a faster sibling had
+  // already advanced; with its own slice a block only ever reads what it wrote in the launch before).
+  // first: start from the empty state;
   // last: normalise and store fp16 `out` instead of the state.  st_o == nullptr: the one-launch kernel.
   float* st_o;
   float* st_ml;
@@ -52,7 +56,7 @@ template <int NB>
 static __device__ __forceinline__ void pf_state_load(const PfParams& p, int h, int qrow, bool qvalid, int c0, int hi, int ls,
                                                      f32x16 (&acc)[NB], float& m_run, float& l_run) {
   if (!qvalid) return;
-  const float* ml = p.st_ml + ((int64_t)h * p.Tq + qrow) * 8;
+  const float* ml = p.st_ml + (((int64_t)blockIdx.z * p.H + h) * p.Tq + qrow) * 8;
   m_run = ml[0];
   l_run = ml[1 + ls];
   const float* so = p.st_o + ((int64_t)h * p.Tq + qrow) * p.Rv + c0 + 4 * hi;
@@ -69,8 +73,8 @@ template <int NB>
 static __device__ __forceinline__ void pf_state_store(const PfParams& p, int h, int qrow, bool qvalid, int c0, int hi, int ls,
                                                       const f32x16 (&acc)[NB], float m_run, float l_run) {
   if (!qvalid) return;
-  float* ml = p.st_ml + ((int64_t)h * p.Tq + qrow) * 8;
-  ml[0] = m_run;                  // (every lane / wave / column chunk of the query writes the same value)
+  float* ml = p.st_ml + (((int64_t)blockIdx.z * p.H + h) * p.Tq + qrow) * 8;
+  ml[0] = m_run;                  // (every lane / wave of the query in this column block writes the same value)
   ml[1 + ls] = l_run;
   float* so = p.st_o + ((int64_t)h * p.Tq + qrow) * p.Rv + c0 + 4 * hi;
 #pragma unroll
@@ -655,7 +659,8 @@ extern "C" int palu_prefill_attn_panel_f16(const void* q, int64_t sq_h, int64_t 
 // bytes of (state_o, state_ml) for H heads x Tq queries
 extern "C" size_t palu_prefill_state_bytes(int H, int Tq, int Rv, int which) {
   if (H <= 0 || Tq <= 0 || Rv <= 0) return 0;
-  return which == 0 ? (size_t)H * Tq * Rv * sizeof(float) : (size_t)H * Tq * 8 * sizeof(float);
+  // (state_ml: one [H][Tq][8] slice per 32-column block -- the most column blocks a launch can split a query tile into)
+  return which == 0 ? (size_t)H * Tq * Rv * sizeof(float) : (size_t)H * Tq * 8 * sizeof(float) * ((Rv + 31) / 32);
 }
 
 static int prefill_impl(const void* q, int64_t sq_h, int64_t sq_t, const void* k, int64_t sk_h, int64_t sk_t, const void* vt,

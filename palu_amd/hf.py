@@ -96,7 +96,14 @@ class PaluAttentionHF(nn.Module):
         # a reference to (a key made of data_ptr / shape / version could be inherited by a different mask that
         # the caching allocator placed at the freed address).
         memo = getattr(past_key_values, "_mask_memo", None)
-        if orig is not None and memo is not None and memo[0] is orig:
+        if q_len == 1 and memo is not None:
+            # the prompt's masks ([1, 1, q, kv] bool + fp16: hundreds of MiB at 8k tokens) are not kept past the prompt pass
+            memo = None
+            try:
+                past_key_values._mask_memo = None
+            except AttributeError:
+                pass
+        if orig is not None and memo is not None and memo[0] is orig and memo[3] == orig._version:
             attention_mask, is_causal = memo[1], memo[2]
         else:
             if attention_mask is not None and attention_mask.dtype == torch.bool:
@@ -111,9 +118,12 @@ class PaluAttentionHF(nn.Module):
                 is_causal = (attention_mask.shape[0] == 1 and attention_mask.shape[-1] == past + q_len
                              and attention_mask.shape[-2] == q_len
                              and bool(self.inner._mask_is_causal(attention_mask, q_len, past)))
-            if orig is not None and past_key_values is not None:
+            last_layer = self.layer_idx == getattr(self.config, "num_hidden_layers", -1) - 1
+            if orig is not None and past_key_values is not None and q_len > 1:
                 try:
-                    past_key_values._mask_memo = (orig, attention_mask, is_causal)
+                    # (identity AND version: a mask tensor mutated in place and reused must be converted again; the last layer
+                    # of the pass drops the entry)
+                    past_key_values._mask_memo = None if last_layer else (orig, attention_mask, is_causal, orig._version)
                 except AttributeError:
                     pass
         if q_len == 1:
@@ -124,10 +134,27 @@ class PaluAttentionHF(nn.Module):
             # kernel/abx_rope.py:114-150: key position = row index), so the module derives it from the cache length: reading
             # it out of the device tensor transformers hands over would be a host sync per layer and token (and raises
             # inside a graph capture).
-            position_ids = None
+            # That is only right when the caller's position IS the cache length (the standard case).  Left-padded or offset
+            # positions must be passed through (the reference rotates the decode query with position_ids,
+            # kernel/palu_attention.py:218-219): a CPU tensor is compared on the host; for a device tensor the prompt pass
+            # recorded whether its positions started at the cache length (`_std_positions`), and only then it is dropped.
+            if position_ids is not None:
+                clen = cache.get_seq_length(self.layer_idx) if cache is not None else 0
+                if position_ids.device.type == "cpu":
+                    if int(position_ids.reshape(-1)[0]) == clen:
+                        position_ids = None
+                elif getattr(past_key_values, "_std_positions", True):
+                    position_ids = None
             is_causal = None
         elif attention_mask is None:
             is_causal = True               # the model is causal; without a mask tensor the module would apply none (:229)
+        if q_len > 1 and position_ids is not None and past_key_values is not None and self.layer_idx == 0:
+            # (one host read per PROMPT pass, first layer only: do this pass's positions start at the cache length?)
+            try:
+                past0 = cache.get_seq_length(0) if cache is not None else 0
+                past_key_values._std_positions = bool(int(position_ids.reshape(-1)[0]) == past0)
+            except AttributeError:
+                pass
         out, weights, _ = self.inner(hidden_states, attention_mask=attention_mask, position_ids=position_ids,
                                      past_key_value=cache, output_attentions=bool(kwargs.get("output_attentions", False)),
                                      is_causal=is_causal)

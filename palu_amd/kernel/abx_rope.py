@@ -35,7 +35,7 @@ def rope_inv_freq(device, head_dim: int = 128, theta: float = 10000.0) -> torch.
     return t
 
 
-ROPE_TABLE_POSITIONS = 1 << 18      # what the two-band score kernel covers (csrc/abx_rope2.hip); 2 MB per (device, theta)
+ROPE_TABLE_POSITIONS = (1 << 18) + 4096      # what the two-band score kernels cover (csrc/abx_rope2.hip): a 256k prompt + 4096 generated tokens; 2.6 MB per (device, theta)
 _rope_tables = {}
 
 

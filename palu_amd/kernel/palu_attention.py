@@ -786,21 +786,34 @@ class LlamaPaluAttention(nn.Module):
         u_ok = (self.n_rep == 1 and Rk % 64 == 0
                 and all(u.weight.dtype == dt and u.weight.is_contiguous() and u.bias is None for u in self.k_proj.U_list))
         out = None
-        for c0 in range(0, q_len, qc):
-            c1 = min(q_len, c0 + qc)
-            t = c1 - c0
-            hs = hidden_states[:, c0:c1]
-            q = self.q_proj(hs).view(t, H, D).transpose(0, 1)                             # [H,t,D] view of [t, H*D]
+
+        def project_latents(hs):
+            t_ = hs.shape[1]
             if not packed:
                 self._project_into_cache(hs, cache)                                       # latents straight into the rows
             elif not self._project_into_packed_cache(hs, cache):
                 # packed 3/4-bit cache: quantise + pack this chunk's rows; attention runs over the de-quantised values
                 # (the accuracy path's fake-quant semantics, svd_linear.py:84-90,124-139)
-                kh = self.k_proj.project_to_latent(hs).view(1, t, G, Rk).transpose(1, 2)
-                vh = self.v_proj.project_to_latent(hs).view(1, t, G, Rv).transpose(1, 2)
+                kh = self.k_proj.project_to_latent(hs).view(1, t_, G, Rk).transpose(1, 2)
+                vh = self.v_proj.project_to_latent(hs).view(1, t_, G, Rv).transpose(1, 2)
                 cache.append_rows(kh, vh, li)
                 del kh, vh
-            kv = past + c1
+
+        # Without a causal mask (the reference's no-mask prompt semantics, palu_attention.py:229-234 with attention_mask None)
+        # every query attends EVERY key of the pass, also those of later chunks: all latents go into the cache before the
+        # first chunk attends, and every chunk runs over kv_all.  (Causal chunks only need the keys up to their own end.)
+        all_first = (not causal) and q_len > qc
+        if all_first:
+            for c0 in range(0, q_len, qc):
+                project_latents(hidden_states[:, c0:min(q_len, c0 + qc)])
+        for c0 in range(0, q_len, qc):
+            c1 = min(q_len, c0 + qc)
+            t = c1 - c0
+            hs = hidden_states[:, c0:c1]
+            q = self.q_proj(hs).view(t, H, D).transpose(0, 1)                             # [H,t,D] view of [t, H*D]
+            if not all_first:
+                project_latents(hs)
+            kv = kv_all if all_first else past + c1
             if contiguous_pos and q.stride(2) == 1:
                 _lib.check(_lib.lib.palu_rope_f16(q.data_ptr(), q.stride(0), q.stride(1), H, t, D, p0 + c0, inv.data_ptr(),
                                                   stream), "palu_rope_f16")

@@ -76,7 +76,7 @@ def test_host_only_entry_points_work_without_gpu():
     assert sup(4096, 1024, 4096, 128, 4) == 1 and sup(4096, 3072, 4096, 384, 3) == 1 and sup(1000, 1536, 2048, 192, 4) == 1
     assert sup(256, 1024, 4096, 128, 4) == 0 and sup(4096, 1280, 4096, 160, 4) == 0 and sup(4096, 1024, 4096, 128, 8) == 0
     assert _lib.lib.palu_prefill_state_bytes(32, 512, 384, 0) == 32 * 512 * 384 * 4
-    assert _lib.lib.palu_prefill_state_bytes(32, 512, 384, 1) == 32 * 512 * 8 * 4
+    assert _lib.lib.palu_prefill_state_bytes(32, 512, 384, 1) == 32 * 512 * 8 * 4 * (384 // 32)     # one slice per 32-column block
     # quantised P.V on the matrix cores: 32-code chunks, or 24-code chunks for 4-bit rows they fill better (192 = 8 x 24)
     assert _lib.lib.palu_pv_direct_nsplit(8, 65536, 384, 3) == 32 and _lib.lib.palu_pv_direct_nsplit(8, 131072, 192, 4) == 32
     assert _lib.lib.palu_pv_direct_nsplit(8, 1000, 40, 4) == 0

@@ -219,3 +219,32 @@ def test_split_ranges_and_merge():
         ctx.append((e / e.sum(1, keepdim=True)) @ v[a:b]); m.append(mm); s.append(e.sum(1))
     out = hp.merge_partials(torch.stack(ctx), torch.stack(m), torch.stack(s))
     torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+
+
+def test_bench_dry_plan_world2_self_spawn():
+    """`python bench.py --gpus 2 --dry_plan` started WITHOUT torch.distributed.run spawns its two ranks itself (gloo, CPU):
+    sharding plan, weight shards of both o_proj forms, the step's collectives at their real message sizes, and ONE JSON
+    line from rank 0 with the contract's keys (the scaling run must be a one-command certainty)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry_plan"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1500:]
+    rec = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config"):
+        assert key in rec
+    assert rec["n_gpus"] == 2 and rec["dry_plan"] is True and rec["value"] is None
+    assert rec["plan"]["groups_local"] == 4 and rec["plan"]["heads_local"] == 16
+    assert rec["plan"]["shards"]["sharded"]["wo"][1] == 16 * 384 and rec["plan"]["shards"]["replicated"]["wo"][1] == 32 * 384
+    ck = rec["checks"]
+    assert ck["all_gather_ok"] and ck["all_reduce_ok"] and ck["sharded_oproj_sums_to_replicated"]
+    assert ck["all_gather_message_bytes"] == 16 * 384 * 2 and ck["all_reduce_message_bytes"] == 4096 * 4

@@ -86,10 +86,11 @@ def test_captured_two_rank_step_equals_eager_and_unsharded(oproj):
     torch.testing.assert_close(outs[0].float(), ref2.float(), rtol=1e-3, atol=1e-3)
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_p2p_exchange_between_processes(world):
     """The one-shot peer-to-peer exchange (csrc/exchange.hip, IpcExchange): N processes on this GPU map each other's buffers
-    through hipIpc handles; 200 checked all-gathers (3 KiB) and fp32 all-reduces (16 KiB), graph replay, no timed-out wait."""
+    through hipIpc handles (uncached device memory); 200 checked all-gathers (3 KiB) and fp32 all-reduces (16 KiB), graph replay,
+    no timed-out wait; world 8 = the rank count of BASELINE config 5."""
     env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exchange_two_procs.py"), "--world", str(world)], env=env,
                        cwd=ROOT, capture_output=True, text=True, timeout=600)

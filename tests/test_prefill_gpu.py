@@ -271,6 +271,38 @@ def test_three_layers_share_one_cache(quant_bits):
     assert [shared.get_seq_length(li) for li in range(3)] == [T + 2] * 3
 
 
+@pytest.mark.parametrize("mode", ["chunks", "panels"])
+def test_prefill_without_causal_mask_in_chunks_equals_one_launch(mode):
+    """with no mask and is_causal unset the prompt pass applies NO mask (the reference's semantics,
+    palu_attention.py:229-234): every query attends every key of the pass.  Forced query chunks / kv panels must project the
+    latents of ALL chunks before the first chunk attends -- same output as the one-launch form."""
+    from palu_amd.kernel.palu_attention import LatentCache
+    tag, seed, hidden, H, D, gs, rank_k, rank_v, T, _ = gi.PREFILL_CASES[2]       # T = 130: three chunks of 48 / two of 128
+    w, prompt, _ = gi.prefill_inputs(seed, hidden, H, D, gs, rank_k, rank_v, T, True)
+    m = _module_from_palu_weights(hidden, H, D, gs, rank_k, rank_v, w)
+    x = prompt.reshape(1, T, hidden).to(DEV)
+    c1, c2 = LatentCache(), LatentCache()
+    with torch.no_grad():
+        ref, _, _ = m(x, past_key_value=c1, is_causal=False)
+        causal_ref, _, _ = m(x, past_key_value=LatentCache(), is_causal=True)
+        if mode == "chunks":
+            m.PREFILL_WORKSPACE_BUDGET, m.PREFILL_QUERY_CHUNK = 0, 48
+        else:
+            m.PREFILL_PANEL_ROWS, m.PREFILL_PANEL_QUERY = 64, 128
+        try:
+            out, _, _ = m(x, past_key_value=c2, is_causal=False)
+        finally:
+            if mode == "chunks":
+                del m.PREFILL_WORKSPACE_BUDGET, m.PREFILL_QUERY_CHUNK
+            else:
+                del m.PREFILL_PANEL_ROWS, m.PREFILL_PANEL_QUERY
+    assert c2.get_seq_length(0) == T
+    torch.testing.assert_close(out.float(), ref.float(), rtol=2e-3, atol=2e-3)
+    assert (ref.float() - causal_ref.float()).abs().max() > 1e-2          # (the two mask semantics really differ on this prompt)
+    for a, b in zip(c1.buffers(0), c2.buffers(0)):
+        assert torch.equal(a[:, :, :T], b[:, :, :T])
+
+
 @pytest.mark.parametrize("bits", [16, 4])
 def test_prefill_in_query_chunks_and_groups_equals_one_launch(bits):
     """Long prompts run in query chunks x latent groups with bounded workspaces (LlamaPaluAttention._prefill_flash); forced
@@ -379,7 +411,10 @@ def prefill_attn_panels(q, k, v_lat, past, causal, C):
 @pytest.mark.parametrize("H,gs,Tq,Tk,Rv,causal,C", [
     (8, 4, 300, 300, 384, True, 64), (8, 4, 300, 300, 384, True, 128), (32, 4, 257, 1000, 384, True, 448),
     (8, 4, 130, 130, 96, True, 64), (8, 2, 200, 700, 448, True, 192), (4, 2, 70, 333, 64, False, 100 // 64 * 64 + 64),
-    (8, 4, 129, 129, 192, True, 1024), (4, 4, 1, 500, 384, True, 128), (8, 4, 640, 640, 256, True, 320)])
+    (8, 4, 129, 129, 192, True, 1024), (4, 4, 1, 500, 384, True, 128), (8, 4, 640, 640, 256, True, 320),
+    # grids of several workgroups per CU whose latent columns are split over blockIdx.z (Rv = 448: 7 column blocks, Rv = 160:
+    # 5): every column block carries its own (m, l) slice of the state (they used to share one entry)
+    (32, 4, 2100, 2100, 448, True, 512), (32, 4, 1500, 1500, 160, True, 384)])
 def test_prefill_panels_equal_one_launch(H, gs, Tq, Tk, Rv, causal, C):
     """kv panels with the carried online-softmax state (palu_prefill_attn_panel_f16) against the one-launch kernel and the
     fp32 restatement: panels that end inside a 64-row tile, panels wholly in a query tile's causal future (its state passes

@@ -58,12 +58,15 @@ def test_selection_rules():
     assert sel(16, 8, 1000, 128, 0) == 0               # 2 heads per group
     assert sel(32, 8, 1000, 96, 0) == 1 and sel(32, 8, 1000, 224, 0) == 1      # column windows (multiples of 32)
     assert sel(32, 8, 1000, 40, 0) == 0 and sel(32, 8, 1000, 136, 0) == 0      # other ranks: one-band kernels
-    assert sel(32, 8, 262145, 128, 0) == 0             # positions beyond the table / 2^18
-    assert sel(32, 8, 204800, 128, 0) == 0             # inv_freq[32] * L >= 2048 rad (0.01 * 204800)
-    assert sel(32, 8, 204000, 128, 0) == 1
+    assert sel(32, 8, 262145, 128, 0) == 1             # (round 5: a 256k prompt + generated tokens: 2^18 + 4096 positions)
+    assert sel(32, 8, 266241, 128, 0) == 0             # positions beyond the table
+    assert sel(32, 8, 204800, 128, 0) == 1             # (round 5: the low band's angle bound is 2700 rad, measured at 2621)
     with ar.one_band():
         assert sel(32, 8, 65537, 128, 0) == 0
     assert sel(32, 8, 65537, 128, 0) == 1
+    inv_8400 = ar.rope_inv_freq(dev, 128, 8400.0)                   # f_32 = 0.0109: psi_max = 0.698 passes, 262 145 positions = 2860 rad do not
+    sel2 = lambda L: _lib.lib.palu_abx_two_band_selected(inv_8400.data_ptr(), 32, 8, L, 128, 0)
+    assert sel2(200000) == 1 and sel2(262145) == 0
     inv_small_theta = ar.rope_inv_freq(dev, 128, 1000.0)            # psi_max = 64 * 1000^-0.5 = 2.0 rad: polynomial too short
     assert _lib.lib.palu_abx_two_band_selected(inv_small_theta.data_ptr(), 32, 8, 1000, 128, 0) == 0
     inv_llama3 = ar.rope_inv_freq(dev, 128, 500000.0)
@@ -128,6 +131,42 @@ def test_randn_scale_inputs_full_size_c2():
         worst = max(worst, float((two[:, l0:l1] - ref).abs().max()))
     assert worst <= 1e-3 * mx, (worst, mx)
     assert e2 <= 1.25 ** 2 * e1, (e2, e1)
+
+
+@pytest.mark.parametrize("form", ["pair_split", "position_split"])
+@pytest.mark.parametrize("R", [128, 64])
+def test_two_band_at_256k_positions(R, form):
+    """the reference's longest bench point (run_latency_kernel.py:11-12, 262 144 cached positions) + the new
+    token.  The low band evaluates the exact angle l f where the oracle rounds l f to fp32 first (<= 2^-13 rad at 2621 rad):
+    P2 on the LAST 8192 positions, where that difference and the high band's angle residual are largest -- error against
+    fp64 no worse than 1.5x the oracle's, rms no worse than 1.25x -- for both forms of the kernel."""
+    _lib, ar = _mods()
+    H, G, L, W = 4, 1, 262145, 8192
+    g = torch.Generator().manual_seed(R)
+    a = torch.randn(H, 1, D, generator=g).half()
+    b = (torch.randn(H, R, D, generator=g) * R ** -0.5).half()
+    x = torch.randn(G, L, R, generator=g).half()
+    ac, bc, xc = a.cuda(), b.cuda(), x.cuda()
+    inv = ar.rope_inv_freq(xc.device)
+    assert _lib.lib.palu_abx_two_band_selected(inv.data_ptr(), H, G, L, R, 0) == 1
+    ctx = ar.pair_split() if form == "pair_split" else ar.position_split(1)
+    with ctx:
+        got = ar.abx(ac, bc, xc)[:, :, L - W:].cpu().double().reshape(H, W)
+    l0 = L - W
+    xw = x[:, l0:]
+    cos, sin = oracle.rope_cos_sin(L, D, start=l0)
+    keys = torch.matmul(xw[:, None], b.reshape(G, H // G, R, D)).reshape(H, W, D)
+    ref16 = torch.matmul(a, oracle.rope_rotate(keys, cos, sin).to(torch.float16).transpose(-1, -2)).double().reshape(H, W)
+    keys64 = torch.matmul(xw.double()[:, None], b.double().reshape(G, H // G, R, D)).reshape(H, W, D)
+    ang = torch.outer(torch.arange(l0, L, dtype=torch.int64).to(torch.float32), oracle.rope_inv_freq(D)).double()
+    ang = torch.cat((ang, ang), dim=-1)
+    exact = torch.matmul(a.double(), oracle.rope_rotate(keys64, ang.cos(), ang.sin()).transpose(-1, -2)).reshape(H, W)
+    scale = exact.abs().max().item()
+    e_mine, e_or = (got - exact).abs().max().item() / scale, (ref16 - exact).abs().max().item() / scale
+    assert (got - ref16).abs().max().item() / scale <= 1e-3
+    assert e_mine <= max(1.5 * e_or, 2.0 ** -10), (e_mine, e_or)
+    rms_mine, rms_or = ((got - exact) ** 2).mean().sqrt().item(), ((ref16 - exact) ** 2).mean().sqrt().item()
+    assert rms_mine <= 1.25 * rms_or, (rms_mine, rms_or)
 
 
 @pytest.mark.parametrize("bits,R,L", [(4, 128, 1000), (4, 64, 4097), (4, 32, 777), (3, 128, 4193), (3, 64, 2100), (3, 32, 1300)])
