@@ -32,6 +32,10 @@ import argparse
 import json
 import math
 import os
+# hipGraph replay: ROCm 7.2's graph "packet capture" path (on by default) costs ~3.5 us per replay of this 5-kernel step
+# (157.3 us against 153.5 with it off, direct launches 152.7: profiles/r05_graph_replay.txt); it is read when the HIP runtime
+# loads, so it must be set before torch is imported.  An explicit setting in the environment wins.
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 import sys
 import time
 
@@ -551,6 +555,8 @@ def main():
                          "and reported beside it")
     ap.add_argument("--no_graph", action="store_true", help="launch the step directly instead of replaying a captured hipGraph")
     ap.add_argument("--no_extra_configs", action="store_true", help="skip the config 3/4/5 sub-records")
+    ap.add_argument("--no_abx_sweep", action="store_true",
+                    help="skip the score-kernel records at other shapes / on the other kernels (profiling runs: one shape per kernel name)")
     ap.add_argument("--no_model32", action="store_true", help="skip the whole-model (32-layer) decode sub-record")
     ap.add_argument("--cpu_sample_len", type=int, default=0, help="positions used for the CPU baseline (0 = full)")
     ap.add_argument("--dry_plan", action="store_true",
@@ -827,10 +833,12 @@ def main():
             from palu_amd.kernel.abx_rope import one_band, pair_split
             two_band = bool(lib.palu_abx_two_band_selected(inv.data_ptr(), H, G, L, Rk, 0))
             split = bool(lib.palu_abx_position_split_selected(inv.data_ptr(), H, G, L, Rk, 0))
-            with one_band():
-                _, kms1 = time_loop(k_abx, n, 10, torch.cuda.synchronize, reps=5)
-            with pair_split():
-                _, kms2 = time_loop(k_abx, n, 10, torch.cuda.synchronize, reps=5)
+            kms1 = kms2 = float("nan")
+            if not args.no_abx_sweep:
+                with one_band():
+                    _, kms1 = time_loop(k_abx, n, 10, torch.cuda.synchronize, reps=5)
+                with pair_split():
+                    _, kms2 = time_loop(k_abx, n, 10, torch.cuda.synchronize, reps=5)
             ex_f = executed_two_band_flops(Rk, L) if two_band else af
             us_abx = kern["abx"]["us"]
             pmc = {}
@@ -839,7 +847,8 @@ def main():
             rec["roofline_abx"] = {
                 "kernel": ("abx_rope3_kernel (two-band, position-split)" if split else
                            "abx_rope2_kernel (two-band, pair-split)" if two_band else "abx_rope_kernel (one-band)"),
-                "one_band_kernel_us": round(kms1 * 1e3 / n, 2), "pair_split_kernel_us": round(kms2 * 1e3 / n, 2),
+                "one_band_kernel_us": None if kms1 != kms1 else round(kms1 * 1e3 / n, 2),
+                "pair_split_kernel_us": None if kms2 != kms2 else round(kms2 * 1e3 / n, 2),
                 "bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_PEAK_TFLOPS,
                 # contract fields: ALGORITHMIC flops (2*H*L*R*D + 5*H*L*D) / time
                 "achieved": kern["abx"]["tflops"], "frac": round(kern["abx"]["tflops"] / MFMA_PEAK_TFLOPS, 4),
@@ -862,7 +871,7 @@ def main():
             # the reference's own bench points (run_latency_kernel.py:11-12: 4k / 16k / 64k / 256k cached positions), fp16,
             # with the kernel each length selects
             sweep = []
-            for Ls in (4096, 16384, 65536, 262144):
+            for Ls in (() if args.no_abx_sweep else (4096, 16384, 65536, 262144)):
                 try:
                     xs = torch.randn(G, Ls, Rk, device=dev, dtype=torch.float16)
                     so = torch.empty(H, Ls, dtype=torch.float16, device=dev)

@@ -21,6 +21,7 @@ __all__ = [
     "build_b_from_u", "fuse_uv_into_wo", "decode_step", "prefill", "quantize_rows",
     "pack_codes", "unpack_codes", "packed_row_bytes", "dequant_codes",
     "fwht", "had12", "hadK_for", "HAD_K_ORDER", "apply_hadamard", "fuse_hadamard_into_weights",
+    "whiten_decompose", "from_linear_whiten",
 ]
 
 
@@ -120,6 +121,36 @@ def fuse_uv_into_wo(wo: torch.Tensor, uv_weights, group_size: int, head_dim: int
             cols.append(wo[:, h * head_dim:(h + 1) * head_dim] @ u[j * head_dim:(j + 1) * head_dim, :])
             h += 1
     return torch.cat(cols, dim=1)
+
+
+def whiten_decompose(weight: torch.Tensor, scaling: torch.Tensor, rank: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Rank-`rank` factors (L [out, rank], R [rank, in]) of one group's weight with the activation-whitening matrix S.
+
+    Follows palu/model/modules/svd_linear.py:6-34: SVD of W S in fp32, V = Vt S^-1, truncate, sqrt(Sigma) on BOTH factors,
+    cast back to the weight's dtype."""
+    dt = weight.dtype
+    s32 = scaling.to(torch.float32)
+    inv = torch.linalg.inv(s32)
+    u, sig, vt = torch.linalg.svd(torch.matmul(weight.to(torch.float32), s32), full_matrices=False)
+    v = torch.matmul(vt, inv)
+    root = torch.sqrt(torch.diag(sig[:rank]))
+    return torch.matmul(u[:, :rank], root).to(dt), torch.matmul(root, v[:rank, :]).to(dt)
+
+
+def from_linear_whiten(weight: torch.Tensor, bias: Optional[torch.Tensor], scaling: torch.Tensor, ranks):
+    """Group-wise whitened decomposition of a dense projection: (u_list [out/G, r_g], vt [sum r_g, in], bias_list or None).
+
+    Follows palu/model/modules/svd_linear.py:170-204: the weight rows are split into len(ranks) groups, each decomposed by
+    whiten_decompose; the bias (if any) is split the same way and stays on the U side."""
+    G = len(ranks)
+    w = weight.reshape(G, -1, weight.shape[1])
+    us, rs = [], []
+    for g, r in enumerate(ranks):
+        left, right = whiten_decompose(w[g], scaling, r)
+        us.append(left.contiguous())
+        rs.append(right)
+    b = None if bias is None else [x for x in bias.reshape(G, -1)]
+    return us, torch.cat(rs, dim=0).contiguous(), b
 
 
 # ------------------------------------------------------------------- prefill (q_len > 1)

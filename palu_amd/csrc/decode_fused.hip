@@ -87,8 +87,10 @@ extern "C" int palu_decode_attn_preferred(int H, int G, int L, int Rk, int Rv, i
   if (!palu_decode_attn_supported(H, G, Rk, Rv, D) || L <= 0) return 0;
   const int m = fused_mode();
   // round 4 (the two-kernel path runs the two-band score kernel): one latent group per launch -- the per-GPU slice of an
-  // 8-way head-group sharding -- or very short caches (profiles/r04_fused_vs_two_kernel_policy_sweep.txt)
-  return m >= 0 ? m : (G == 1 ? L <= 300000 : (int64_t)G * L <= 24576);
+  // 8-way head-group sharding -- or very short caches (profiles/r04_fused_vs_two_kernel_policy_sweep.txt).  Round 5: the
+  // two-band kernel covers 2^18 + 4096 positions, and from ~200k positions of ONE group on the two kernels win again
+  // (262 145 positions: 85.3 us against 90.5 fused; 131k: 63.3 against 57.0 -- profiles/r05_c5_slice_policy.txt)
+  return m >= 0 ? m : (G == 1 ? L <= 196608 : (int64_t)G * L <= 24576);
 }
 
 extern "C" int palu_decode_attn_nsplit(int G, int L) {

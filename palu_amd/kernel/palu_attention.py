@@ -422,6 +422,40 @@ class HeadwiseLowRankModule(nn.Module):
         return new
 
 
+    @staticmethod
+    def from_linear_whiten(old_module: nn.Linear, ranks: list):
+        """Per-group truncated SVD of the WHITENED projection (palu/model/modules/svd_linear.py:6-34,170-204): with the
+        activation scaling matrix S the calibration pass left on the layer (`old_module.scaling_diag_matrix`,
+        palu/decomposition.py:21-80), W_g S = U Sigma Vt, L = U sqrt(Sigma)[:, :r], R = sqrt(Sigma) (Vt S^-1)[:r] -- sqrt(Sigma)
+        on both factors, unlike from_linear.  The bias (if any) stays on the U side, split by group."""
+        try:
+            scaling = old_module.scaling_diag_matrix
+        except AttributeError:
+            raise FileExistsError("Cache may not be loaded correctly") from None          # (the reference's error, :9-11)
+        new = HeadwiseLowRankModule(ranks, old_module.in_features, old_module.out_features,
+                                    bias=old_module.bias is not None)
+        G = len(ranks)
+        dt = old_module.weight.dtype
+        w = old_module.weight.data.reshape(G, -1, old_module.in_features)
+        s32 = scaling.to(device=w.device, dtype=torch.float32)
+        s_inv = torch.linalg.inv(s32)
+        rows = []
+        for g, r in enumerate(ranks):
+            u, sig, vh = torch.linalg.svd(torch.matmul(w[g].float(), s32), full_matrices=False)
+            root = torch.sqrt(sig[:r])
+            left = (u[:, :r] * root).to(dt).contiguous()
+            if new.U_list[g].weight.data.shape != left.shape:
+                raise ValueError(f"{new.U_list[g].weight.data.shape} != {left.shape}")
+            new.U_list[g].weight.data = left
+            rows.append((root[:, None] * torch.matmul(vh, s_inv)[:r, :]).to(dt))
+            if old_module.bias is not None:
+                new.U_list[g].bias.data = old_module.bias.data.reshape(G, -1)[g].clone()
+        vt = torch.cat(rows, dim=0).contiguous()
+        assert new.VT.weight.data.shape == vt.shape
+        new.VT.weight.data = vt
+        return new
+
+
 # --------------------------------------------------------------------------------- attention
 def _q_scratch_ok(mod, Rk: int) -> bool:
     """palu_decode_step_q parks the new (unquantised) latent rows in its workspace: G * Rk <= 4096 halves."""

@@ -23,6 +23,10 @@ import json
 import logging
 import math
 import os
+# hipGraph replay: ROCm 7.2's graph "packet capture" path (on by default) costs ~3.5 us per replay of this 5-kernel step
+# (157.3 us against 153.5 with it off, direct launches 152.7: profiles/r05_graph_replay.txt); it is read when the HIP runtime
+# loads, so it must be set before torch is imported.  An explicit setting in the environment wins.
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 import sys
 
 import torch

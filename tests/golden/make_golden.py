@@ -357,6 +357,42 @@ def gen_hadamard(rh, rs):
     _save("g6_hadamard", **out)
 
 
+# ------------------------------------------------------------------ G9 whitened decomposition
+def gen_whiten(rs):
+    print("G9 from_linear_whiten (palu/model/modules/svd_linear.py:6-34,170-204)")
+    rng = np.random.default_rng(31)
+    out = {}
+    for tag, fin, per_group, ranks, bias in (("a", 64, 48, [16, 24], True), ("b", 96, 32, [32, 8, 20], False)):
+        lin = nn.Linear(fin, per_group * len(ranks), bias=bias)
+        with torch.no_grad():
+            lin.weight.copy_(torch.from_numpy(rng.standard_normal((per_group * len(ranks), fin)).astype(np.float32) * 0.2))
+            if bias:
+                lin.bias.copy_(torch.from_numpy(rng.standard_normal(per_group * len(ranks)).astype(np.float32)))
+        # a calibration-style scaling matrix: lower-triangular (Cholesky-like), well conditioned
+        a = rng.standard_normal((fin, fin)).astype(np.float32) * 0.05
+        sc = torch.from_numpy(np.linalg.cholesky(a @ a.T + np.eye(fin, dtype=np.float32)).astype(np.float32))
+        lin.scaling_diag_matrix = sc
+        mod = rs.HeadwiseLowRankModule.from_linear_whiten(lin, ranks)
+        us = [u.weight.data.clone() for u in mod.U]
+        vt = mod.VT.weight.data.clone()
+        mine_u, mine_vt, mine_b = oracle.from_linear_whiten(lin.weight.data, lin.bias.data if bias else None, sc, ranks)
+        r0 = 0
+        for g, r in enumerate(ranks):
+            d = (us[g] @ vt[r0:r0 + r] - mine_u[g] @ mine_vt[r0:r0 + r]).abs().max()
+            print(f"  {tag} group {g}: |U VT - oracle| {d:.2e}")
+            out[f"{tag}/u{g}"] = _np(us[g])
+            if bias:
+                out[f"{tag}/bias{g}"] = _np(mod.U[g].bias.data)
+            r0 += r
+        out[f"{tag}/w"], out[f"{tag}/scaling"], out[f"{tag}/vt"] = _np(lin.weight.data), _np(sc), _np(vt)
+        out[f"{tag}/ranks"] = np.array(ranks)
+        if bias:
+            out[f"{tag}/b"] = _np(lin.bias.data)
+        x = torch.from_numpy(rng.standard_normal((1, 5, fin)).astype(np.float32))
+        out[f"{tag}/x"], out[f"{tag}/y"] = _np(x), _np(mod(x))          # forward of the decomposed module
+    _save("g9_whiten", **out)
+
+
 def main():
     ml, pa, ar, pr, rq, rh, rs = _import_reference()
     only = set(sys.argv[1:])
@@ -376,6 +412,8 @@ def main():
         gen_prefill(ml, pa)
     if not only or "reftest" in only:
         gen_reftest(ml, pa)
+    if not only or "whiten" in only:
+        gen_whiten(rs)
 
 
 if __name__ == "__main__":

@@ -130,7 +130,8 @@ def test_fused_attention_shape_policy():
     assert lib.palu_decode_attn_supported(32, 8, 128, 384, 64) == 0
     assert lib.palu_decode_attn_supported(32, 16, 128, 384, 128) == 0    # gs = 2
     if "PALU_FUSED_ATTN" not in os.environ:
-        assert lib.palu_decode_attn_preferred(4, 1, 262145, 128, 384, 128) == 1    # one group per GPU: measured win
+        assert lib.palu_decode_attn_preferred(4, 1, 262145, 128, 384, 128) == 0    # (r5) one group, 256k: the two kernels with the two-band score kernel win again
+        assert lib.palu_decode_attn_preferred(4, 1, 131073, 128, 384, 128) == 1    # one group per GPU up to ~192k positions: measured win
         assert lib.palu_decode_attn_preferred(4, 1, 65537, 128, 384, 128) == 1     # 8-GPU shard of config 2
         assert lib.palu_decode_attn_preferred(8, 2, 65537, 128, 384, 128) == 0     # 4-GPU shard of config 2: two kernels (r4)
         assert lib.palu_decode_attn_preferred(32, 8, 65537, 128, 384, 128) == 0    # config 2 on one GPU: two kernels

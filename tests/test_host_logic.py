@@ -200,3 +200,35 @@ def test_cache_save_load_roundtrip(tmp_path):
         from safetensors.torch import save_file
         save_file({"x": torch.zeros(1)}, str(tmp_path / "other.safetensors"))
         load_cache(str(tmp_path / "other.safetensors"))
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_from_linear_whiten_against_reference_fixture(golden_dir, tag):
+    """HeadwiseLowRankModule.from_linear_whiten (svd_linear.py:170-204) on the inputs the reference ran (g9_whiten.npz): the
+    decomposed module reproduces the reference module's forward, its factors up to SVD signs, the bias stays on the U side;
+    a layer without `scaling_diag_matrix` raises the reference's error."""
+    import numpy as np
+    g = np.load(os.path.join(golden_dir, "g9_whiten.npz"))
+    ranks = [int(r) for r in g[f"{tag}/ranks"]]
+    w = torch.from_numpy(g[f"{tag}/w"])
+    has_bias = f"{tag}/b" in g
+    lin = nn.Linear(w.shape[1], w.shape[0], bias=has_bias)
+    with torch.no_grad():
+        lin.weight.copy_(w)
+        if has_bias:
+            lin.bias.copy_(torch.from_numpy(g[f"{tag}/b"]))
+    with pytest.raises(FileExistsError):
+        HeadwiseLowRankModule.from_linear_whiten(lin, ranks)
+    lin.scaling_diag_matrix = torch.from_numpy(g[f"{tag}/scaling"])
+    mod = HeadwiseLowRankModule.from_linear_whiten(lin, ranks)
+    vt_ref = torch.from_numpy(g[f"{tag}/vt"])
+    r0 = 0
+    for i, r in enumerate(ranks):
+        u_ref = torch.from_numpy(g[f"{tag}/u{i}"])
+        got = mod.U_list[i].weight.data @ mod.VT.weight.data[r0:r0 + r]
+        torch.testing.assert_close(got, u_ref @ vt_ref[r0:r0 + r], rtol=0, atol=2e-5)
+        if has_bias:
+            assert torch.equal(mod.U_list[i].bias.data, torch.from_numpy(g[f"{tag}/bias{i}"]))
+        r0 += r
+    x = torch.from_numpy(g[f"{tag}/x"])
+    torch.testing.assert_close(mod(x), torch.from_numpy(g[f"{tag}/y"]), rtol=1e-5, atol=1e-5)

@@ -196,3 +196,26 @@ def test_oracle_hadamard_every_hadk_width(golden_dir):
             m = hk.numpy().astype(np.int64)
             assert np.array_equal(m @ m.T, K * np.eye(K, dtype=np.int64))
     assert seen == set(oracle.HAD_K_ORDER)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_from_linear_whiten_matches_reference(golden_dir, tag):
+    """palu/model/modules/svd_linear.py:6-34,170-204 (whitened group-wise SVD): the restatement against factors the reference
+    produced (g9_whiten.npz).  Factors of an SVD are defined up to the signs of the singular vectors: the products U_g VT_g
+    (what the module computes) are compared element-wise, the factors themselves up to a per-component sign."""
+    g = _load(golden_dir, "g9_whiten")
+    ranks = [int(r) for r in g[f"{tag}/ranks"]]
+    w, sc = torch.from_numpy(g[f"{tag}/w"]), torch.from_numpy(g[f"{tag}/scaling"])
+    bias = torch.from_numpy(g[f"{tag}/b"]) if f"{tag}/b" in g else None
+    us, vt, bs = oracle.from_linear_whiten(w, bias, sc, ranks)
+    vt_ref = torch.from_numpy(g[f"{tag}/vt"])
+    assert vt.shape == vt_ref.shape
+    r0 = 0
+    for i, r in enumerate(ranks):
+        u_ref = torch.from_numpy(g[f"{tag}/u{i}"])
+        np.testing.assert_allclose((us[i] @ vt[r0:r0 + r]).numpy(), (u_ref @ vt_ref[r0:r0 + r]).numpy(), rtol=0, atol=2e-5)
+        sign = torch.sign((us[i] * u_ref).sum(dim=0))
+        np.testing.assert_allclose((us[i] * sign).numpy(), u_ref.numpy(), rtol=0, atol=2e-4)
+        if bias is not None:
+            np.testing.assert_array_equal(bs[i].numpy(), g[f"{tag}/bias{i}"])
+        r0 += r

@@ -190,3 +190,22 @@ def test_hadamard_vs_reference(golden_dir):
     with pytest.raises(ValueError):
         hu.apply_hadamard(torch.zeros(2, 200, device="cuda"))      # 200 = 40 * 5: not K * 2^m (the reference asserts too)
 
+
+
+@pytest.mark.parametrize("n", [2, 8, 32, 64, 128, 512, 1024, 2048, 4096])
+def test_hadamard_transform_every_kernel_form(n):
+    """palu_hadamard_transform over its kernel forms: several rows per wave (n < 64), one row per wave with 1 .. 32 elements per
+    lane in registers (64 <= n <= 2048, cross-lane butterflies), one workgroup per row through LDS (above); ragged row counts;
+    fp32 against the fp64 butterfly of the oracle, fp16 against the fp32 result rounded once."""
+    from palu_amd.kernel import hadamard_utils as hu
+    rows = 37 if n >= 64 else 3 * (64 // n) + 1
+    g = torch.Generator().manual_seed(n)
+    x = torch.randn(rows, n, generator=g)
+    ref = oracle.fwht(x.double())
+    y = hu.hadamard_transform(x.cuda(), 0.5).cpu()
+    np.testing.assert_allclose(y.double().numpy(), 0.5 * ref.numpy(), rtol=0, atol=2e-6 * n ** 0.5 * 4)
+    xh = x.half()
+    yh = hu.hadamard_transform(xh.cuda(), 1.0).cpu()
+    exp = hu.hadamard_transform(xh.float().cuda(), 1.0).cpu().half()        # same fp32 arithmetic, one rounding
+    finite = torch.isfinite(exp)
+    assert torch.equal(yh[finite], exp[finite])

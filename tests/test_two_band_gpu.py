@@ -250,7 +250,7 @@ def test_pos_offset_in_whole_tiles_and_other_theta():
 
 
 @pytest.mark.parametrize("two_band", [1, 0])
-@pytest.mark.parametrize("kind", ["perhead", "q3", "q4", "fused_c5", "fused_c2"])
+@pytest.mark.parametrize("kind", ["perhead", "pairsplit", "split64", "q3", "q4", "fused_c5", "fused_c2"])
 def test_cold_start_first_launch_is_deterministic(kind, two_band):
     """the first launch of every score kernel of the family in a FRESH process equals its second and
     third (the shared-B kernel's cold-start flake is guarded in test_abx_gpu.py); 8 processes per kernel kind, with the
@@ -260,8 +260,13 @@ def test_cold_start_first_launch_is_deterministic(kind, two_band):
     import sys
     if kind.startswith("fused") and not two_band:
         pytest.skip("the fused core has one score pipeline")
+    if kind in ("pairsplit", "split64") and not two_band:
+        pytest.skip("forms of the two-band kernel")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PYTHONPATH=root, PALU_ABX_TWO_BAND=str(two_band))
+    env.pop("PALU_ABX_SPLIT", None)
+    if kind == "pairsplit":                      # (round 5: "perhead" is the position-split form at this shape)
+        env["PALU_ABX_SPLIT"] = "0"
     env.pop("PALU_ABX_PRIO_MODE", None)
     procs = [subprocess.Popen([sys.executable, os.path.join(root, "tools", "diag_cold_start.py"), kind], env=env, cwd=root,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for _ in range(4)]

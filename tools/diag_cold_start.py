@@ -1,5 +1,5 @@
 """First launch vs second / third launch of one kernel in a FRESH process (profiles/r03_shared_b_cold_start.txt):
-    python tools/diag_cold_start.py perhead | shared | q3 | q4 | fused_c5 | fused_c2 | pvq3 | pvq4
+    python tools/diag_cold_start.py perhead | pairsplit | split64 | shared | q3 | q4 | fused_c5 | fused_c2 | pvq3 | pvq4
 Run it many times (one process each): a kernel with a start-up race differs in its first launch only."""
 import sys, math, numpy as np, torch
 from palu_amd import _lib
@@ -11,8 +11,10 @@ D = 128
 def t16(*shape, scale=1.0):
     return torch.from_numpy((rng.standard_normal(shape) * scale).astype(np.float16)).cuda()
 S = lambda: torch.cuda.current_stream().cuda_stream
-if kind in ("perhead", "shared"):
-    H, gs, R, L = 32, 4, 128, 65537
+if kind in ("perhead", "shared", "pairsplit", "split64"):
+    # perhead: the default fp16 score kernel at C2 (round 5: the position-split form of the two-band kernel); pairsplit: the
+    # same launch on the pair-split form (the caller sets PALU_ABX_SPLIT=0); split64: position-split at R = 64, 8 tiles per wave
+    H, gs, R, L = (32, 4, 64, 131073) if kind == "split64" else (32, 4, 128, 65537)
     G = H // gs
     a = t16(H, 1, D)
     if kind == "shared":
