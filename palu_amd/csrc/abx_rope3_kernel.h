@@ -151,6 +151,19 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
     for (int k = 0; k < NKS; ++k) dma_piece(0, 0, k);
   }
 
+  // ---- small loads FIRST (loads return in issue order: the query gates the first barrier, behind 32 KB of fragments it
+  //      would arrive last): the query, frequencies, the first tile's coefficients
+  h16 qv[2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e) {
+    const int idx = tid + ABX3_THREADS * e;
+    qv[e] = p.a[(int64_t)(g * 4 + (idx >> 7)) * p.sa_h + (int64_t)(idx & 127) * p.sa_d];
+  }
+  // lane (n, hi) holds the 16 high-band pairs i = 4 mb + 2 j + hi, q = 2 mb + j, of one position per block
+  float fr[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) fr[q] = p.inv_freq[4 * (q >> 1) + 2 * (q & 1) + hi];
+  const float psimax = 64.0f * p.inv_freq[ABX2_I0];
   // stage 1 uses 8 of the 16 MFMA columns: lanes k + 8 load the coefficients of lane k, compute the same W values and store
   // them to the same LDS words (no exec masking, no zero fill)
   const u32x4* tab0 = p.rope_tab + (int64_t)(p.tab_tile0 + tile0) * 64;      // (uniform) this wave's first tile: 2 x 32 u32x4 per tile
@@ -172,18 +185,6 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
 #pragma unroll
   for (int t = 0; t < FPW; ++t) hraw[t] = bh_base[(int64_t)t * 64];
 
-  // ---- small loads: the query, frequencies, the first tile's coefficients, the RoPE start tables
-  h16 qv[2];
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int idx = tid + ABX3_THREADS * e;
-    qv[e] = p.a[(int64_t)(g * 4 + (idx >> 7)) * p.sa_h + (int64_t)(idx & 127) * p.sa_d];
-  }
-  // lane (n, hi) holds the 16 high-band pairs i = 4 mb + 2 j + hi, q = 2 mb + j, of one position per block
-  float fr[16];
-#pragma unroll
-  for (int q = 0; q < 16; ++q) fr[q] = p.inv_freq[4 * (q >> 1) + 2 * (q & 1) + hi];
-  const float psimax = 64.0f * p.inv_freq[ABX2_I0];
   stamp();  // 1
 
   // the query to LDS as (q_i, q_{i+64}) pairs
