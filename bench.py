@@ -945,7 +945,7 @@ def main():
                     import bench_model
                     m32 = bench_model.run(32, rank_k, rank_v, 4, Lp, 16, reps=15, dev=str(dev))
                     m32["attention_share"] = ("32 x the single-layer decode step above = %.2f ms of the %.2f ms per token "
-                                              "(the rest: RMSNorm / MLP / lm_head through torch)"
+                                              "(the rest: RMSNorm / gated MLP / lm_head one-token kernels, residual adds and the embedding through torch)"
                                               % (32 * us_step * 1e-3, m32.get("graph_ms_per_token", m32["eager_ms_per_token"])))
                     sub["model32"] = m32
                 except Exception as e:                      # noqa: BLE001

@@ -96,15 +96,18 @@ class PaluAttentionHF(nn.Module):
         # a reference to (a key made of data_ptr / shape / version could be inherited by a different mask that
         # the caching allocator placed at the freed address).
         memo = getattr(past_key_values, "_mask_memo", None)
-        if q_len == 1 and memo is not None:
-            # the prompt's masks ([1, 1, q, kv] bool + fp16: hundreds of MiB at 8k tokens) are not kept past the prompt pass
+        if memo is not None and (orig is None or memo[0] is not orig or memo[3] != orig._version):
+            # an entry of another pass (the prompt's masks: [1, 1, q, kv] bool + fp16, hundreds of MiB at 8k tokens) is not kept
             memo = None
             try:
                 past_key_values._mask_memo = None
             except AttributeError:
                 pass
-        if orig is not None and memo is not None and memo[0] is orig and memo[3] == orig._version:
+        last_layer = self.layer_idx == getattr(self.config, "num_hidden_layers", -1) - 1
+        if orig is not None and memo is not None:
             attention_mask, is_causal = memo[1], memo[2]
+            if last_layer:
+                past_key_values._mask_memo = None
         else:
             if attention_mask is not None and attention_mask.dtype == torch.bool:
                 # transformers 5.x (sdpa / create_causal_mask) hands over BOOLEAN masks, True = attend: the module speaks the
@@ -118,11 +121,11 @@ class PaluAttentionHF(nn.Module):
                 is_causal = (attention_mask.shape[0] == 1 and attention_mask.shape[-1] == past + q_len
                              and attention_mask.shape[-2] == q_len
                              and bool(self.inner._mask_is_causal(attention_mask, q_len, past)))
-            last_layer = self.layer_idx == getattr(self.config, "num_hidden_layers", -1) - 1
-            if orig is not None and past_key_values is not None and q_len > 1:
+            if orig is not None and past_key_values is not None:
                 try:
                     # (identity AND version: a mask tensor mutated in place and reused must be converted again; the last layer
-                    # of the pass drops the entry)
+                    # of the pass drops the entry.  Decode steps memoise too: converting a [1, 1, 1, kv] mask is three small
+                    # launches per LAYER otherwise -- 7 us of a 220 us layer, measured in tools/bench_model.py)
                     past_key_values._mask_memo = None if last_layer else (orig, attention_mask, is_causal, orig._version)
                 except AttributeError:
                     pass

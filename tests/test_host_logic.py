@@ -232,3 +232,59 @@ def test_from_linear_whiten_against_reference_fixture(golden_dir, tag):
         r0 += r
     x = torch.from_numpy(g[f"{tag}/x"])
     torch.testing.assert_close(mod(x), torch.from_numpy(g[f"{tag}/y"]), rtol=1e-5, atol=1e-5)
+
+
+def test_hf_adapter_converts_a_mask_once_per_forward_pass(monkeypatch):
+    """palu_amd.hf.PaluAttentionHF: the boolean mask transformers hands to every layer is converted (and, for prompts, tested
+    for causality) once per forward PASS -- decode steps included: three small launches per layer otherwise -- keyed on the
+    mask's identity and version; the last layer drops the entry, an entry of another pass is never used."""
+    import types
+    from palu_amd import hf
+
+    calls = []
+    real = hf.additive_mask
+    monkeypatch.setattr(hf, "additive_mask", lambda m, dt: (calls.append(m), real(m, dt))[1])
+
+    class Inner(nn.Module):
+        def __init__(self, idx):
+            super().__init__()
+            self.layer_idx, self.config, self.seen = idx, types.SimpleNamespace(num_hidden_layers=3), []
+
+        def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_value=None, output_attentions=False,
+                    is_causal=None):
+            self.seen.append(attention_mask)
+            return hidden_states, None, None
+
+    class Cache:
+        _mask_memo = None
+
+        def get_seq_length(self, layer_idx=0):
+            return 7
+
+    layers = [hf.PaluAttentionHF(Inner(i)) for i in range(3)]
+    cache = Cache()
+    x = torch.zeros(1, 1, 8, dtype=torch.float16)
+
+    def one_pass(mask):
+        for l in layers:
+            l(x, attention_mask=mask, past_key_values=cache)
+
+    m1 = torch.ones(1, 1, 1, 8, dtype=torch.bool)
+    one_pass(m1)
+    assert len(calls) == 1 and cache._mask_memo is None                        # once for three layers; dropped by the last
+    assert all(l.inner.seen[-1] is layers[0].inner.seen[-1] for l in layers)   # the same converted tensor
+    assert layers[0].inner.seen[-1].dtype == torch.float16
+    m2 = torch.ones(1, 1, 1, 8, dtype=torch.bool)
+    one_pass(m2)
+    assert len(calls) == 2
+    # a pass that stopped early leaves an entry: a different mask, or the same one mutated in place, must not inherit it
+    layers[0](x, attention_mask=m2, past_key_values=cache)
+    assert len(calls) == 3 and cache._mask_memo is not None
+    m3 = torch.zeros(1, 1, 1, 8, dtype=torch.bool)
+    layers[1](x, attention_mask=m3, past_key_values=cache)
+    assert len(calls) == 4 and float(layers[1].inner.seen[-1].max()) < 0
+    m3[..., 0] = True
+    layers[2](x, attention_mask=m3, past_key_values=cache)
+    assert len(calls) == 5 and float(layers[2].inner.seen[-1][..., 0]) == 0 and cache._mask_memo is None
+    layers[0](x, attention_mask=None, past_key_values=cache)                   # no mask: nothing converted, nothing kept
+    assert len(calls) == 5 and layers[0].inner.seen[-1] is None and cache._mask_memo is None

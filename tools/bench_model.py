@@ -6,7 +6,8 @@ A transformers-5 `LlamaForCausalLM` of Llama-2-7B geometry (32 layers, hidden 40
 random weights -- there is no network for checkpoints) whose attention modules are `LlamaPaluAttention` behind
 `palu_amd.hf.PaluAttentionHF` (random low-rank factors of the named ranks: a throughput measurement needs no SVD), one
 `PaluCacheHF` with `prompt_len` cached positions per layer (synthetic latents, fp16 or packed).  One decode step =
-`model(token, past_key_values=cache)`: 32 HIP decode steps + the model's own RMSNorm / MLP / lm_head through torch.
+`model(token, past_key_values=cache)`: 32 HIP decode steps + the model's RMSNorm / MLP / lm_head (HIP one-token kernels,
+`palu_amd.hf.use_hip_decode_linears`, or torch with --torch_mlp).
 
 Reports ms per token and tokens/s for eager launches and for the replay of ONE captured hipGraph of the whole forward, the
 host microseconds per layer that the graph removes, and 32 x the single-layer attention step beside it.
