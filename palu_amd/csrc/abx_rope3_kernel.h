@@ -408,10 +408,12 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
   float cc[2] = {0.f, 0.f}, ss[2] = {0.f, 0.f};
   auto epi_chunk = [&](auto mbp_c, auto c_c, const f32x16& ac) {
     constexpr int mbp = decltype(mbp_c)::value, c = decltype(c_c)::value;
-    if (c < 4) {
+    if constexpr (mbp < 0 || mbp > 7) {
+      // (instantiated from slots whose run-time guard never lets them through)
+    } else if constexpr (c < 4) {
       constexpr int j = c >> 1;
       constexpr int q = 2 * mbp + j, qn = (q + 1) & 15;
-      if ((c & 1) == 0) {
+      if constexpr ((c & 1) == 0) {
         if (q == 15) lfe += 32.0f;                 // pair 0 comes next: it belongs to the following block
         cc[j] = fmaf(lo_cur, sn[q], cs[q]);
         ss[j] = fmaf(-lo_cur, cs[q], sn[q]);
