@@ -146,11 +146,6 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
         : "s"(dst), "v"(dvoff[k % NV]), "s"(xrs), "s"(soff)
         : "memory");
   };
-  if (nblk > 0) {
-#pragma unroll
-    for (int k = 0; k < NKS; ++k) dma_piece(0, 0, k);
-  }
-
   // ---- small loads FIRST (loads return in issue order: the query gates the first barrier, behind 32 KB of fragments it
   //      would arrive last): the query, frequencies, the first tile's coefficients
   h16 qv[2];
@@ -179,11 +174,12 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
   //      (memory order [mb][j]), low f = rb 8 + h 2 + cs
   const u32x4* bh_base = p.bfrag2 + ((int64_t)g * 8 * NKS + w * FPW) * 64 + lane;
   const u32x4* bl_base = p.bfrag2 + (int64_t)p.G * 8 * NKS * 64 + ((int64_t)g * NKS * 8 + w * FPW) * 64 + lane;
+  // (a CU takes ~25 B per clock of these: a wave sits ~200 cycles on every load it issues once the queue is full.  The low
+  //  fragments are requested here; the high ones one per low-fold step below, so that the fold runs while the requests drain
+  //  instead of behind all 32 of them)
   u32x4 hraw[FPW], lraw[FPW];
 #pragma unroll
   for (int t = 0; t < FPW; ++t) lraw[t] = bl_base[(int64_t)t * 64];
-#pragma unroll
-  for (int t = 0; t < FPW; ++t) hraw[t] = bh_base[(int64_t)t * 64];
 
   stamp();  // 1
 
@@ -201,21 +197,39 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
   asm volatile("" : "+v"(cf0[0]), "+v"(cf0[1]));   // (hipcc's wait for these loads goes here, where nothing else is in flight)
 
   // ---- (q_i, q_{i+64}) of this lane's rows in the two high M-blocks it folds
-  unsigned qp[2];
+  unsigned qp0, qp1;                               // (two scalars, not an array: the fold below picks one by a run-time bit)
   {
     const int m = lane & 31;
     const int hh = 2 * ((m >> 3) & 1) + (m & 1);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const int i = 4 * (2 * w + s) + 2 * (m >> 4) + ((m >> 2) & 1);
-      qp[s] = *(const lds_u32*)(uintptr_t)(lds0 + (unsigned)(M::OFF_Q + (hh * 64 + i) * 4));
-    }
+    const int i0 = 4 * (2 * w) + 2 * (m >> 4) + ((m >> 2) & 1);
+    qp0 = *(const lds_u32*)(uintptr_t)(lds0 + (unsigned)(M::OFF_Q + (hh * 64 + i0) * 4));
+    qp1 = *(const lds_u32*)(uintptr_t)(lds0 + (unsigned)(M::OFF_Q + (hh * 64 + i0 + 4) * 4));
   }
+  // exact-angle (cos, sin) of: the wave's first tile start (T1), this lane's offset n, the one-block-early start of M-block 7
+  // (its epilogue runs during the NEXT block) and the 32-position step (T2, abx2_rope_start_kernel): 25 loads of 16 bytes per
+  // lane, requested a few per low-fold step behind the high fragments (their issue costs the CU's address unit 16 cycles each:
+  // 1.6 k cycles per CU that would otherwise sit between the two folds)
+  const f32x4* t1p = reinterpret_cast<const f32x4*>(p.rope_t1 + ((int64_t)(p.tab_tile0 + (ntile > 0 ? tile0 : 0)) * 2 + hi) * 32);
+  const f32x4* t2n = reinterpret_cast<const f32x4*>(p.rope_t2 + (n * 2 + hi) * 32);
+  const f32x4* t2m = reinterpret_cast<const f32x4*>(p.rope_t2 + ((32 - n) * 2 + hi) * 32);
+  const f32x4* t2s = reinterpret_cast<const f32x4*>(p.rope_t2 + (32 * 2 + hi) * 32);
+  f32x4 vt1[8], vt2[8], vts[8], vtm;
+  auto tload = [&](auto i_c) {
+    constexpr int i = decltype(i_c)::value;
+    if constexpr (i < 8) vt1[i] = t1p[i];
+    else if constexpr (i < 16) vt2[i - 8] = t2n[i - 8];
+    else if constexpr (i < 24) vts[i - 16] = t2s[i - 16];
+    else if constexpr (i == 24) vtm = t2m[7];      // pairs q = 14, 15
+  };
+  constexpr int TPS = (25 + FPW - 1) / FPW;        // table loads per fold step
   // ---- low fold: a register holds (B[r,i], B[r,i+64]) -> (P[r,i], Q[r,i]) (v_dot2_f32_f16: exact products, one rounding)
   {
     const int qd = lane >> 4;
-#pragma unroll
-    for (int t = 0; t < FPW; ++t) {
+    abx3_for<0, FPW>([&](auto t_c) {
+      constexpr int t = decltype(t_c)::value;
+      hraw[t] = bh_base[(int64_t)t * 64];
+      abx3_for<0, TPS>([&](auto j_c) { tload(std::integral_constant<int, t * TPS + decltype(j_c)::value>{}); });
+      __builtin_amdgcn_sched_barrier(0);
       const int f = w * FPW + t;
       const int h4 = (f >> 1) & 3, cs2 = t & 1;
       const u32x4 qq = *(const lds_u32x4*)(uintptr_t)(lds0 + (unsigned)(M::OFF_Q + (h4 * 64 + ABX2_I0 + 16 * cs2 + 4 * qd) * 4));
@@ -237,22 +251,15 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
         res[e4] = __builtin_bit_cast(unsigned, r2);
       }
       *(lds_u32x4*)(uintptr_t)(lds0 + (unsigned)(M::OFF_LOWF + (f * 64 + lane) * 16)) = res;
-    }
+    });
   }
-  // exact-angle (cos, sin) of: the wave's first tile start (T1), this lane's offset n, the one-block-early start of M-block 7
-  // (its epilogue runs during the NEXT block) and the 32-position step (T2, abx2_rope_start_kernel)
-  const f32x4* t1p = reinterpret_cast<const f32x4*>(p.rope_t1 + ((int64_t)(p.tab_tile0 + (ntile > 0 ? tile0 : 0)) * 2 + hi) * 32);
-  const f32x4* t2n = reinterpret_cast<const f32x4*>(p.rope_t2 + (n * 2 + hi) * 32);
-  const f32x4* t2m = reinterpret_cast<const f32x4*>(p.rope_t2 + ((32 - n) * 2 + hi) * 32);
-  const f32x4* t2s = reinterpret_cast<const f32x4*>(p.rope_t2 + (32 * 2 + hi) * 32);
-  f32x4 vt1[8], vt2[8], vts[8];
+  // the first block's latents LAST: a wave's loads return in issue order, and these come from HBM while 256 workgroups ask
+  // for theirs at once -- in front of the fragment loads they held every fold back by their latency; nothing reads the
+  // block before the main loop (>= 8 k cycles from here)
+  if (nblk > 0) {
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    vt1[k] = t1p[k];
-    vt2[k] = t2n[k];
-    vts[k] = t2s[k];
+    for (int k = 0; k < NKS; ++k) dma_piece(0, 0, k);
   }
-  const f32x4 vtm = t2m[7];                        // pairs q = 14, 15
   stamp();  // 3
   __syncthreads();                                 // #2: nobody reads the query any more (the high fragments overwrite it)
 
@@ -265,7 +272,7 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
       const int s = t / NKS, j = t % NKS;
       const int mb = 2 * w + s;
       const int ks = (j + (mb >= 4 ? NKS / 2 : 0)) % NKS;              // (abx2_prepare_b_kernel: waves 4-7 store half a turn ahead)
-      const h16x2 q2 = __builtin_bit_cast(h16x2, qp[s]);
+      const h16x2 q2 = __builtin_bit_cast(h16x2, s ? qp1 : qp0);
       h16x2 coef;
       coef[0] = u ? -q2[0] : q2[0];
       coef[1] = q2[1];
