@@ -36,9 +36,10 @@ int position_split_enabled() {
 }
 
 // The position-split kernel pays a longer prologue (every wave takes all high-band fragments) for a main loop that needs
-// 2/3 of the cycles: it wins once a wave (4 per CU) has about three 128-position tiles (profiles/r05_abx_split_vs_pair.txt).
+// 3/4 of the cycles: it wins once a wave (4 per CU) has two 128-position tiles (32k positions x 8 groups: 27.7 against 29.0 us;
+// one tile per wave: 18.7 against 18.3; profiles/r05_abx_split_vs_pair.txt).
 // g_split_min_tiles: tiles per wave from which it is selected (palu_abx_set_position_split(n > 1) sets it; 1 = always)
-int g_split_min_tiles = 3;
+int g_split_min_tiles = 2;
 bool position_split_preferred(const AbxParams& p) {
   const int on = position_split_enabled();
   if (!on) return false;

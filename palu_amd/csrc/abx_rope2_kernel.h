@@ -229,7 +229,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
     if (p.ncols) c = min(c, p.qcol0 + p.ncols - 1);
     xmg += 2 * (c / p.qgroup);
   }
-  auto load_q = [&](int tt) {
+  auto load_q_into = [&](int tt, unsigned (&qraw)[NW], unsigned& qmeta) {
     if (!qactive) return;
     const int row = tid / LPR, quarter = tid % LPR;
     const int l = min((tile0 + tt) * TL + row, p.L - 1);
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
     for (int k = 0; k < NW; ++k) qraw[k] = __builtin_nontemporal_load(src + k);
     qmeta = *reinterpret_cast<const unsigned*>(xmg + (int64_t)l * p.sm_l);
   };
-  auto store_q = [&](int slot) {
+  auto store_q_from = [&](int slot, const unsigned (&qraw)[NW], const unsigned& qmeta) {
     if (!qactive) return;
     const int row = tid / LPR, quarter = tid % LPR;
     const h16x2 m2 = __builtin_bit_cast(h16x2, qmeta);
@@ -272,6 +272,8 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
       *reinterpret_cast<u32x4*>(dst + Geo::swz(row, c) * 16) = o;
     }
   };
+  auto load_q = [&](int tt) { load_q_into(tt, qraw, qmeta); };
+  auto store_q = [&](int slot) { store_q_from(slot, qraw, qmeta); };
 
   // ---- prologue: small loads first (they feed ~300 VALU operations that depend on nothing else), then the bulk
   float fr[2];
@@ -287,15 +289,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
     *(__attribute__((address_space(3))) h16*)(uintptr_t)(qbuf + (unsigned)(((hh * 64 + (d & 63)) * 2 + (d >> 6)) * 2)) = v;
   }
 
+  // packed rows: the first TWO tiles are requested at once (a second register set for the prologue) and stored behind the
+  // fragment loads and the RoPE start below -- one HBM round trip in front of the fragment requests instead of two in a row
+  unsigned qrawB[NW];
+  unsigned qmetaB = 0;
   if (QBITS == 0) {
     dma_tile(0, 0);
     dma_tile(min(1, ntile - 1), 1);
   } else {
     load_q(0);
-    store_q(0);
-    load_q(min(1, ntile - 1));
-    store_q(1);
-    load_q(min(2, ntile - 1));
+    load_q_into(min(1, ntile - 1), qrawB, qmetaB);
   }
 
   // weight fragments
@@ -352,6 +355,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
     pw[3] = pw[2] * t * (hi ? (1.0f / 7.0f) : (1.0f / 3.0f));
   }
 
+  if (QBITS != 0) {
+    store_q(0);
+    store_q_from(1, qrawB, qmetaB);
+    load_q(min(2, ntile - 1));
+  }
   __syncthreads();                                // query and zeroed partial sums visible
 
   // ---- fold the query into the fragments (v_dot2_f32_f16: both products exact in fp32, one rounding to fp16)

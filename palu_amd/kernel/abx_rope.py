@@ -81,7 +81,7 @@ def pair_split():
 
 @contextlib.contextmanager
 def position_split(min_tiles: int = 1):
-    """Run the enclosed launches on the position-split kernel wherever the shape allows (default: from 3 tiles per wave on)."""
+    """Run the enclosed launches on the position-split kernel wherever the shape allows (default: from 2 tiles per wave on)."""
     old = _lib.lib.palu_abx_set_position_split(int(min_tiles))
     try:
         yield
