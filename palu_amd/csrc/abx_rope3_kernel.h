@@ -47,17 +47,31 @@ struct Abx3Lds {
   static constexpr int OFF_X1 = OFF_X0 + 4 * BLK;  // ring slot 1
   static constexpr int OFF_W = OFF_X1 + 4 * BLK;   // W images of the 4 waves
   static constexpr int OFF_HIF = OFF_X1;           // prologue: aliases [slot 1 | W images] = 8 NKS KB exactly
-  static constexpr int OFF_Q = OFF_X1;             // prologue, before the high fold: the query as (q_i, q_{i+64}) pairs, 1 KB
+  static constexpr int OFF_Q = OFF_X0;             // prologue, until the folds are done: the query as (q_i, q_{i+64}) pairs, 1 KB (ring slot 0 is
+                                                   // filled behind them)
   static constexpr int TOTAL = OFF_W + 4 * WIMG;
   static_assert(4 * BLK + 4 * WIMG == HIF, "the folded high fragments alias ring slot 1 + the W images");
 };
 constexpr int abx3_smem(int nks) { return 8 * nks * 1024 + 8 * 32 * 32 * nks + 4 * nks * 1024; }
 
-// a.x * b.x + a.y * b.y in fp32 (exact products, one rounding).  (The builtin: hipcc selects v_dot2c_f32_f16 + a v_mov for its
-// accumulator.  An inline-asm v_dot2_f32_f16 with an inline 0 saves the v_mov and returns garbage: on gfx950 a DOT result needs
-// 3 wait states before another VALU reads it, which hipcc only inserts for instructions it can see -- measured, round 5.)
-static __device__ __forceinline__ float abx3_dot2(unsigned a, unsigned b) {
-  return __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, a), __builtin_bit_cast(h16x2, b), 0.f, false);
+// Eight dot products r[e] = a[e].x * b[e].x + a[e].y * b[e].y in fp32 (exact products, one rounding) as ONE asm block.
+// hipcc turns the builtin with a zero accumulator into v_mov + v_dot2c_f32_f16 + hazard padding (2.7 instructions per dot in the
+// folds); the VOP3P form takes the inline 0.  On gfx950 a DOT result is not interlocked against the next VALU read (3 wait
+// states; an asm v_dot2 followed directly by its consumer returns garbage -- measured, round 5) and hipcc pads only the DOTs
+// it can see: the block itself ends 3 wait states after its last DOT, so whatever follows is safe.
+static __device__ __forceinline__ void abx3_dot2x8(float (&r)[8], const unsigned (&a)[8], const unsigned (&b)[8]) {
+  asm("v_dot2_f32_f16 %0, %8, %16, 0\n\t"
+      "v_dot2_f32_f16 %1, %9, %17, 0\n\t"
+      "v_dot2_f32_f16 %2, %10, %18, 0\n\t"
+      "v_dot2_f32_f16 %3, %11, %19, 0\n\t"
+      "v_dot2_f32_f16 %4, %12, %20, 0\n\t"
+      "v_dot2_f32_f16 %5, %13, %21, 0\n\t"
+      "v_dot2_f32_f16 %6, %14, %22, 0\n\t"
+      "v_dot2_f32_f16 %7, %15, %23, 0\n\t"
+      "s_nop 2"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
+        "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]));
 }
 
 template <int I, int N, class F>
@@ -222,19 +236,22 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
     else if constexpr (i == 24) vtm = t2m[7];      // pairs q = 14, 15
   };
   constexpr int TPS = (25 + FPW - 1) / FPW;        // table loads per fold step
-  // ---- low fold: a register holds (B[r,i], B[r,i+64]) -> (P[r,i], Q[r,i]) (v_dot2_f32_f16: exact products, one rounding)
+  // ---- the two folds in ONE loop: step t requests high fragment t and its share of the table loads, folds low fragment t
+  //      (a register holds (B[r,i], B[r,i+64]) -> (P[r,i], Q[r,i]); v_dot2_f32_f16: exact products, one rounding) and high
+  //      fragment t - FD, which was requested FD steps earlier -- the loop is bound by what the CU takes in, and the high fold's
+  //      VALU work fills the waits of the low one.  High fold (abx_rope_kernel FOLD): row (pair, u, head) of an M-block:
+  //      P = q_i B_i + q_{i+64} B_{i+64} (u = 0), Q = q_{i+64} B_i - q_i B_{i+64} (u = 1); the (d, d + 64) partner row sits in
+  //      lane ^ 2.  The query stays readable throughout (ring slot 0; the folded high fragments go to slot 1 + the W region).
   {
     const int qd = lane >> 4;
-    abx3_for<0, FPW>([&](auto t_c) {
+    const int u = (lane >> 1) & 1;
+    auto fold_low = [&](auto t_c) {
       constexpr int t = decltype(t_c)::value;
-      hraw[t] = bh_base[(int64_t)t * 64];
-      abx3_for<0, TPS>([&](auto j_c) { tload(std::integral_constant<int, t * TPS + decltype(j_c)::value>{}); });
-      __builtin_amdgcn_sched_barrier(0);
       const int f = w * FPW + t;
       const int h4 = (f >> 1) & 3, cs2 = t & 1;
       const u32x4 qq = *(const lds_u32x4*)(uintptr_t)(lds0 + (unsigned)(M::OFF_Q + (h4 * 64 + ABX2_I0 + 16 * cs2 + 4 * qd) * 4));
       u32x4 own = lraw[t];
-      u32x4 res;
+      unsigned da[8], db[8];
 #pragma unroll
       for (int e4 = 0; e4 < 4; ++e4) {
         // (element -> scalar -> bit_cast: hipcc 7.2 folds __builtin_bit_cast(h16x2, vec[e4]) to element 0 for every e4)
@@ -243,33 +260,25 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
         h16x2 cq;
         cq[0] = cp[1];
         cq[1] = -cp[0];                                                  // (q_{i+64}, -q_i)
-        const float r0 = abx3_dot2(oe, __builtin_bit_cast(unsigned, cp));
-        const float r1 = abx3_dot2(oe, __builtin_bit_cast(unsigned, cq));
+        da[2 * e4] = da[2 * e4 + 1] = oe;
+        db[2 * e4] = qe;
+        db[2 * e4 + 1] = __builtin_bit_cast(unsigned, cq);
+      }
+      float dr[8];
+      abx3_dot2x8(dr, da, db);
+      u32x4 res;
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4) {
         h16x2 r2;
-        r2[0] = (h16)r0;
-        r2[1] = (h16)r1;
+        r2[0] = (h16)dr[2 * e4];
+        r2[1] = (h16)dr[2 * e4 + 1];
         res[e4] = __builtin_bit_cast(unsigned, r2);
       }
       *(lds_u32x4*)(uintptr_t)(lds0 + (unsigned)(M::OFF_LOWF + (f * 64 + lane) * 16)) = res;
-    });
-  }
-  // the first block's latents LAST: a wave's loads return in issue order, and these come from HBM while 256 workgroups ask
-  // for theirs at once -- in front of the fragment loads they held every fold back by their latency; nothing reads the
-  // block before the main loop (>= 8 k cycles from here)
-  if (nblk > 0) {
-#pragma unroll
-    for (int k = 0; k < NKS; ++k) dma_piece(0, 0, k);
-  }
-  stamp();  // 3
-  __syncthreads();                                 // #2: nobody reads the query any more (the high fragments overwrite it)
-
-  // ---- high fold (abx_rope_kernel FOLD): row (pair, u, head) of an M-block: P = q_i B_i + q_{i+64} B_{i+64} (u = 0),
-  //      Q = q_{i+64} B_i - q_i B_{i+64} (u = 1); the (d, d + 64) partner row sits in lane ^ 2
-  {
-    const int u = (lane >> 1) & 1;
-#pragma unroll
-    for (int t = 0; t < FPW; ++t) {
-      const int s = t / NKS, j = t % NKS;
+    };
+    auto fold_high = [&](auto t_c) {
+      constexpr int t = decltype(t_c)::value;
+      constexpr int s = t / NKS, j = t % NKS;
       const int mb = 2 * w + s;
       const int ks = (j + (mb >= 4 ? NKS / 2 : 0)) % NKS;              // (abx2_prepare_b_kernel: waves 4-7 store half a turn ahead)
       const h16x2 q2 = __builtin_bit_cast(h16x2, s ? qp1 : qp0);
@@ -277,22 +286,39 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
       coef[0] = u ? -q2[0] : q2[0];
       coef[1] = q2[1];
       u32x4 own = hraw[t];
-      u32x4 res;
+      unsigned da[8], db[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const unsigned ow = own[e];
         const unsigned par = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ow, 0x4E, 0xF, 0xF, false);   // lane ^ 2
-        const unsigned lo2 = __builtin_amdgcn_perm(par, ow, 0x05040100u);
-        const unsigned hi2 = __builtin_amdgcn_perm(par, ow, 0x07060302u);
-        const float r0 = abx3_dot2(lo2, __builtin_bit_cast(unsigned, coef));
-        const float r1 = abx3_dot2(hi2, __builtin_bit_cast(unsigned, coef));
+        da[2 * e] = __builtin_amdgcn_perm(par, ow, 0x05040100u);
+        da[2 * e + 1] = __builtin_amdgcn_perm(par, ow, 0x07060302u);
+        db[2 * e] = db[2 * e + 1] = __builtin_bit_cast(unsigned, coef);
+      }
+      float dr[8];
+      abx3_dot2x8(dr, da, db);
+      u32x4 res;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
         h16x2 r2;
-        r2[0] = (h16)r0;
-        r2[1] = (h16)r1;
+        r2[0] = (h16)dr[2 * e];
+        r2[1] = (h16)dr[2 * e + 1];
         res[e] = __builtin_bit_cast(unsigned, r2);
       }
       *(lds_u32x4*)(uintptr_t)(lds0 + (unsigned)(M::OFF_HIF + ((mb * NKS + ks) * 64 + lane) * 16)) = res;
-    }
+    };
+    constexpr int FD = FPW / 2;                    // the high fold runs this many steps behind its loads
+    abx3_for<0, FPW + FD>([&](auto t_c) {
+      constexpr int t = decltype(t_c)::value;
+      if constexpr (t < FPW) {
+        hraw[t] = bh_base[(int64_t)t * 64];
+        abx3_for<0, TPS>([&](auto j_c) { tload(std::integral_constant<int, t * TPS + decltype(j_c)::value>{}); });
+        __builtin_amdgcn_sched_barrier(0);
+        fold_low(t_c);
+      }
+      if constexpr (t >= FD) fold_high(std::integral_constant<int, t - FD>{});
+      __builtin_amdgcn_sched_barrier(0);
+    });
   }
   // ---- RoPE state of this lane: (cs, sn)[q] = cos, sin of the exact angle of position n of the wave's first block -- one
   //      complex product per pair; M-block 7's pairs start one block early; (rc, rs) = the step of 32 positions
@@ -313,8 +339,17 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
       sn[q] = fmaf(st, cm, -(ct * sm));
     }
   }
+  stamp();  // 3
   stamp();  // 4
-  __syncthreads();                                 // #3: all folded fragments are in LDS
+  __syncthreads();                                 // #2: all folded fragments are in LDS, nobody reads the query any more
+
+  // the first block's latents LAST: a wave's loads return in issue order, and these come from HBM while 256 workgroups ask
+  // for theirs at once -- in front of the fragment loads they held every fold back by their latency (and ring slot 0 held the
+  // query until here); nothing reads the block before the main loop (>= 5 k cycles from here)
+  if (nblk > 0) {
+#pragma unroll
+    for (int k = 0; k < NKS; ++k) dma_piece(0, 0, k);
+  }
 
   // ---- every wave takes ALL high fragments: 8 NKS AGPR quads, MFMA-only operands from here on
   h16x8 bf[8][NKS];
@@ -328,7 +363,7 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
   stamp();  // 5
-  __syncthreads();                                 // #4: ring slot 1 and the W images are free
+  __syncthreads();                                 // #3: ring slot 1 and the W images are free
 
   if (nblk <= 0) return;                           // (no barrier below this line)
 
