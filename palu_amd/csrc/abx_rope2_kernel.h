@@ -30,6 +30,27 @@
 
 namespace {
 
+// Eight dot products r[e] = a[e].x * b[e].x + a[e].y * b[e].y in fp32 (exact products, one rounding) as ONE asm block.
+// hipcc turns the builtin with a zero accumulator into v_mov + v_dot2c_f32_f16 + hazard padding (2.7 instructions per dot in the
+// folds); the VOP3P form takes the inline 0.  On gfx950 a DOT result is not interlocked against the next VALU read (3 wait
+// states; an asm v_dot2 followed directly by its consumer returns garbage -- measured, round 5) and hipcc pads only the DOTs
+// it can see: the block itself ends 3 wait states after its last DOT, so whatever follows is safe.
+static __device__ __forceinline__ void abx2_dot2x8(float (&r)[8], const unsigned (&a)[8], const unsigned (&b)[8]) {
+  asm("v_dot2_f32_f16 %0, %8, %16, 0\n\t"
+      "v_dot2_f32_f16 %1, %9, %17, 0\n\t"
+      "v_dot2_f32_f16 %2, %10, %18, 0\n\t"
+      "v_dot2_f32_f16 %3, %11, %19, 0\n\t"
+      "v_dot2_f32_f16 %4, %12, %20, 0\n\t"
+      "v_dot2_f32_f16 %5, %13, %21, 0\n\t"
+      "v_dot2_f32_f16 %6, %14, %22, 0\n\t"
+      "v_dot2_f32_f16 %7, %15, %23, 0\n\t"
+      "s_nop 2"
+      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
+      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
+        "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]));
+}
+
+
 constexpr int ABX2_I0 = 32;       // first pair of the low band
 constexpr int ABX2_K = 8;         // polynomial terms (degree 7)
 
@@ -377,17 +398,22 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
     for (int ks = 0; ks < NKS; ++ks) {
       u32x4 own = __builtin_bit_cast(u32x4, bf[ks]);
       u32x4 res;
+      unsigned da[8], db[8];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         unsigned ow = own[e];
         unsigned par = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ow, 0x4E, 0xF, 0xF, false);   // lane ^ 2: the other of (d, d + 64)
-        unsigned lo2 = __builtin_amdgcn_perm(par, ow, 0x05040100u);
-        unsigned hi2 = __builtin_amdgcn_perm(par, ow, 0x07060302u);
-        float r0 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, lo2), coef, 0.f, false);
-        float r1 = __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, hi2), coef, 0.f, false);
+        da[2 * e] = __builtin_amdgcn_perm(par, ow, 0x05040100u);
+        da[2 * e + 1] = __builtin_amdgcn_perm(par, ow, 0x07060302u);
+        db[2 * e] = db[2 * e + 1] = __builtin_bit_cast(unsigned, coef);
+      }
+      float dr[8];
+      abx2_dot2x8(dr, da, db);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
         h16x2 r2;
-        r2[0] = (h16)r0;
-        r2[1] = (h16)r1;
+        r2[0] = (h16)dr[2 * e];
+        r2[1] = (h16)dr[2 * e + 1];
         res[e] = __builtin_bit_cast(unsigned, r2);
       }
       bf[ks] = __builtin_bit_cast(h16x8, res);
@@ -401,6 +427,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
         const u32x4 qq = *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)(qbuf + (unsigned)((h4 * 64 + ABX2_I0 + 16 * cs + 4 * q) * 4));
         u32x4 own = __builtin_bit_cast(u32x4, lowf[h4][cs]);
         u32x4 res;
+        unsigned da[8], db[8];
 #pragma unroll
         for (int e4 = 0; e4 < 4; ++e4) {
           // (element -> scalar -> bit_cast: hipcc 7.2 folds __builtin_bit_cast(h16x2, vec[e4]) to element 0 for every e4)
@@ -409,12 +436,17 @@ __global__ __launch_bounds__(NTHREADS, 2) void abx_rope2_kernel(AbxParams p) {
           h16x2 cq;
           cq[0] = cp[1];
           cq[1] = -cp[0];                                                  // (q_{i+64}, -q_i)
-          const h16x2 bb = __builtin_bit_cast(h16x2, oe);
-          float r0 = __builtin_amdgcn_fdot2(bb, cp, 0.f, false);
-          float r1 = __builtin_amdgcn_fdot2(bb, cq, 0.f, false);
+          da[2 * e4] = da[2 * e4 + 1] = oe;
+          db[2 * e4] = qe;
+          db[2 * e4 + 1] = __builtin_bit_cast(unsigned, cq);
+        }
+        float dr[8];
+        abx2_dot2x8(dr, da, db);
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
           h16x2 r2;
-          r2[0] = (h16)r0;
-          r2[1] = (h16)r1;
+          r2[0] = (h16)dr[2 * e4];
+          r2[1] = (h16)dr[2 * e4 + 1];
           res[e4] = __builtin_bit_cast(unsigned, r2);
         }
         lowf[h4][cs] = __builtin_bit_cast(h16x8, res);
