@@ -58,34 +58,46 @@ static __device__ __forceinline__ float block_sum(float v, float* sh, int tid) {
 // per thread are requested together, so a range costs ceil(rows / (PA_UN * threads)) memory latencies instead of one
 // per row.  Writes the scaled logits to pl[h][i] and returns the running maxima.
 constexpr int PA_UN = 4;
+// one sweep = PA_UN x PV_THREADS positions: the loads (scores of the GS heads + the mask) ...
 template <int GS>
-static __device__ __forceinline__ void logits_sweep(const h16* scores, int64_t ss_h, const h16* mask, int g, int l0, int n,
-                                                    int rps, float inv_scale, float* pl, float (&mloc)[GS], int tid) {
+static __device__ __forceinline__ void logits_load(const h16* scores, int64_t ss_h, const h16* mask, int g, int l0, int n, int k0,
+                                                   h16 (&sc)[PA_UN][GS], h16 (&mk)[PA_UN], int tid) {
   const int nlast = max(n - 1, 0);
-  for (int k0 = 0; k0 * PV_THREADS < n; k0 += PA_UN) {
-    h16 sc[PA_UN][GS], mk[PA_UN];
 #pragma unroll
-    for (int u = 0; u < PA_UN; ++u) {
-      const int ic = min(tid + (k0 + u) * PV_THREADS, nlast);
+  for (int u = 0; u < PA_UN; ++u) {
+    const int ic = min(tid + (k0 + u) * PV_THREADS, nlast);
 #pragma unroll
-      for (int h = 0; h < GS; ++h) sc[u][h] = scores[(int64_t)(g * GS + h) * ss_h + l0 + ic];
-      mk[u] = mask ? mask[l0 + ic] : (h16)0.f;
-    }
+    for (int h = 0; h < GS; ++h) sc[u][h] = scores[(int64_t)(g * GS + h) * ss_h + l0 + ic];
+    mk[u] = mask ? mask[l0 + ic] : (h16)0.f;
+  }
+}
+// ... and what is done with them: x = fp16(fp16(s) / sqrt(D)) (+ mask), the logits to LDS, the thread's running maxima
+template <int GS>
+static __device__ __forceinline__ void logits_apply(const h16 (&sc)[PA_UN][GS], const h16 (&mk)[PA_UN], bool masked, int n, int k0, int rps,
+                                                    float inv_scale, float* pl, float (&mloc)[GS], int tid) {
 #pragma unroll
-    for (int u = 0; u < PA_UN; ++u) {
-      const int i = tid + (k0 + u) * PV_THREADS;
-      if (i < n) {
+  for (int u = 0; u < PA_UN; ++u) {
+    const int i = tid + (k0 + u) * PV_THREADS;
+    if (i < n) {
 #pragma unroll
-        for (int h = 0; h < GS; ++h) {
-          // fp16 tensor / python float -> fp32 divide, rounded to fp16 (torch semantics); then + mask in fp16
-          h16 x16 = (h16)((float)sc[u][h] / inv_scale);
-          if (mask) x16 = (h16)((float)x16 + (float)mk[u]);
-          const float x = (float)x16;
-          pl[h * rps + i] = x;
-          mloc[h] = fmaxf(mloc[h], x);
-        }
+      for (int h = 0; h < GS; ++h) {
+        // fp16 tensor / python float -> fp32 divide, rounded to fp16 (torch semantics); then + mask in fp16
+        h16 x16 = (h16)((float)sc[u][h] / inv_scale);
+        if (masked) x16 = (h16)((float)x16 + (float)mk[u]);
+        const float x = (float)x16;
+        pl[h * rps + i] = x;
+        mloc[h] = fmaxf(mloc[h], x);
       }
     }
+  }
+}
+template <int GS>
+static __device__ __forceinline__ void logits_sweep(const h16* scores, int64_t ss_h, const h16* mask, int g, int l0, int n,
+                                                    int rps, float inv_scale, float* pl, float (&mloc)[GS], int tid, int k_begin = 0) {
+  for (int k0 = k_begin; k0 * PV_THREADS < n; k0 += PA_UN) {
+    h16 sc[PA_UN][GS], mk[PA_UN];
+    logits_load<GS>(scores, ss_h, mask, g, l0, n, k0, sc, mk, tid);
+    logits_apply<GS>(sc, mk, mask != nullptr, n, k0, rps, inv_scale, pl, mloc, tid);
   }
 }
 
@@ -133,8 +145,16 @@ __global__ __launch_bounds__(PV_THREADS) void pv_partial_kernel(PvParams p) {
     for (int u = 0; u < U; ++u)
       raw[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + (int64_t)min(i + u * rpp, nlast) * p.sv_l));
   };
+  // A wave's loads return in issue order: the range's scores (L2 / MALL: the score kernel has just written them) are requested
+  // FIRST, then two batches of V rows (HBM).  The other way round the statistics waited for the V rows' round trip and HBM sat
+  // idle while they were computed; now the stream runs from the first cycle and phase A works in its shadow.
+  h16 sc0[PA_UN][GS], mk0[PA_UN];
+  logits_load<GS>(p.scores, p.ss_h, p.mask, g, l0, n, 0, sc0, mk0, tid);
   u32x4 rawA[U], rawB[U];
-  if (streamer) load_batch(rawA, rg);   // in flight while the softmax statistics are computed
+  if (streamer) {
+    load_batch(rawA, rg);
+    load_batch(rawB, rg + U * rpp);
+  }
 
   // ---- phase A: logits, local max, probabilities, local sum (per head of the group)
   // all heads of the group in one sweep: one block reduction (two barriers) for the maxima, one for the sums
@@ -142,7 +162,8 @@ __global__ __launch_bounds__(PV_THREADS) void pv_partial_kernel(PvParams p) {
   float mloc[GS], sloc[GS];
 #pragma unroll
   for (int h = 0; h < GS; ++h) mloc[h] = -INFINITY;
-  logits_sweep<GS>(p.scores, p.ss_h, p.mask, g, l0, n, p.rps, p.inv_scale, pl, mloc, tid);
+  logits_apply<GS>(sc0, mk0, p.mask != nullptr, n, 0, p.rps, p.inv_scale, pl, mloc, tid);
+  logits_sweep<GS>(p.scores, p.ss_h, p.mask, g, l0, n, p.rps, p.inv_scale, pl, mloc, tid, PA_UN);   // (ranges above 1024 rows)
   block_reduce<GS, true>(mloc, shg, tid);
 #pragma unroll
   for (int h = 0; h < GS; ++h) sloc[h] = 0.f;
@@ -189,16 +210,16 @@ __global__ __launch_bounds__(PV_THREADS) void pv_partial_kernel(PvParams p) {
   };
   if (streamer) {
     const int stride = U * rpp;
-    int i = rg;   // rawA holds the batch whose first row is i (issued before phase A)
+    int i = rg;   // rawA holds the batch whose first row is i, rawB the next one (both issued before phase A)
     for (;;) {
-      load_batch(rawB, i + stride);   // one batch ahead; clamped beyond the range (weight 0 in consume)
       consume(rawA, i);
       i += stride;
       if (i >= n) break;
-      load_batch(rawA, i + stride);
+      load_batch(rawA, i + stride);   // one batch ahead; clamped beyond the range (weight 0 in consume)
       consume(rawB, i);
       i += stride;
       if (i >= n) break;
+      load_batch(rawB, i + stride);
     }
   }
   __syncthreads();   // everyone is done reading the probabilities: reuse the buffer for the reduction
