@@ -99,8 +99,9 @@ int palu_abx_two_band_selected(const float* inv_freq, int H, int G, int L, int R
  * (csrc/abx_rope3_kernel.h: 4 waves per workgroup, a wave owns whole 32-position blocks for all RoPE pairs, high-band
  * fragments in AGPRs, no cross-wave reduction) and the pair-split one (csrc/abx_rope2_kernel.h: 8 waves, 4 pairs each,
  * per-tile LDS reduction).  The first needs 2/3 of the cycles per tile and a longer prologue: it is selected (fp16 latents,
- * one launch) from n = 2 tiles per wave on.  palu_abx_set_position_split(n): 0 = never (PALU_ABX_SPLIT=0 in the environment
- * starts there), n >= 1 = from n tiles per wave on (1 = whenever the shape allows); returns the previous setting.
+ * one launch) from n = 1 tile per wave on.  palu_abx_set_position_split(n): 0 = never (PALU_ABX_SPLIT=0 in the environment
+ * starts there), n >= 1 = from n tiles per wave on, n < 0 = on every shape the kernel takes (tests, A/B); returns the previous setting
+ * (in the same encoding).
  * Process-wide, for A/B measurements. */
 int palu_abx_set_position_split(int enable);
 int palu_abx_position_split_selected(const float* inv_freq, int H, int G, int L, int R, int pos0);

@@ -36,10 +36,10 @@ int position_split_enabled() {
 }
 
 // The position-split kernel pays a longer prologue (every wave takes all high-band fragments) for a main loop that needs
-// 3/4 of the cycles: it wins once a wave (4 per CU) has two 128-position tiles (32k positions x 8 groups: 27.7 against 29.0 us;
-// one tile per wave: 18.7 against 18.3; profiles/r05_abx_split_vs_pair.txt).
-// g_split_min_tiles: tiles per wave from which it is selected (palu_abx_set_position_split(n > 1) sets it; 1 = always)
-int g_split_min_tiles = 2;
+// 3/4 of the cycles: it wins once a wave (4 per CU) has ONE 128-position tile (16k positions x 8 groups: 17.1 against 17.9 us,
+// 32k: 26.4 against 29.2, 64k: 43.3 against 48.7; a quarter of a tile per wave: equal; profiles/r05_abx_split_vs_pair.txt).
+// g_split_min_tiles: tiles per wave from which it is selected (palu_abx_set_position_split(n >= 1) sets it; n < 0: 0 = always)
+int g_split_min_tiles = 1;
 bool position_split_preferred(const AbxParams& p) {
   const int on = position_split_enabled();
   if (!on) return false;
@@ -182,9 +182,10 @@ extern "C" int palu_abx_two_band_selected(const float* inv_freq, int H, int G, i
 // Process-wide switch between the two forms of the two-band kernel (returns the previous value): 1 (default) the
 // position-split kernel (abx_rope3_kernel.h) where it applies, 0 the pair-split kernel (abx_rope2_kernel.h) everywhere
 extern "C" int palu_abx_set_position_split(int enable) {
-  const int o = position_split_enabled() ? g_split_min_tiles : 0;
+  const int o = position_split_enabled() ? (g_split_min_tiles > 0 ? g_split_min_tiles : -1) : 0;
   g_position_split = enable ? 1 : 0;
-  if (enable > 0) g_split_min_tiles = enable;        // (1 = whenever the shape allows, n = from n tiles per wave on)
+  if (enable > 0) g_split_min_tiles = enable;        // from n tiles per wave on
+  if (enable < 0) g_split_min_tiles = 0;             // every shape the kernel takes (tests, A/B measurements)
   return o;
 }
 

@@ -131,7 +131,7 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
   auto dma_piece = [&](int b, int slot, int k) {
     const int bb = min(b, blk_last);
     const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)(row00 + 32 * bb + k * RPP) * row_bytes);
-    const unsigned dst = (unsigned)((slot ? M::OFF_X1 : M::OFF_X0) + w * M::BLK + k * 1024);
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)((slot ? M::OFF_X1 : M::OFF_X0) + w * M::BLK + k * 1024));   // (an SGPR whatever the pressure)
     asm volatile(
         "s_mov_b32 m0, %0\n\t"
         "s_nop 0\n\t"
@@ -365,37 +365,46 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
   auto read_lowf = [&](int f) { return *(const lds_h16x8*)(uintptr_t)(lowa + (unsigned)(f * 1024)); };
   auto write_w = [&](int rb, int h4, const h16x4& v) { *(lds_h16x4*)(uintptr_t)(w_st + (unsigned)(rb * 1024 + h4 * 128)) = v; };
 
-  // ---- W image of the first tile (stage 1, plain form): D = [P|Q](16 latent columns x 64) . coef(64 x 16 terms); two fragment
-  //      sets alternate (the next r-block's fragments are requested before this one's MFMAs), the four first halves of an
-  //      r-block before the four second halves (no dependent pair back to back)
+  // ---- W image of the first tile (stage 1, plain form): D = [P|Q](16 latent columns x 64) . coef(64 x 16 terms).  Asm MFMAs
+  //      with VGPR accumulators (hipcc puts the builtin's into AGPRs -- all 256 hold fragments here: it spilled two of them to
+  //      scratch around this block -- and reads every element back); two fragment sets and two accumulator sets alternate:
+  //      r-block rb's fragments are requested one r-block ahead, its results are converted and stored behind the MFMAs of
+  //      r-block rb + 1 (a full burst after their own: the asm-MFMA rule of this file), the four first halves of an r-block
+  //      before the four second halves (no dependent pair back to back)
   {
-    h16x8 lfa[8], lfb2[8];
+    h16x8 lfa[8];
+    f32x4 waA[4], waB[4];
     auto load8 = [&](h16x8 (&lf)[8], int rb) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) lf[i] = read_lowf(rb * 8 + i);
     };
-    auto rblock = [&](const h16x8 (&lf)[8], int rb) {
-      f32x4 wa4[4];
+    auto mfma8 = [&](const h16x8 (&lf)[8], f32x4 (&wa)[4]) {
 #pragma unroll
-      for (int h4 = 0; h4 < 4; ++h4) wa4[h4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lf[2 * h4], cf0[0], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      for (int h4 = 0; h4 < 4; ++h4) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(wa[h4]) : "v"(lf[2 * h4]), "v"(cf0[0]));
 #pragma unroll
-      for (int h4 = 0; h4 < 4; ++h4) wa4[h4] = __builtin_amdgcn_mfma_f32_16x16x32_f16(lf[2 * h4 + 1], cf0[1], wa4[h4], 0, 0, 0);
+      for (int h4 = 0; h4 < 3; ++h4) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(wa[h4]) : "v"(lf[2 * h4 + 1]), "v"(cf0[1]));
+      asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\ts_nop 7" : "+v"(wa[3]) : "v"(lf[7]), "v"(cf0[1]));
+    };
+    auto store4 = [&](const f32x4 (&wa)[4], int rb) {
 #pragma unroll
       for (int h4 = 0; h4 < 4; ++h4) {
         h16x4 wpk;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) wpk[j] = (h16)wa4[h4][j];
+        for (int j = 0; j < 4; ++j) wpk[j] = (h16)wa[h4][j];
         write_w(rb, h4, wpk);
       }
     };
     load8(lfa, 0);
-#pragma unroll
-    for (int rb = 0; rb < NKS; rb += 2) {
-      load8(lfb2, rb + 1);
-      rblock(lfa, rb);
-      if (rb + 2 < NKS) load8(lfa, rb + 2);
-      rblock(lfb2, rb + 1);
-    }
+    abx3_for<0, NKS>([&](auto rb_c) {
+      constexpr int rb = decltype(rb_c)::value;
+      mfma8(lfa, (rb & 1) ? waB : waA);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (rb + 1 < NKS) load8(lfa, rb + 1);   // (an MFMA has read its sources long before an LDS load returns)
+      if constexpr (rb > 0) store4((rb & 1) ? waA : waB, rb - 1);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // the last burst's results (no MFMAs follow to cover them)
+    store4(((NKS - 1) & 1) ? waB : waA, NKS - 1);
   }
   stamp();  // 6
 
@@ -489,9 +498,10 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
   //      The 8 low fragments of a burst are requested in the last slots of the phase before; its results are rounded and stored
   //      two slots later -- a result of an asm MFMA is never read before the slot AFTER the next one (whatever hipcc hoists
   //      inside a slot, a whole slot with its 32-cycle MFMA lies in between).
-  auto block = [&](auto B_c, auto S1_c, int b, int tnext) {
+  auto block = [&](auto B_c, auto S1_c, auto LAST_c, int b, int tnext) {
     constexpr int B = decltype(B_c)::value;
     constexpr bool S1 = decltype(S1_c)::value;
+    constexpr bool LAST = decltype(LAST_c)::value;   // a block of the wave's last tile
     constexpr int SL = B & 1;
     constexpr int PH0 = 9 * B;                       // phase number of this block's stage 2
     constexpr int PSTEP = 8 / NKS;                   // r-block r of stage 1 sits in front of phase 1 + r PSTEP
@@ -561,7 +571,12 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
         if (mb == 7 && ks == 0) {
           // block b + 1 has landed: only the NKS pieces of block b + 2 (issued above; in block 1 also the two coefficient
           // loads behind them) may still be in flight
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B == 1 ? NKS + 2 : NKS) : "memory");
+          // ... in the wave's LAST tile every request is waited for: there the younger requests are re-reads past the wave's
+          // range (clamped to its last block, which may be partly out of range), and such a re-read was seen retiring ahead of
+          // the block's own, older request on cold launches -- rows of the wave's last block stale in 18 of 240 launches
+          // (tools/stress_tail_cold.py).  (A compile-time choice: a run-time branch here makes hipcc spill around the asm MFMAs.)
+          if (LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B == 1 ? NKS + 2 : NKS) : "memory");
           if (B == 2) asm volatile("" : "+v"(cfr[0]), "+v"(cfr[1]));
         }
         constexpr bool BURST = S1 && mb % PSTEP == 0;  // this phase opens with the stage-1 burst of r-block mb / PSTEP
@@ -633,28 +648,34 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
   };
 
   // ---- first block: its fragments
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NKS) : "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (both: block 1's request may be a re-read of block 0, see the blocks' own waits)
   stamp();  // 7
 #pragma unroll
   for (int ks = 0; ks < NKS; ++ks) xf[ks] = read_x(ks, 0);
 #pragma unroll
   for (int i = 0; i < WD; ++i) wfr[i] = read_w(i);
 
-  // ---- tiles of 4 blocks; the partial tail tile leaves through a side exit.  Stage 1 always runs in a tile's last block (after
-  //      the wave's last full tile it builds the image of the tail tile, or one nobody reads)
+  // ---- tiles of 4 blocks.  Every tile but the wave's last is full and carries stage 1 of its successor in its last block; the
+  //      last one (possibly a partial tail: side exits) builds no image -- a peeled copy, so that the loop body has one shape
+  //      (a stage-1 choice INSIDE the loop made hipcc spill; an image nobody reads cost 3.7 % of a 4-tile wave's launch)
   int b = 0, tt = 0;
+  for (; tt + 1 < ntile; ++tt) {
+    block(ABX3_IC(0), std::false_type{}, std::false_type{}, b, tt + 1);
+    block(ABX3_IC(1), std::false_type{}, std::false_type{}, b + 1, tt + 1);
+    block(ABX3_IC(2), std::false_type{}, std::false_type{}, b + 2, tt + 1);
+    block(ABX3_IC(3), std::true_type{}, std::false_type{}, b + 3, tt + 1);
+    b += 4;
+  }
   do {
-    const int tnext = min(tt + 1, ntile - 1);
-    block(ABX3_IC(0), std::false_type{}, b, tnext);
+    block(ABX3_IC(0), std::false_type{}, std::true_type{}, b, tt);
     if (++b == nblk) break;
-    block(ABX3_IC(1), std::false_type{}, b, tnext);
+    block(ABX3_IC(1), std::false_type{}, std::true_type{}, b, tt);
     if (++b == nblk) break;
-    block(ABX3_IC(2), std::false_type{}, b, tnext);
+    block(ABX3_IC(2), std::false_type{}, std::true_type{}, b, tt);
     if (++b == nblk) break;
-    block(ABX3_IC(3), std::true_type{}, b, tnext);
+    block(ABX3_IC(3), std::false_type{}, std::true_type{}, b, tt);
     ++b;
-    ++tt;
-  } while (b < nblk);
+  } while (false);
   // ---- drain: the epilogue of the last block's M-block 7, then its scores
   stamp();
   // (the last block's M-block 7 sits in set (9 B + 8) & 1 = B & 1: accB after an odd B, accA after an even one)

@@ -414,7 +414,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void decode_fused_kernel(FusedParams p
       int lane_o = lane;
       asm volatile("" : "+v"(lane_o));
       const pvm::Lane<NT> ln = pvm::make_lane<NT>(lane_o, col0, v_row_bytes, FTL * 2);
-      if (p.exp_flags & 1) {
+      // (the range's last units: the younger requests the count relies on are re-reads of the last unit, clamped; in the
+      //  position-split score kernel such re-reads were seen retiring ahead of an older request on cold launches -- every
+      //  request is waited for there: abx_rope3_kernel.h, tools/stress_tail_cold.py)
+      if ((p.exp_flags & 1) || u + 3 > last_unit) {
         vm_wait<0>();
       } else {
         vm_wait<WAIT>();                   // this unit's DMA pieces have landed (static issue schedule)
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void decode_fused_kernel(FusedParams p
     for (int s = 0; s <= T + 2; ++s) {
       if (s >= 8 && s < 20) stamp();
       if (s > 0) {
-        if (s <= 3 || (p.exp_flags & 1)) {
+        if (s <= 3 || s + 3 >= T || (p.exp_flags & 1)) {   // (the range's last steps: see pv_step)
           vm_wait<0>();
         } else {
           vm_wait<2 * NT>();               // K tile s+1 (issued first thing in step s-1) has landed

@@ -80,9 +80,10 @@ def pair_split():
 
 
 @contextlib.contextmanager
-def position_split(min_tiles: int = 1):
-    """Run the enclosed launches on the position-split kernel wherever the shape allows (default: from 2 tiles per wave on)."""
-    old = _lib.lib.palu_abx_set_position_split(int(min_tiles))
+def position_split(min_tiles: int = 0):
+    """Run the enclosed launches on the position-split kernel: on every shape it takes (min_tiles = 0, the default of this
+    context manager) or from `min_tiles` tiles of 128 positions per wave on (the library's own rule: from 1)."""
+    old = _lib.lib.palu_abx_set_position_split(int(min_tiles) if min_tiles > 0 else -1)
     try:
         yield
     finally:

@@ -32,6 +32,15 @@ def _inputs(H, G, R, L, seed, band="all", scale_b=None):
     return torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(x)
 
 
+def _form(ar, form):
+    """The two forms of the two-band kernel: "pair_split" (csrc/abx_rope2_kernel.h), "position_split" (csrc/abx_rope3_kernel.h)
+    on EVERY shape it takes -- the library itself selects it from one tile per wave on, which small test shapes never reach."""
+    return ar.pair_split() if form == "pair_split" else ar.position_split(0)
+
+
+FORMS = ["pair_split", "position_split"]
+
+
 def _p2(got, a, b, x, theta=10000.0):
     exact = oracle.abx_scores_f64(a, b, x, theta)
     ref16 = oracle.abx_scores(a, b, x, theta)
@@ -73,26 +82,34 @@ def test_selection_rules():
     assert _lib.lib.palu_abx_two_band_selected(inv_llama3.data_ptr(), 32, 8, 65537, 128, 0) == 1
 
 
+@pytest.mark.parametrize("form", FORMS)
 @pytest.mark.parametrize("band", ["high", "low", "all"])
 @pytest.mark.parametrize("R,L", [(128, 1000), (64, 517), (32, 300)])
-def test_bands_in_isolation_vs_oracle(band, R, L):
+def test_bands_in_isolation_vs_oracle(band, R, L, form):
     """A query with only high-band (or only low-band) components exercises one half of the kernel alone."""
     _lib, ar = _mods()
     a, b, x = _inputs(32, 8, R, L, seed=R + L, band=band)
-    got = ar.abx(a.cuda(), b.cuda(), x.cuda())
+    with _form(ar, form):
+        got = ar.abx(a.cuda(), b.cuda(), x.cuda())
     _p2(got, a, b, x)
 
 
 @pytest.mark.parametrize("H,G,R,L", [(32, 8, 128, 1), (32, 8, 128, 33), (32, 8, 128, 128), (32, 8, 128, 129), (32, 8, 128, 255),
                                      (32, 8, 128, 4096 + 97), (4, 1, 128, 8191), (32, 8, 64, 2113), (32, 8, 32, 2048),
                                      (8, 2, 64, 5000)])
-def test_two_band_and_one_band_agree(H, G, R, L):
+@pytest.mark.parametrize("form", FORMS)
+def test_two_band_and_one_band_agree(H, G, R, L, form):
     _lib, ar = _mods()
     a, b, x = _inputs(H, G, R, L, seed=7 * L + R)
     ac, bc, xc = a.cuda(), b.cuda(), x.cuda()
     inv = ar.rope_inv_freq(xc.device)
     assert _lib.lib.palu_abx_two_band_selected(inv.data_ptr(), H, G, L, R, 0) == 1
-    two = ar.abx(ac, bc, xc)
+    with _form(ar, form):
+        if form == "position_split":
+            assert _lib.lib.palu_abx_position_split_selected(inv.data_ptr(), H, G, L, R, 0) == 1
+        two = ar.abx(ac, bc, xc)
+        again = ar.abx(ac, bc, xc)
+    assert torch.equal(two, again)                     # (deterministic: no atomics, no order-dependent reduction)
     with ar.one_band():
         one = ar.abx(ac, bc, xc)
     _p2(two, a, b, x)
@@ -149,7 +166,7 @@ def test_two_band_at_256k_positions(R, form):
     ac, bc, xc = a.cuda(), b.cuda(), x.cuda()
     inv = ar.rope_inv_freq(xc.device)
     assert _lib.lib.palu_abx_two_band_selected(inv.data_ptr(), H, G, L, R, 0) == 1
-    ctx = ar.pair_split() if form == "pair_split" else ar.position_split(1)
+    ctx = ar.pair_split() if form == "pair_split" else ar.position_split(0)
     with ctx:
         got = ar.abx(ac, bc, xc)[:, :, L - W:].cpu().double().reshape(H, W)
     l0 = L - W
@@ -234,19 +251,25 @@ def test_packed_ranks_above_128_score_like_their_dequantised_rows(bits, R, L):
     assert torch.equal(out, ar.abx(ac, bc, xdq))
 
 
-def test_pos_offset_in_whole_tiles_and_other_theta():
+@pytest.mark.parametrize("form", FORMS)
+def test_pos_offset_in_whole_tiles_and_other_theta(form):
     """pos_offset a multiple of 128 indexes the coefficient table by absolute tile (split-L ranks, chunked callers); a
-    Llama-3 style theta = 5e5 builds its own table."""
+    Llama-3 style theta = 5e5 builds its own table; a cache VIEW with a row stride above R (interleaved layouts)."""
     _lib, ar = _mods()
     H, G, R, L = 32, 8, 128, 1500
     a, b, x = _inputs(H, G, R, L, seed=3)
     ac, bc, xc = a.cuda(), b.cuda(), x.cuda()
-    full = ar.abx(ac, bc, xc)
-    part = ar.abx(ac, bc, xc[:, 384:].contiguous(), pos_offset=384)
-    scale = float(full.float().abs().max())
-    assert float((part.float() - full[:, :, 384:].float()).abs().max()) <= 5e-4 * scale
-    got = ar.abx(ac, bc, xc, theta=500000.0)
-    _p2(got, a, b, x, theta=500000.0)
+    with _form(ar, form):
+        full = ar.abx(ac, bc, xc)
+        part = ar.abx(ac, bc, xc[:, 384:].contiguous(), pos_offset=384)
+        scale = float(full.float().abs().max())
+        assert float((part.float() - full[:, :, 384:].float()).abs().max()) <= 5e-4 * scale
+        got = ar.abx(ac, bc, xc, theta=500000.0)
+        _p2(got, a, b, x, theta=500000.0)
+        wide = torch.zeros(G, L, 160, dtype=torch.float16, device="cuda")
+        wide[:, :, :R] = xc
+        view = ar.abx(ac, bc, wide[:, :, :R])
+    assert torch.equal(view, full)
 
 
 @pytest.mark.parametrize("two_band", [1, 0])
@@ -304,3 +327,41 @@ def test_rows_quantised_in_column_groups_run_the_two_band_kernel(bits, R, gsz, L
                                          scr.data_ptr(), torch.cuda.current_stream().cuda_stream), "abx_qg")
     _p2(out, a, b, xdq.cpu())
     assert torch.equal(out, ar.abx(ac, bc, xdq))
+
+@pytest.mark.parametrize("form", FORMS)
+def test_tail_blocks_on_cold_launches(form):
+    """A wave's LAST block on launches that start cold (fresh inputs, L2 / MALL turned over in between): the position-split
+    kernel's counted `s_waitcnt vmcnt(N)` relied on younger requests that, past the wave's range, are re-reads of its last
+    block -- and such a re-read was seen retiring ahead of the block's own request: 4..16 stale rows at the end of a group in
+    7 % of such launches at R = 32, rarely at R = 64 (round 5; fixed by waiting for every request in a wave's last tile).
+    48 cold launches per form, ragged lengths, against an fp64 evaluation on the GPU."""
+    _lib, ar = _mods()
+    dev = torch.device("cuda:0")
+    inv = ar.rope_inv_freq(dev)
+    big = torch.empty(1 << 28, device=dev, dtype=torch.float16)
+
+    def ref(a, b, x):
+        H, R, _ = b.shape
+        G, L, _ = x.shape
+        keys = torch.matmul(x[:, None].double(), b.double().reshape(G, H // G, R, D))
+        ang = torch.outer(torch.arange(L, device=dev).float(), inv).double()
+        c, s = ang.cos(), ang.sin()
+        k1, k2 = keys[..., :64], keys[..., 64:]
+        rot = torch.cat((k1 * c - k2 * s, k2 * c + k1 * s), -1)
+        return torch.einsum("ghd,ghld->ghl", a.double().reshape(G, H // G, D), rot).reshape(H, L)
+
+    bad = []
+    with _form(ar, form):
+        for rep in range(12):
+            for R, L in ((32, 4396), (32, 300), (64, 4396), (128, 4400)):
+                g = torch.Generator().manual_seed(1000 * rep + L + R)
+                a = torch.randn(32, 1, D, generator=g).half().to(dev)
+                b = (torch.randn(32, R, D, generator=g) * R ** -0.5).half().to(dev)
+                x = torch.randn(8, L, R, generator=g).half().to(dev)
+                r = ref(a, b, x)
+                big[: 1 << 27].copy_(big[1 << 27:])          # 512 MB through the caches: the launch below starts cold
+                y = ar.abx(a, b, x).reshape(32, L).double()
+                err = float((y - r).abs().max()) / float(r.abs().max())
+                if not err <= 2e-3:
+                    bad.append((rep, R, L, err))
+    assert not bad, bad

@@ -12,7 +12,7 @@ import torch
 from palu_amd import _lib
 from palu_amd.kernel.abx_rope import abx, rope_inv_freq, pair_split, one_band
 
-_lib.lib.palu_abx_set_position_split(1)      # every shape the kernel takes, not only where it is the default
+_lib.lib.palu_abx_set_position_split(-1)      # every shape the kernel takes, not only where it is the default
 
 dev = torch.device("cuda:0")
 D = 128

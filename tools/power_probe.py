@@ -25,7 +25,7 @@ x = torch.randn(G, L, R, generator=g).half().to(dev)
 xz = torch.zeros_like(x)
 out = torch.empty(H, 1, L, device=dev, dtype=torch.float16)
 rope_inv_freq(dev)
-_lib.lib.palu_abx_set_position_split(1)
+_lib.lib.palu_abx_set_position_split(-1)
 
 samples = []
 stop = False
