@@ -569,14 +569,16 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
       abx3_for<0, NKS>([&](auto ks_c) {
         constexpr int ks = decltype(ks_c)::value;
         if (mb == 7 && ks == 0) {
-          // block b + 1 has landed: only the NKS pieces of block b + 2 (issued above; in block 1 also the two coefficient
-          // loads behind them) may still be in flight
+          // block b + 1 has landed: only the NKS LDS-DMA pieces of block b + 2 (issued above) may still be in flight.  The count
+          // is of DMA requests alone: block 1's two coefficient loads (plain loads, requested behind its pieces) and the
+          // stores may retire in any order relative to them -- counted in, a coefficient load that retires early would let the
+          // wait pass with two pieces of block b + 1 still on their way
           // ... in the wave's LAST tile every request is waited for: there the younger requests are re-reads past the wave's
           // range (clamped to its last block, which may be partly out of range), and such a re-read was seen retiring ahead of
           // the block's own, older request on cold launches -- rows of the wave's last block stale in 18 of 240 launches
           // (tools/stress_tail_cold.py).  (A compile-time choice: a run-time branch here makes hipcc spill around the asm MFMAs.)
           if (LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B == 1 ? NKS + 2 : NKS) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NKS) : "memory");
           if (B == 2) asm volatile("" : "+v"(cfr[0]), "+v"(cfr[1]));
         }
         constexpr bool BURST = S1 && mb % PSTEP == 0;  // this phase opens with the stage-1 burst of r-block mb / PSTEP
@@ -621,9 +623,9 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
           });
           dma_piece(b + 2, SL, ks);
           if (B == 1 && ks == NKS - 1) {
-            // coefficients of the next tile (its stage 1 runs in this tile's last block): requested BEHIND this block's DMA
-            // pieces -- the vmcnt(NKS + 2) of this block leaves them in flight, the vmcnt(NKS) of the next block covers them:
-            // two block times for a read that misses every cache
+            // coefficients of the next tile (its stage 1 runs in this tile's last block): requested behind this block's DMA
+            // pieces; this block's and the next block's vmcnt(NKS) cover them (most of a block time for a read that may miss
+            // every cache)
             const u32x4* src = tab0 + (int64_t)tnext * 64;             // (uniform: scalar base + the lane's offset)
             asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:512"
                          : "=&v"(cfr[0]), "=&v"(cfr[1])
