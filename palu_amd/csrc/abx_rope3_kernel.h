@@ -20,7 +20,10 @@
 //     builds its own per-tile low-band weights W (stage 1, from the folded [P|Q]_low fragments all waves share read-only in
 //     LDS) and keeps them in a private 8 KB image.  No barrier after the prologue.
 //   * the prologue is cooperative: every wave folds the query into a quarter of the fragments, the folded fragments go
-//     through LDS once (the high ones through the space the rings use later).
+//     through LDS once (the high ones through the space the rings use later).  Its loads are ordered for in-order return (what
+//     comes from HBM is requested last), both folds run in one loop behind their loads, dot products as asm blocks.
+//   * the wave's last tile is a peeled copy of the loop body: no stage 1 for a tile that does not exist, and every request is
+//     waited for there (the counted waits of the loop rely on younger requests that, past the wave's range, are re-reads).
 // Per 32-position block and wave: 8 NKS + NKS big MFMAs (+ 8 NKS small ones per tile in the tile's last block), 256 + 16
 // VALU of rotation work, 2 NKS LDS reads; at R = 128 about 6.3 issued instructions per big MFMA -- what one wave can
 // issue in a matrix-pipe slot (tools/ubench_issue.hip).
@@ -62,8 +65,9 @@ static __device__ __forceinline__ void abx3_for(F&& f) {
   }
 }
 
-// dbg (TIMING): [workgroup][wave 4][64] s_memtime stamps: 0 start, 1 loads issued, 2 RoPE init, 3 low fold, 4 high fold,
-// 5 fragments in AGPRs, 6 first W image, 7 first block landed, 8.. start of every block, then drain start, end
+// dbg (TIMING): [workgroup][wave 4][64] s_memtime stamps: 0 start, 1 low fragments requested, 2 query in LDS, 3 = 4 both folds
+// done, 5 fragments in AGPRs, 6 first W image, 7 first block landed, 8.. start of every block, then drain start, end.  (With the
+// peeled last tile the TIMING build no longer fits the register file: it spills and its numbers mean nothing -- use the PMC passes.)
 template <int NKS, bool TIMING = false>
 __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void abx_rope3_kernel(AbxParams p) {
   using Geo = LdsGeom<NKS>;
