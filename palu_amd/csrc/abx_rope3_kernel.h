@@ -440,7 +440,7 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
   //   c = 4, 5 / 6, 7: the two head pairs of j = 0 / 1 -- the only chunks that read the accumulators: they sit in the second
   //                    half of the M-block's slots, at least one full MFMA after the accumulators' last MFMA whatever hipcc
   //                    hoists inside a slot (with NKS < 8 a slot carries several chunks)
-  float cc[2] = {0.f, 0.f}, ss[2] = {0.f, 0.f}, m1[2] = {0.f, 0.f}, m2[2] = {0.f, 0.f};
+  float cc[2] = {0.f, 0.f}, ss[2] = {0.f, 0.f}, m1[2] = {0.f, 0.f};
   auto epi_chunk = [&](auto mbp_c, auto c_c, const f32x16& ac) {
     constexpr int mbp = decltype(mbp_c)::value, c = decltype(c_c)::value;
     if constexpr (mbp < 0 || mbp > 7) {
@@ -453,13 +453,13 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
         cc[j] = fmaf(lo_cur, sn[q], cs[q]);
         ss[j] = fmaf(-lo_cur, cs[q], sn[q]);
         ang_n = lfe * fr[qn];
-        m1[j] = cs[q] * rc[q];                     // (the first two products of the state advance ride here: 5 + 4 VALU operations
-        m2[j] = sn[q] * rc[q];                     //  for the two slots instead of 3 + 6 -- a slot hides five beside its MFMA)
-      } else {
+        m1[j] = fmaf(-sn[q], rs[q], cs[q] * rc[q]);   // (the new cosine rides here, the sine is advanced in place in the next
+                                                      //  chunk: 5 + 4 VALU operations for the two slots instead of 3 + 6 -- a
+      } else {                                        //  slot hides five beside its MFMA -- and one register copy less per pair)
         lo_cur = fmaf(lfe, fr[qn], -ang_n);
-        const float c2 = fmaf(-sn[q], rs[q], m1[j]);
-        sn[q] = fmaf(cs[q], rs[q], m2[j]);
-        cs[q] = c2;
+        sn[q] *= rc[q];
+        sn[q] = fmaf(cs[q], rs[q], sn[q]);
+        cs[q] = m1[j];
       }
     } else {
       constexpr int j = (c - 4) >> 1, h1 = (c - 4) & 1;
