@@ -82,6 +82,20 @@ def test_host_only_entry_points_work_without_gpu():
     assert _lib.lib.palu_pv_direct_nsplit(8, 1000, 40, 4) == 0
 
 
+def test_position_split_switch_round_trips_without_gpu():
+    """palu_abx_set_position_split (include/palu_hip.h): 0 = never, n >= 1 = from n tiles per wave, n < 0 = every shape the kernel
+    takes; the call returns the previous setting in the same encoding (what the Python context managers restore)."""
+    from palu_amd import _lib
+    f = _lib.lib.palu_abx_set_position_split
+    first = f(3)
+    try:
+        assert first != 0                       # the library starts with the position-split form enabled ...
+        assert f(-1) == 3 and f(0) == -1 and f(2) == 0 and f(first) == 2
+        assert f(first) == first                # ... from one tile per wave on (unless PALU_ABX_SPLIT=0 was set)
+    finally:
+        f(first)
+
+
 def test_pv_workspace_covers_every_fill_level():
     """the split count is not monotone in L, so a workspace sized for a cache capacity must hold the
     partials of EVERY L <= capacity -- for the split-L P.V kernel and for the fused decode kernel (host arithmetic only;
