@@ -26,7 +26,10 @@ def ref_fp64(a, b, x, v, pos0, scores16):
     return torch.einsum("ghl,glr->ghr", p.view(G, gs, -1), v.double()).reshape(H, -1)
 
 
-def run(H, G, Rk, Rv, L, pos0=0, scale=1.0, seed=0, time_it=False, ldk=None, ldv=None):
+_BIG = None
+
+
+def run(H, G, Rk, Rv, L, pos0=0, scale=1.0, seed=0, time_it=False, ldk=None, ldv=None, cold=False, quiet=False):
     dev = "cuda"
     torch.manual_seed(seed)
     a = (torch.randn(H, D, device=dev) * scale).half()
@@ -69,12 +72,18 @@ def run(H, G, Rk, Rv, L, pos0=0, scale=1.0, seed=0, time_it=False, ldk=None, ldv
     old()
     torch.cuda.synchronize()
     ref = ref_fp64(a, b, k[:, :L], v[:, :L], pos0, scores[:, :L])
+    if cold:                                   # 512 MB through the caches: the fused launch starts cold
+        global _BIG
+        if _BIG is None:
+            _BIG = torch.empty(1 << 28, device=dev, dtype=torch.float16)
+        _BIG[: 1 << 27].copy_(_BIG[1 << 27:])
     new()
     torch.cuda.synchronize()
     e_old = (ctx0.double() - ref).abs().max().item()
     e_new = (ctx1.double() - ref).abs().max().item()
     d = (ctx1.float() - ctx0.float()).abs().max().item()
-    ok = bool(torch.isfinite(ctx1).all()) and e_new <= max(2e-3 * ref.abs().max().item(), 3 * e_old + 1e-4)
+    # (cold stress: a stale 32-row unit shows as >= 1e-2 of the largest output; the kernel's own fp16 rounding stays below 3e-3)
+    ok = bool(torch.isfinite(ctx1).all()) and e_new <= max((5e-3 if cold else 2e-3) * ref.abs().max().item(), 3 * e_old + 1e-4)
     line = (f"H={H} G={G} Rk={Rk} Rv={Rv} L={L} pos0={pos0} scale={scale}: |ref|max {ref.abs().max():.3f}  "
             f"err two-kernel {e_old:.2e}  err fused {e_new:.2e}  fused-vs-two {d:.2e}  {'OK' if ok else 'FAIL'}")
     if time_it:
@@ -90,7 +99,8 @@ def run(H, G, Rk, Rv, L, pos0=0, scale=1.0, seed=0, time_it=False, ldk=None, ldv
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) * 1e3 / n
         line += f"   two-kernel {t(old):.1f} us  fused {t(new):.1f} us"
-    print(line, flush=True)
+    if not (quiet and ok):
+        print(line, flush=True)
     return ok
 
 
@@ -98,7 +108,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--time", action="store_true")
     ap.add_argument("--quick", action="store_true")
+    ap.add_argument("--cold", type=int, default=0, help="N repetitions of ragged shapes on launches that start cold (fresh inputs, "
+                    "caches turned over): the static vmcnt schedule of the kernel at the end of a workgroup's range")
     args = ap.parse_args()
+    if args.cold:
+        bad = n = 0
+        for rep in range(args.cold):
+            for c in ((4, 1, 128, 384, 3000 + 7 * rep), (4, 1, 128, 384, 65537 + rep), (32, 8, 128, 384, 2900 + 13 * rep),
+                      (4, 1, 64, 192, 20011 + rep), (8, 2, 128, 384, 9973 + 5 * rep), (32, 8, 64, 128, 5003 + rep)):
+                n += 1
+                bad += not run(*c, seed=100 + rep, cold=True, quiet=True)
+        print(f"check_fused --cold: {bad} bad of {n} launches")
+        sys.exit(1 if bad else 0)
     ok = True
     cases = [
         (32, 8, 128, 384, 64), (32, 8, 128, 384, 65), (32, 8, 128, 384, 1), (32, 8, 128, 384, 129),
