@@ -750,18 +750,38 @@ def main():
             sc_buf = torch.empty((H, (cap + 8) // 8 * 8), dtype=torch.float16, device=dev)
             pv_buf = torch.empty(lib.palu_pv_workspace_bytes(H, G, cap, Rv), dtype=torch.uint8, device=dev)
 
-            def k_qkv():
-                _lib.check(lib.palu_decode_qkv_f16(w["wq"].data_ptr(), w["wq"].stride(0), w["vt_k"].data_ptr(),
-                                                   w["vt_k"].stride(0), w["vt_v"].data_ptr(), w["vt_v"].stride(0),
-                                                   hidden.data_ptr(), q_buf.data_ptr(), k_cache.data_ptr(),
-                                                   k_cache.stride(0), k_cache.stride(1), v_cache.data_ptr(),
-                                                   v_cache.stride(0), v_cache.stride(1), inv.data_ptr(), Hl, D, HIDDEN,
-                                                   G, Rk, Rv, Lp, Lp, s()), "qkv")
+            # the step's own launches: when its score launch takes the position-split kernel, the projection kernel folds the
+            # query into the B fragments in the tail of its q waves and the score kernel reads the folded fragments
+            # (csrc/abx_fold.h; palu_decode_attend_f16 makes the same choice)
+            nfold = lib.palu_abx_fold_bytes(H, G, Rk)
+            prefold = bool(nfold and lib.palu_abx_position_split_selected(inv.data_ptr(), H, G, L, Rk, 0))
+            qf_buf = torch.zeros(max(nfold, 16), dtype=torch.uint8, device=dev)
 
-            def k_abx():
+            def k_qkv():
+                _lib.check(lib.palu_decode_qkv_fold_f16(w["wq"].data_ptr(), w["wq"].stride(0), 0, w["vt_k"].data_ptr(),
+                                                        w["vt_k"].stride(0), w["vt_v"].data_ptr(), w["vt_v"].stride(0),
+                                                        hidden.data_ptr(), q_buf.data_ptr(), k_cache.data_ptr(),
+                                                        k_cache.stride(0), k_cache.stride(1), v_cache.data_ptr(),
+                                                        v_cache.stride(0), v_cache.stride(1), inv.data_ptr(), Hl, D, HIDDEN,
+                                                        G, Rk, Rv, Lp, Lp, dec.frag.data_ptr() if prefold else 0,
+                                                        qf_buf.data_ptr() if prefold else 0, s()), "qkv")
+
+            def k_abx_in_kernel_fold():            # round 5's form: every workgroup folds the query in its prologue
                 _lib.check(lib.palu_abx_rope_f16(q_buf.data_ptr(), D, 1, dec.frag.data_ptr(), k_cache.data_ptr(),
                                                  k_cache.stride(0), k_cache.stride(1), sc_buf.data_ptr(),
                                                  sc_buf.stride(0), Hl, G, L, Rk, D, inv.data_ptr(), 0, s()), "abx")
+
+            def k_abx_fold_launch():               # the stand-alone op: fold kernel + score kernel (palu_abx_rope_ws_f16 with scratch)
+                _lib.check(lib.palu_abx_rope_ws_f16(q_buf.data_ptr(), D, 1, dec.frag.data_ptr(), k_cache.data_ptr(),
+                                                    k_cache.stride(0), k_cache.stride(1), sc_buf.data_ptr(),
+                                                    sc_buf.stride(0), Hl, G, L, Rk, D, inv.data_ptr(), 0, qf_buf.data_ptr(), s()), "abx")
+
+            def k_abx():
+                if not prefold:
+                    return k_abx_in_kernel_fold()
+                _lib.check(lib.palu_abx_rope_pf_f16(qf_buf.data_ptr(), k_cache.data_ptr(), k_cache.stride(0), k_cache.stride(1),
+                                                    sc_buf.data_ptr(), sc_buf.stride(0), Hl, G, L, Rk, D, inv.data_ptr(), 0,
+                                                    s()), "abx_pf")
 
             def k_pv():
                 _lib.check(lib.palu_softmax_pv_f16(sc_buf.data_ptr(), sc_buf.stride(0), 0, v_cache.data_ptr(),
@@ -833,22 +853,30 @@ def main():
             from palu_amd.kernel.abx_rope import one_band, pair_split
             two_band = bool(lib.palu_abx_two_band_selected(inv.data_ptr(), H, G, L, Rk, 0))
             split = bool(lib.palu_abx_position_split_selected(inv.data_ptr(), H, G, L, Rk, 0))
-            kms1 = kms2 = float("nan")
+            kms1 = kms2 = kms3 = kms4 = float("nan")
             if not args.no_abx_sweep:
                 with one_band():
-                    _, kms1 = time_loop(k_abx, n, 10, torch.cuda.synchronize, reps=5)
+                    _, kms1 = time_loop(k_abx_in_kernel_fold, n, 10, torch.cuda.synchronize, reps=5)
                 with pair_split():
-                    _, kms2 = time_loop(k_abx, n, 10, torch.cuda.synchronize, reps=5)
+                    _, kms2 = time_loop(k_abx_in_kernel_fold, n, 10, torch.cuda.synchronize, reps=5)
+                if prefold:
+                    _, kms3 = time_loop(k_abx_in_kernel_fold, n, 10, torch.cuda.synchronize, reps=5)
+                    _, kms4 = time_loop(k_abx_fold_launch, n, 10, torch.cuda.synchronize, reps=5)
             ex_f = executed_two_band_flops(Rk, L) if two_band else af
             us_abx = kern["abx"]["us"]
             pmc = {}
             if os.path.exists(tf):
                 pmc = json.load(open(tf))
             rec["roofline_abx"] = {
-                "kernel": ("abx_rope3_kernel (two-band, position-split)" if split else
+                "kernel": ("abx_rope3_kernel (two-band, position-split" + (", fragments folded by the projection kernel's q waves)"
+                                                                          if prefold else ")") if split else
                            "abx_rope2_kernel (two-band, pair-split)" if two_band else "abx_rope_kernel (one-band)"),
                 "one_band_kernel_us": None if kms1 != kms1 else round(kms1 * 1e3 / n, 2),
                 "pair_split_kernel_us": None if kms2 != kms2 else round(kms2 * 1e3 / n, 2),
+                # the same kernel with the fold in every workgroup's prologue (round 5's form), and the stand-alone op
+                # (fold kernel + score kernel, two launches): bit-identical scores (tests/test_fold_gpu.py)
+                "in_kernel_fold_us": None if kms3 != kms3 else round(kms3 * 1e3 / n, 2),
+                "fold_launch_plus_kernel_us": None if kms4 != kms4 else round(kms4 * 1e3 / n, 2),
                 "bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_PEAK_TFLOPS,
                 # contract fields: ALGORITHMIC flops (2*H*L*R*D + 5*H*L*D) / time
                 "achieved": kern["abx"]["tflops"], "frac": round(kern["abx"]["tflops"] / MFMA_PEAK_TFLOPS, 4),
@@ -876,13 +904,22 @@ def main():
                     xs = torch.randn(G, Ls, Rk, device=dev, dtype=torch.float16)
                     so = torch.empty(H, Ls, dtype=torch.float16, device=dev)
 
+                    sp = bool(lib.palu_abx_position_split_selected(inv.data_ptr(), H, G, Ls, Rk, 0))
+                    if sp:                                  # (the query's fold is the projection kernel's, as in a step)
+                        _lib.check(lib.palu_abx_fold_f16(q_buf.data_ptr(), D, 1, dec.frag.data_ptr(), qf_buf.data_ptr(), H, G, Rk,
+                                                         s()), "fold")
+
                     def k_s():
+                        if sp:
+                            _lib.check(lib.palu_abx_rope_pf_f16(qf_buf.data_ptr(), xs.data_ptr(), xs.stride(0), xs.stride(1),
+                                                                so.data_ptr(), so.stride(0), H, G, Ls, Rk, D, inv.data_ptr(), 0,
+                                                                s()), "abx_pf")
+                            return
                         _lib.check(lib.palu_abx_rope_f16(q_buf.data_ptr(), D, 1, dec.frag.data_ptr(), xs.data_ptr(), xs.stride(0),
                                                          xs.stride(1), so.data_ptr(), so.stride(0), H, G, Ls, Rk, D,
                                                          inv.data_ptr(), 0, s()), "abx")
                     _, kms = time_loop(k_s, 30, 5, torch.cuda.synchronize, reps=3)
                     tb = bool(lib.palu_abx_two_band_selected(inv.data_ptr(), H, G, Ls, Rk, 0))
-                    sp = bool(lib.palu_abx_position_split_selected(inv.data_ptr(), H, G, Ls, Rk, 0))
                     bs = 2 * G * Ls * Rk + 2 * H * Rk * D + 2 * H * D + 2 * H * Ls
                     sweep.append({"L": Ls, "us": round(kms * 1e3 / 30, 2),
                                   "kernel": "two-band position-split" if sp else "two-band pair-split" if tb else "one-band",

@@ -105,6 +105,25 @@ int palu_abx_two_band_selected(const float* inv_freq, int H, int G, int L, int R
  * Process-wide, for A/B measurements. */
 int palu_abx_set_position_split(int enable);
 int palu_abx_position_split_selected(const float* inv_freq, int H, int G, int L, int R, int pos0);
+/* The query fold as its own step (round 6; csrc/abx_fold.h).  The position-split kernel multiplies the latents with
+ * P[r,i] = q_i B[r,i] + q_{i+64} B[r,i+64], Q[r,i] = q_{i+64} B[r,i] - q_i B[r,i+64] -- the weight of the reference's
+ * `_abx_fwd` (kernel/abx_rope.py:79-111) with the query moved onto B.  Folding inside the kernel repeated the same work in every
+ * workgroup of a latent group; it is now done once per launch, by one wave per (head, RoPE pair):
+ *   palu_abx_fold_bytes(H, G, R)  bytes of the folded-fragment buffer `qfold` (16 R KB per group; 0 = shape without the
+ *                                 position-split kernel: it needs H == 4 G and R in {32, 64, 128});
+ *   palu_abx_fold_f16             a [H, D] (strides sa_h, sa_d), bfrag from palu_abx_prepare_b -> qfold: the stand-alone fold;
+ *   palu_decode_qkv_fold_f16      (below) the decode step's form: the q waves of the projection kernel fold their own pair;
+ *   palu_abx_rope_pf_f16          scores from the folded fragments: same operands as palu_abx_rope_f16 with `qfold` in the
+ *                                 place of (a, bfrag).  PALU_ERR_UNSUPPORTED when the launch would not take the position-split
+ *                                 kernel (palu_abx_position_split_selected(...) == 0, or palu_abx_set_fold(0)).
+ * palu_abx_rope_ws_f16 runs fold + kernel itself when its scratch holds palu_abx_scratch_bytes() bytes (which now covers
+ * palu_abx_fold_bytes()); without scratch (palu_abx_rope_f16) the kernel folds in its own prologue as in round 5.  All three
+ * forms produce bit-identical scores (the same v_dot2_f32_f16 arithmetic on the same operands). */
+size_t palu_abx_fold_bytes(int H, int G, int R);
+int palu_abx_fold_f16(const void* a, int64_t sa_h, int64_t sa_d, const void* bfrag, void* qfold, int H, int G, int R,
+                      palu_stream_t stream);
+int palu_abx_rope_pf_f16(const void* qfold, const void* x, int64_t sx_g, int64_t sx_l, void* out, int64_t so_h,
+                         int H, int G, int L, int R, int D, const float* inv_freq, int pos0, palu_stream_t stream);
 size_t palu_abx_scratch_bytes(int H, int G, int L, int R);
 int palu_abx_rope_ws_f16(const void* a, int64_t sa_h, int64_t sa_d, const void* bfrag,
                          const void* x, int64_t sx_g, int64_t sx_l, void* out, int64_t so_h,
@@ -214,6 +233,16 @@ int palu_decode_qkv_bias_f16(const void* wq, int64_t ldq, const void* q_bias, co
                              int64_t sk_g, int64_t sk_l, void* v_cache, int64_t sv_g, int64_t sv_l,
                              const float* inv_freq, int H, int D, int hidden, int G, int Rk, int Rv, int pos,
                              int row, palu_stream_t stream);
+
+/* The same launch with the query fold of the position-split score kernel in the tail of its q waves: the wave that has just
+ * produced the rotated (q_i, q_{i+64}) of head h folds them into its 2 x R fragment values of B (bfrag = palu_abx_prepare_b's
+ * fragments) and writes them to `qfold` (palu_abx_fold_bytes(H, G, Rk) bytes), which palu_abx_rope_pf_f16 consumes later on the
+ * same stream.  bfrag = qfold = NULL: plain palu_decode_qkv_bias_f16. */
+int palu_decode_qkv_fold_f16(const void* wq, int64_t ldq, const void* q_bias, const void* vtk, int64_t ldk,
+                             const void* vtv, int64_t ldv, const void* x, void* q_out, void* k_cache,
+                             int64_t sk_g, int64_t sk_l, void* v_cache, int64_t sv_g, int64_t sv_l,
+                             const float* inv_freq, int H, int D, int hidden, int G, int Rk, int Rv, int pos,
+                             int row, const void* bfrag, void* qfold, palu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Whole decode step (5 launches on `stream`): qkv+RoPE+append -> abx -> softmax.PV -> o_proj.

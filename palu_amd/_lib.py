@@ -50,6 +50,9 @@ SIGNATURES = {
     "palu_abx_set_position_split": (i32, [i32]),
     "palu_abx_position_split_selected": (i32, [vp, i32, i32, i32, i32, i32]),
     "palu_abx_scratch_bytes": (sz, [i32, i32, i32, i32]),
+    "palu_abx_fold_bytes": (sz, [i32, i32, i32]),
+    "palu_abx_fold_f16": (i32, [vp, i64, i64, vp, vp, i32, i32, i32, vp]),
+    "palu_abx_rope_pf_f16": (i32, [vp, vp, i64, i64, vp, i64, i32, i32, i32, i32, i32, vp, i32, vp]),
     "palu_abx_rope_ws_f16": (i32, [vp, i64, i64, vp, vp, i64, i64, vp, i64, i32, i32, i32, i32, i32, vp, i32, vp, vp]),
     "palu_abx_rope_shared_f16": (i32, [vp, i64, i64, vp, vp, i64, i64, vp, i64, i32, i32, i32, i32, i32, vp, i32, vp]),
     "palu_pv_nsplit": (i32, [i32, i32]),
@@ -71,6 +74,8 @@ SIGNATURES = {
     "palu_rmsnorm_row_f16": (i32, [vp, vp, vp, i32, f32, vp]),
     "palu_decode_qkv_bias_f16": (i32, [vp, i64, vp, vp, i64, vp, i64, vp, vp, vp, i64, i64, vp, i64, i64, vp,
                                        i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "palu_decode_qkv_fold_f16": (i32, [vp, i64, vp, vp, i64, vp, i64, vp, vp, vp, i64, i64, vp, i64, i64, vp,
+                                       i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
     "palu_gemv_f16_acc32": (i32, [vp, i64, vp, vp, i32, i32, vp]),
     "palu_decode_qkv_f16": (i32, [vp, i64, vp, i64, vp, i64, vp, vp, vp, i64, i64, vp, i64, i64, vp,
                                   i32, i32, i32, i32, i32, i32, i32, i32, vp]),

@@ -17,7 +17,34 @@ LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libpalu_hip.so")
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc"]
 # per-file flags: the position-split score kernel schedules its VALU work by hand (no packed fp32 forms)
-FILE_FLAGS = {"abx_rope3.hip": ["-fno-slp-vectorize"]}
+FILE_FLAGS = {"abx_rope3.hip": ["-fno-slp-vectorize", "-Rpass-analysis=kernel-resource-usage"]}
+# kernels that must not touch scratch: the position-split score kernel sits at 256 VGPRs + 256 AGPRs with hand-placed
+# asm MFMAs -- a spill there is slow at best and has produced wrong scores.  Validated with the hipcc of ROCm 7.2.0;
+# after a compiler change re-run tools/check_fused.py and tools/stress_tail_cold.py on a GPU.  (name fragment, excluded fragment)
+NO_SCRATCH = {"abx_rope3.hip": ("abx_rope3_kernelILi", "ELb1ELb")}     # (the TIMING instantiations of experiment builds may spill)
+
+
+def _check_no_scratch(src: str, out: str) -> str:
+    """Parse -Rpass-analysis=kernel-resource-usage remarks; raise when a guarded kernel needs scratch.  Returns the
+    compiler output without the remarks."""
+    want, skip = NO_SCRATCH[os.path.basename(src)]
+    keep, name, seen = [], None, 0
+    for line in out.splitlines():
+        if "remark:" not in line:
+            keep.append(line)
+            continue
+        if "Function Name:" in line:
+            name = line.split("Function Name:")[1].split()[0]
+        elif "ScratchSize" in line and name and want in name and skip not in name:
+            seen += 1
+            nbytes = int(line.split("ScratchSize [bytes/lane]:")[1].split()[0])
+            if nbytes:
+                raise RuntimeError(f"{os.path.basename(src)}: {name} spills {nbytes} bytes/lane to scratch "
+                                   f"(it must fit 256 VGPRs + 256 AGPRs; see palu_amd/build.py NO_SCRATCH)")
+    if not seen:
+        raise RuntimeError(f"{os.path.basename(src)}: no resource-usage remark for {want}* (compiler output format changed?)")
+    # (the remarks come with source excerpts; keep the rest only when it carries a diagnostic of its own)
+    return "\n".join(keep) if any("warning:" in l or "error:" in l for l in keep) else ""
 
 
 def sources():
@@ -53,6 +80,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
         out, _ = pr.communicate()
         if pr.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        if os.path.basename(src) in NO_SCRATCH:
+            out = _check_no_scratch(src, out)
         if verbose and out.strip():
             print(out)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]

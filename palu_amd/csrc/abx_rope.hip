@@ -47,9 +47,9 @@ int launch_abx_shared(const AbxParams& p, int nwg, hipStream_t stream) {
 
 }  // namespace
 
-extern "C" int palu_abx_set_fold(int enable) {
+extern "C" int palu_abx_set_fold(int enable) {      // (enable < 0: query only)
   int o = g_abx_fold;
-  g_abx_fold = enable ? 1 : 0;
+  if (enable >= 0) g_abx_fold = enable ? 1 : 0;
   return o;
 }
 
@@ -75,10 +75,64 @@ extern "C" int palu_abx_prepare_b(const void* b, int64_t sb_h, int64_t sb_r, int
   return palu_abx2_prepare_b(b, sb_h, sb_r, sb_d, H, G, R, (char*)bfrag + abx_frag1_bytes(G, pl), (hipStream_t)stream);
 }
 
+const void* palu_abx_two_band_frags(const void* bfrag, int H, int G, int R) {
+  AbxPlan pl;
+  if (!bfrag || !abx_plan(H, G, R, &pl) || !palu_abx2_frag_bytes(H, G, R)) return nullptr;
+  return (const char*)bfrag + abx_frag1_bytes(G, pl);
+}
+
+extern "C" size_t palu_abx_fold_bytes(int H, int G, int R) {
+  if (G <= 0 || H != 4 * G || !(R == 32 || R == 64 || R == 128)) return 0;
+  return (size_t)G * abx_fold_u32x4_per_group(R / 16) * sizeof(u32x4);
+}
+
 extern "C" size_t palu_abx_scratch_bytes(int H, int G, int L, int R) {
   AbxPlan pl;
-  if (!abx_plan(H, G, R, &pl) || L <= 0 || !pl.chunked || pl.nkc < 2) return 0;
+  if (!abx_plan(H, G, R, &pl) || L <= 0) return 0;
+  if (!pl.chunked) return palu_abx_fold_bytes(H, G, R);       // the folded fragments of the position-split kernel (0: other shapes)
+  if (pl.nkc < 2) return 0;
   return (size_t)H * (((size_t)L + 7) & ~(size_t)7) * sizeof(float);
+}
+
+extern "C" int palu_abx_fold_f16(const void* a, int64_t sa_h, int64_t sa_d, const void* bfrag, void* qfold, int H, int G, int R,
+                                 palu_stream_t stream) {
+  PALU_REQUIRE(a && bfrag && qfold, PALU_ERR_ARG, "abx_fold: null pointer");
+  PALU_REQUIRE(palu_abx_fold_bytes(H, G, R) != 0, PALU_ERR_UNSUPPORTED,
+               "abx_fold: needs 4 heads per group and R in {32, 64, 128} (H=%d G=%d R=%d)", H, G, R);
+  PALU_REQUIRE((((uintptr_t)bfrag | (uintptr_t)qfold) & 15) == 0, PALU_ERR_ARG, "abx_fold: bfrag and qfold must be 16-byte aligned");
+  return palu_abx3_fold_launch(a, sa_h, sa_d, palu_abx_two_band_frags(bfrag, H, G, R), qfold, H, G, R / 16, (hipStream_t)stream);
+}
+
+// scores from pre-folded fragments: the position-split kernel or nothing (the caller decided with
+// palu_abx_position_split_selected when it asked for the fold)
+extern "C" int palu_abx_rope_pf_f16(const void* qfold, const void* x, int64_t sx_g, int64_t sx_l, void* out, int64_t so_h,
+                                    int H, int G, int L, int R, int D, const float* inv_freq, int pos0, palu_stream_t stream) {
+  AbxPlan pl;
+  PALU_REQUIRE(abx_plan(H, G, R, &pl) && palu_abx_fold_bytes(H, G, R) != 0, PALU_ERR_UNSUPPORTED,
+               "abx_pf: needs 4 heads per group and R in {32, 64, 128} (H=%d G=%d R=%d)", H, G, R);
+  PALU_REQUIRE(D == HEAD_DIM, PALU_ERR_UNSUPPORTED, "abx_pf: head_dim must be 128 (got %d)", D);
+  PALU_REQUIRE(L >= 0, PALU_ERR_ARG, "abx_pf: negative L");
+  if (L == 0) return PALU_OK;
+  PALU_REQUIRE(qfold && x && out && inv_freq, PALU_ERR_ARG, "abx_pf: null pointer");
+  PALU_REQUIRE((((uintptr_t)x | (uintptr_t)qfold) & 15) == 0 && sx_g % 8 == 0 && sx_l % 8 == 0 && sx_l >= R, PALU_ERR_ARG,
+               "abx_pf: x rows and qfold must be 16-byte aligned, rows contiguous (sx_g=%lld sx_l=%lld R=%d)", (long long)sx_g,
+               (long long)sx_l, R);
+  PALU_REQUIRE(((int64_t)L + 3 * 128) * sx_l * 2 < ((int64_t)1 << 32), PALU_ERR_ARG,
+               "abx_pf: one group's latent slab must stay below 4 GiB (L=%d sx_l=%lld)", L, (long long)sx_l);
+  const int64_t ob = ((int64_t)(H - 1) * so_h + L) * 2;
+  PALU_REQUIRE(ob > 0 && ob < 0xFFFFFFF0ll, PALU_ERR_UNSUPPORTED, "abx_pf: out extent must be < 4 GiB");
+  PALU_REQUIRE(g_abx_fold != 0 && palu_abx_position_split_selected(inv_freq, H, G, L, R, pos0), PALU_ERR_UNSUPPORTED,
+               "abx_pf: this launch does not take the position-split kernel (H=%d G=%d L=%d R=%d pos0=%d)", H, G, L, R, pos0);
+  AbxParams p = {};
+  p.x = (const h16*)x; p.sx_g = sx_g; p.sx_l = sx_l;
+  p.out = (h16*)out; p.so_h = so_h; p.out_bytes = (unsigned)ob;
+  p.inv_freq = inv_freq;
+  const int nwg = abx_fill_params(p, pl, H, G, L, R, pos0);
+  p.qfold = (const u32x4*)qfold;
+  p.bfrag2 = p.qfold;                                 // (palu_abx2_try_launch insists on fragments; the PREFOLD kernel reads qfold only)
+  const int rc = palu_abx2_try_launch(&p, nwg, 0, (hipStream_t)stream);
+  PALU_REQUIRE(rc != PALU_ABX2_SKIP, PALU_ERR_UNSUPPORTED, "abx_pf: no coefficient table covers these positions");
+  return rc;
 }
 
 extern "C" int palu_abx_rope_f16(const void* a, int64_t sa_h, int64_t sa_d, const void* bfrag, const void* x,
@@ -172,6 +226,12 @@ extern "C" int palu_abx_rope_ws_f16(const void* a, int64_t sa_h, int64_t sa_d, c
   if (fold && palu_abx2_frag_bytes(H, G, R)) {
     // gs = 4 at a fast rank: the two-band kernel when a coefficient table covers the positions (abx_rope2.hip)
     p.bfrag2 = (const u32x4*)((const char*)bfrag + abx_frag1_bytes(G, pl));
+    if (scratch && ((uintptr_t)scratch & 15) == 0 && palu_abx_position_split_selected(inv_freq, H, G, L, R, pos0)) {
+      // the position-split form on fragments folded once per launch (abx_fold.h) instead of once per workgroup
+      const int rcf = palu_abx3_fold_launch(a, sa_h, sa_d, p.bfrag2, scratch, H, G, R / 16, s);
+      if (rcf) return rcf;
+      p.qfold = (const u32x4*)scratch;
+    }
     const int rc = palu_abx2_try_launch(&p, nwg, 0, s);
     if (rc != PALU_ABX2_SKIP) return rc;
   }

@@ -52,6 +52,10 @@ bool position_split_preferred(const AbxParams& p) {
 template <int NKS, int QBITS>
 int launch2(const AbxParams& p, int nwg, hipStream_t stream) {
   if (QBITS == 0 && p.acc == nullptr && p.ncols == 0 && position_split_preferred(p)) return palu_abx3_launch(&p, NKS, stream);
+  if (p.qfold) {                                     // pre-folded fragments exist for the position-split kernel only
+    palu_set_error("abx: pre-folded fragments given to a launch that does not take the position-split kernel");
+    return PALU_ERR_UNSUPPORTED;
+  }
   if (p.acc == nullptr) return launch_kernel(abx_rope2_kernel<NKS, QBITS, 0>, abx2_smem(NKS), p, nwg, stream);
   if (p.win_pass == 0) return launch_kernel(abx_rope2_kernel<NKS, QBITS, 1>, abx2_smem(NKS), p, nwg, stream);   // first window: store
   if (p.win_pass == 1) return launch_kernel(abx_rope2_kernel<NKS, QBITS, 2>, abx2_smem(NKS), p, nwg, stream);   // middle ones: add

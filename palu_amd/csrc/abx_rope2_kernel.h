@@ -30,27 +30,7 @@
 
 namespace {
 
-// Eight dot products r[e] = a[e].x * b[e].x + a[e].y * b[e].y in fp32 (exact products, one rounding) as ONE asm block.
-// hipcc turns the builtin with a zero accumulator into v_mov + v_dot2c_f32_f16 + hazard padding (2.7 instructions per dot in the
-// folds); the VOP3P form takes the inline 0.  On gfx950 a DOT result is not interlocked against the next VALU read (3 wait
-// states; an asm v_dot2 followed directly by its consumer returns garbage -- measured, round 5) and hipcc pads only the DOTs
-// it can see: the block itself ends 3 wait states after its last DOT, so whatever follows is safe.
-static __device__ __forceinline__ void abx2_dot2x8(float (&r)[8], const unsigned (&a)[8], const unsigned (&b)[8]) {
-  asm("v_dot2_f32_f16 %0, %8, %16, 0\n\t"
-      "v_dot2_f32_f16 %1, %9, %17, 0\n\t"
-      "v_dot2_f32_f16 %2, %10, %18, 0\n\t"
-      "v_dot2_f32_f16 %3, %11, %19, 0\n\t"
-      "v_dot2_f32_f16 %4, %12, %20, 0\n\t"
-      "v_dot2_f32_f16 %5, %13, %21, 0\n\t"
-      "v_dot2_f32_f16 %6, %14, %22, 0\n\t"
-      "v_dot2_f32_f16 %7, %15, %23, 0\n\t"
-      "s_nop 2"
-      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7])
-      : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
-        "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]));
-}
-
-
+// (abx2_dot2x8, the asm block of eight v_dot2_f32_f16 the folds use, lives in abx_fold.h)
 constexpr int ABX2_I0 = 32;       // first pair of the low band
 constexpr int ABX2_K = 8;         // polynomial terms (degree 7)
 

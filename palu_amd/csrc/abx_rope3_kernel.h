@@ -68,7 +68,13 @@ static __device__ __forceinline__ void abx3_for(F&& f) {
 // dbg (TIMING): [workgroup][wave 4][64] s_memtime stamps: 0 start, 1 low fragments requested, 2 query in LDS, 3 = 4 both folds
 // done, 5 fragments in AGPRs, 6 first W image, 7 first block landed, 8.. start of every block, then drain start, end.  (With the
 // peeled last tile the TIMING build no longer fits the register file: it spills and its numbers mean nothing -- use the PMC passes.)
-template <int NKS, bool TIMING = false>
+// PREFOLD (round 6): the folded fragments come from p.qfold (abx_fold.h: written once per launch by the projection kernel's q
+// waves or by abx_fold_kernel) instead of being folded from (p.a, p.bfrag2) by every workgroup.  The prologue is then: tables +
+// the folded LOW fragments by LDS-DMA -> wait -> the folded HIGH fragments by LDS-DMA (into the ring's space) and the first
+// block's latents straight into registers -> barrier -> the first W image (needs the low fragments only: it runs while the high
+// ones land) -> wait, barrier -> LDS -> AGPRs -> barrier -> main loop.  Every wait is a vmcnt(0) (no counted wait on mixed
+// request types), and no VALU work, L2 read or LDS pass of the fold is left in the kernel.
+template <int NKS, bool TIMING = false, bool PREFOLD = false>
 __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void abx_rope3_kernel(AbxParams p) {
   using Geo = LdsGeom<NKS>;
   using M = Abx3Lds<NKS>;
@@ -86,7 +92,8 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n = lane & 31, hi = lane >> 5;
+  int n = lane & 31;                               // (re-derived behind the main loop, see there)
+  const int hi = lane >> 5;
   const int g = blockIdx.x % p.G;
   const int cidx = blockIdx.x / p.G;
   int stamp_i = 0;
@@ -142,15 +149,17 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
         "buffer_load_dwordx4 %1, %2, %3 offen lds"
         :
         : "s"(dst), "v"(dvoff[k % NV]), "s"(xrs), "s"(soff)
-        : "memory");
+        : "memory");   // (m0 cannot be listed: hipcc treats it as reserved and warns that the clobber is ignored; it never keeps a value in m0 on gfx950)
   };
   // ---- small loads FIRST (loads return in issue order: the query gates the first barrier, behind 32 KB of fragments it
   //      would arrive last): the query, frequencies, the first tile's coefficients
-  h16 qv[2];
+  h16 qv[2] = {(h16)0.f, (h16)0.f};
+  if constexpr (!PREFOLD) {
 #pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int idx = tid + ABX3_THREADS * e;
-    qv[e] = p.a[(int64_t)(g * 4 + (idx >> 7)) * p.sa_h + (int64_t)(idx & 127) * p.sa_d];
+    for (int e = 0; e < 2; ++e) {
+      const int idx = tid + ABX3_THREADS * e;
+      qv[e] = p.a[(int64_t)(g * 4 + (idx >> 7)) * p.sa_h + (int64_t)(idx & 127) * p.sa_d];
+    }
   }
   // lane (n, hi) holds the 16 high-band pairs i = 4 mb + 2 j + hi, q = 2 mb + j, of one position per block
   float fr[16];
@@ -168,45 +177,10 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
     if (ntile > 0) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(tab0 + cs * 32) + tab_lane);
     cf0[cs] = *reinterpret_cast<h16x8*>(&v);
   }
-  // ---- this wave's share of the fragments first (the bulk: nothing waits for them for a while): high f = mb NKS + j
-  //      (memory order [mb][j]), low f = rb 8 + h 2 + cs
-  const u32x4* bh_base = p.bfrag2 + ((int64_t)g * 8 * NKS + w * FPW) * 64 + lane;
-  const u32x4* bl_base = p.bfrag2 + (int64_t)p.G * 8 * NKS * 64 + ((int64_t)g * NKS * 8 + w * FPW) * 64 + lane;
-  // (a CU takes ~25 B per clock of these: a wave sits ~200 cycles on every load it issues once the queue is full.  The low
-  //  fragments are requested here; the high ones one per low-fold step below, so that the fold runs while the requests drain
-  //  instead of behind all 32 of them)
-  u32x4 hraw[FPW], lraw[FPW];
-#pragma unroll
-  for (int t = 0; t < FPW; ++t) lraw[t] = bl_base[(int64_t)t * 64];
-
-  stamp();  // 1
-
-  // the query to LDS as (q_i, q_{i+64}) pairs
-#pragma unroll
-  for (int e = 0; e < 2; ++e) {
-    const int idx = tid + ABX3_THREADS * e;
-    const int hh = idx >> 7, d = idx & 127;
-    *(lds_h16*)(uintptr_t)(lds0 + (unsigned)(M::OFF_Q + ((hh * 64 + (d & 63)) * 2 + (d >> 6)) * 2)) = qv[e];
-  }
-
-  stamp();  // 2
-
-  __syncthreads();                                 // #1: the query is in LDS
-  asm volatile("" : "+v"(cf0[0]), "+v"(cf0[1]));   // (hipcc's wait for these loads goes here, where nothing else is in flight)
-
-  // ---- (q_i, q_{i+64}) of this lane's rows in the two high M-blocks it folds
-  unsigned qp0, qp1;                               // (two scalars, not an array: the fold below picks one by a run-time bit)
-  {
-    const int m = lane & 31;
-    const int hh = 2 * ((m >> 3) & 1) + (m & 1);
-    const int i0 = 4 * (2 * w) + 2 * (m >> 4) + ((m >> 2) & 1);
-    qp0 = *(const lds_u32*)(uintptr_t)(lds0 + (unsigned)(M::OFF_Q + (hh * 64 + i0) * 4));
-    qp1 = *(const lds_u32*)(uintptr_t)(lds0 + (unsigned)(M::OFF_Q + (hh * 64 + i0 + 4) * 4));
-  }
   // exact-angle (cos, sin) of: the wave's first tile start (T1), this lane's offset n, the one-block-early start of M-block 7
   // (its epilogue runs during the NEXT block) and the 32-position step (T2, abx2_rope_start_kernel): 25 loads of 16 bytes per
-  // lane, requested a few per low-fold step behind the high fragments (their issue costs the CU's address unit 16 cycles each:
-  // 1.6 k cycles per CU that would otherwise sit between the two folds)
+  // lane (in-kernel fold: requested a few per low-fold step behind the high fragments -- their issue costs the CU's address unit
+  // 16 cycles each: 1.6 k cycles per CU that would otherwise sit between the two folds)
   const f32x4* t1p = reinterpret_cast<const f32x4*>(p.rope_t1 + ((int64_t)(p.tab_tile0 + (ntile > 0 ? tile0 : 0)) * 2 + hi) * 32);
   const f32x4* t2n = reinterpret_cast<const f32x4*>(p.rope_t2 + (n * 2 + hi) * 32);
   const f32x4* t2m = reinterpret_cast<const f32x4*>(p.rope_t2 + ((32 - n) * 2 + hi) * 32);
@@ -219,90 +193,180 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
     else if constexpr (i < 24) vts[i - 16] = t2s[i - 16];
     else if constexpr (i == 24) vtm = t2m[7];      // pairs q = 14, 15
   };
-  constexpr int TPS = (25 + FPW - 1) / FPW;        // table loads per fold step
-  // ---- the two folds in ONE loop: step t requests high fragment t and its share of the table loads, folds low fragment t
-  //      (a register holds (B[r,i], B[r,i+64]) -> (P[r,i], Q[r,i]); v_dot2_f32_f16: exact products, one rounding) and high
-  //      fragment t - FD, which was requested FD steps earlier -- the loop is bound by what the CU takes in, and the high fold's
-  //      VALU work fills the waits of the low one.  High fold (abx_rope_kernel FOLD): row (pair, u, head) of an M-block:
-  //      P = q_i B_i + q_{i+64} B_{i+64} (u = 0), Q = q_{i+64} B_i - q_i B_{i+64} (u = 1); the (d, d + 64) partner row sits in
-  //      lane ^ 2.  The query stays readable throughout (ring slot 0; the folded high fragments go to slot 1 + the W region).
-  {
-    const int qd = lane >> 4;
-    const int u = (lane >> 1) & 1;
-    auto fold_low = [&](auto t_c) {
-      constexpr int t = decltype(t_c)::value;
-      const int f = w * FPW + t;
-      const int h4 = (f >> 1) & 3, cs2 = t & 1;
-      const u32x4 qq = *(const lds_u32x4*)(uintptr_t)(lds0 + (unsigned)(M::OFF_Q + (h4 * 64 + ABX2_I0 + 16 * cs2 + 4 * qd) * 4));
-      u32x4 own = lraw[t];
-      unsigned da[8], db[8];
+  h16x8 bf[8][NKS];                                // the folded high fragments: AGPRs, MFMA-only operands from the prologue's end on
+  h16x8 xf[NKS];                                   // the X fragments of the current block
+
+  if constexpr (!PREFOLD) {
+    // ---- this wave's share of the fragments first (the bulk: nothing waits for them for a while): high f = mb NKS + j
+    //      (memory order [mb][j]), low f = rb 8 + h 2 + cs
+    const u32x4* bh_base = p.bfrag2 + ((int64_t)g * 8 * NKS + w * FPW) * 64 + lane;
+    const u32x4* bl_base = p.bfrag2 + (int64_t)p.G * 8 * NKS * 64 + ((int64_t)g * NKS * 8 + w * FPW) * 64 + lane;
+    // (a CU takes ~25 B per clock of these: a wave sits ~200 cycles on every load it issues once the queue is full.  The low
+    //  fragments are requested here; the high ones one per low-fold step below, so that the fold runs while the requests drain
+    //  instead of behind all 32 of them)
+    u32x4 hraw[FPW], lraw[FPW];
 #pragma unroll
-      for (int e4 = 0; e4 < 4; ++e4) {
-        // (element -> scalar -> bit_cast: hipcc 7.2 folds __builtin_bit_cast(h16x2, vec[e4]) to element 0 for every e4)
-        const unsigned qe = qq[e4], oe = own[e4];
-        const h16x2 cp = __builtin_bit_cast(h16x2, qe);                 // (q_i, q_{i+64})
-        h16x2 cq;
-        cq[0] = cp[1];
-        cq[1] = -cp[0];                                                  // (q_{i+64}, -q_i)
-        da[2 * e4] = da[2 * e4 + 1] = oe;
-        db[2 * e4] = qe;
-        db[2 * e4 + 1] = __builtin_bit_cast(unsigned, cq);
-      }
-      float dr[8];
-      abx2_dot2x8(dr, da, db);
-      u32x4 res;
+    for (int t = 0; t < FPW; ++t) lraw[t] = bl_base[(int64_t)t * 64];
+
+    stamp();  // 1
+
+    // the query to LDS as (q_i, q_{i+64}) pairs
 #pragma unroll
-      for (int e4 = 0; e4 < 4; ++e4) {
-        h16x2 r2;
-        r2[0] = (h16)dr[2 * e4];
-        r2[1] = (h16)dr[2 * e4 + 1];
-        res[e4] = __builtin_bit_cast(unsigned, r2);
-      }
-      *(lds_u32x4*)(uintptr_t)(lds0 + (unsigned)(M::OFF_LOWF + (f * 64 + lane) * 16)) = res;
-    };
-    auto fold_high = [&](auto t_c) {
-      constexpr int t = decltype(t_c)::value;
-      constexpr int s = t / NKS, j = t % NKS;
-      const int mb = 2 * w + s;
-      const int ks = (j + (mb >= 4 ? NKS / 2 : 0)) % NKS;              // (abx2_prepare_b_kernel: waves 4-7 store half a turn ahead)
-      const h16x2 q2 = __builtin_bit_cast(h16x2, s ? qp1 : qp0);
-      h16x2 coef;
-      coef[0] = u ? -q2[0] : q2[0];
-      coef[1] = q2[1];
-      u32x4 own = hraw[t];
-      unsigned da[8], db[8];
+    for (int e = 0; e < 2; ++e) {
+      const int idx = tid + ABX3_THREADS * e;
+      const int hh = idx >> 7, d = idx & 127;
+      *(lds_h16*)(uintptr_t)(lds0 + (unsigned)(M::OFF_Q + ((hh * 64 + (d & 63)) * 2 + (d >> 6)) * 2)) = qv[e];
+    }
+
+    stamp();  // 2
+
+    __syncthreads();                                 // #1: the query is in LDS
+    asm volatile("" : "+v"(cf0[0]), "+v"(cf0[1]));   // (hipcc's wait for these loads goes here, where nothing else is in flight)
+
+    // ---- (q_i, q_{i+64}) of this lane's rows in the two high M-blocks it folds
+    unsigned qp0, qp1;                               // (two scalars, not an array: the fold below picks one by a run-time bit)
+    {
+      const int m = lane & 31;
+      const int hh = 2 * ((m >> 3) & 1) + (m & 1);
+      const int i0 = 4 * (2 * w) + 2 * (m >> 4) + ((m >> 2) & 1);
+      qp0 = *(const lds_u32*)(uintptr_t)(lds0 + (unsigned)(M::OFF_Q + (hh * 64 + i0) * 4));
+      qp1 = *(const lds_u32*)(uintptr_t)(lds0 + (unsigned)(M::OFF_Q + (hh * 64 + i0 + 4) * 4));
+    }
+    constexpr int TPS = (25 + FPW - 1) / FPW;        // table loads per fold step
+    // ---- the two folds in ONE loop: step t requests high fragment t and its share of the table loads, folds low fragment t
+    //      (a register holds (B[r,i], B[r,i+64]) -> (P[r,i], Q[r,i]); v_dot2_f32_f16: exact products, one rounding) and high
+    //      fragment t - FD, which was requested FD steps earlier -- the loop is bound by what the CU takes in, and the high fold's
+    //      VALU work fills the waits of the low one.  High fold (abx_rope_kernel FOLD): row (pair, u, head) of an M-block:
+    //      P = q_i B_i + q_{i+64} B_{i+64} (u = 0), Q = q_{i+64} B_i - q_i B_{i+64} (u = 1); the (d, d + 64) partner row sits in
+    //      lane ^ 2.  The query stays readable throughout (ring slot 0; the folded high fragments go to slot 1 + the W region).
+    //      (abx_fold.h does the same arithmetic once per launch: the PREFOLD form of this kernel.)
+    {
+      const int qd = lane >> 4;
+      const int u = (lane >> 1) & 1;
+      auto fold_low = [&](auto t_c) {
+        constexpr int t = decltype(t_c)::value;
+        const int f = w * FPW + t;
+        const int h4 = (f >> 1) & 3, cs2 = t & 1;
+        const u32x4 qq = *(const lds_u32x4*)(uintptr_t)(lds0 + (unsigned)(M::OFF_Q + (h4 * 64 + ABX2_I0 + 16 * cs2 + 4 * qd) * 4));
+        u32x4 own = lraw[t];
+        unsigned da[8], db[8];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const unsigned ow = own[e];
-        const unsigned par = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ow, 0x4E, 0xF, 0xF, false);   // lane ^ 2
-        da[2 * e] = __builtin_amdgcn_perm(par, ow, 0x05040100u);
-        da[2 * e + 1] = __builtin_amdgcn_perm(par, ow, 0x07060302u);
-        db[2 * e] = db[2 * e + 1] = __builtin_bit_cast(unsigned, coef);
-      }
-      float dr[8];
-      abx2_dot2x8(dr, da, db);
-      u32x4 res;
+        for (int e4 = 0; e4 < 4; ++e4) {
+          // (element -> scalar -> bit_cast: hipcc 7.2 folds __builtin_bit_cast(h16x2, vec[e4]) to element 0 for every e4)
+          const unsigned qe = qq[e4], oe = own[e4];
+          const h16x2 cp = __builtin_bit_cast(h16x2, qe);                 // (q_i, q_{i+64})
+          h16x2 cq;
+          cq[0] = cp[1];
+          cq[1] = -cp[0];                                                  // (q_{i+64}, -q_i)
+          da[2 * e4] = da[2 * e4 + 1] = oe;
+          db[2 * e4] = qe;
+          db[2 * e4 + 1] = __builtin_bit_cast(unsigned, cq);
+        }
+        float dr[8];
+        abx2_dot2x8(dr, da, db);
+        u32x4 res;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        h16x2 r2;
-        r2[0] = (h16)dr[2 * e];
-        r2[1] = (h16)dr[2 * e + 1];
-        res[e] = __builtin_bit_cast(unsigned, r2);
-      }
-      *(lds_u32x4*)(uintptr_t)(lds0 + (unsigned)(M::OFF_HIF + ((mb * NKS + ks) * 64 + lane) * 16)) = res;
-    };
-    constexpr int FD = FPW / 2;                    // the high fold runs this many steps behind its loads
-    abx3_for<0, FPW + FD>([&](auto t_c) {
-      constexpr int t = decltype(t_c)::value;
-      if constexpr (t < FPW) {
-        hraw[t] = bh_base[(int64_t)t * 64];
-        abx3_for<0, TPS>([&](auto j_c) { tload(std::integral_constant<int, t * TPS + decltype(j_c)::value>{}); });
+        for (int e4 = 0; e4 < 4; ++e4) {
+          h16x2 r2;
+          r2[0] = (h16)dr[2 * e4];
+          r2[1] = (h16)dr[2 * e4 + 1];
+          res[e4] = __builtin_bit_cast(unsigned, r2);
+        }
+        *(lds_u32x4*)(uintptr_t)(lds0 + (unsigned)(M::OFF_LOWF + (f * 64 + lane) * 16)) = res;
+      };
+      auto fold_high = [&](auto t_c) {
+        constexpr int t = decltype(t_c)::value;
+        constexpr int s = t / NKS, j = t % NKS;
+        const int mb = 2 * w + s;
+        const int ks = (j + (mb >= 4 ? NKS / 2 : 0)) % NKS;              // (abx2_prepare_b_kernel: waves 4-7 store half a turn ahead)
+        const h16x2 q2 = __builtin_bit_cast(h16x2, s ? qp1 : qp0);
+        h16x2 coef;
+        coef[0] = u ? -q2[0] : q2[0];
+        coef[1] = q2[1];
+        u32x4 own = hraw[t];
+        unsigned da[8], db[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const unsigned ow = own[e];
+          const unsigned par = (unsigned)__builtin_amdgcn_update_dpp(0, (int)ow, 0x4E, 0xF, 0xF, false);   // lane ^ 2
+          da[2 * e] = __builtin_amdgcn_perm(par, ow, 0x05040100u);
+          da[2 * e + 1] = __builtin_amdgcn_perm(par, ow, 0x07060302u);
+          db[2 * e] = db[2 * e + 1] = __builtin_bit_cast(unsigned, coef);
+        }
+        float dr[8];
+        abx2_dot2x8(dr, da, db);
+        u32x4 res;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          h16x2 r2;
+          r2[0] = (h16)dr[2 * e];
+          r2[1] = (h16)dr[2 * e + 1];
+          res[e] = __builtin_bit_cast(unsigned, r2);
+        }
+        *(lds_u32x4*)(uintptr_t)(lds0 + (unsigned)(M::OFF_HIF + ((mb * NKS + ks) * 64 + lane) * 16)) = res;
+      };
+      constexpr int FD = FPW / 2;                    // the high fold runs this many steps behind its loads
+      abx3_for<0, FPW + FD>([&](auto t_c) {
+        constexpr int t = decltype(t_c)::value;
+        if constexpr (t < FPW) {
+          hraw[t] = bh_base[(int64_t)t * 64];
+          abx3_for<0, TPS>([&](auto j_c) { tload(std::integral_constant<int, t * TPS + decltype(j_c)::value>{}); });
+          __builtin_amdgcn_sched_barrier(0);
+          fold_low(t_c);
+        }
+        if constexpr (t >= FD) fold_high(std::integral_constant<int, t - FD>{});
         __builtin_amdgcn_sched_barrier(0);
-        fold_low(t_c);
+      });
+    }
+  } else {
+    // ---- PREFOLD: tables, then this wave's quarter of the folded LOW fragments (LDS-DMA, 1 KB per instruction: fragment f of
+    //      the group's buffer lands at OFF_LOWF + f KB as it lies in memory)
+    abx3_for<0, 25>([&](auto i_c) { tload(i_c); });
+    u32x4 qrs;
+    {
+      const unsigned long long qb = reinterpret_cast<unsigned long long>(p.qfold + (int64_t)g * 16 * NKS * 64);
+      qrs[0] = __builtin_amdgcn_readfirstlane((unsigned)qb);
+      qrs[1] = __builtin_amdgcn_readfirstlane((unsigned)(qb >> 32));
+      qrs[2] = 16 * NKS * 1024;
+      qrs[3] = 0x00020000u;
+    }
+    const unsigned lane16 = (unsigned)(lane * 16);
+    auto dma_frag = [&](int src_kb, int dst_off) {
+      const unsigned soff = __builtin_amdgcn_readfirstlane((unsigned)(src_kb * 1024));
+      const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)dst_off);
+      asm volatile(
+          "s_mov_b32 m0, %0\n\t"
+          "s_nop 0\n\t"
+          "buffer_load_dwordx4 %1, %2, %3 offen lds"
+          :
+          : "s"(dst), "v"(lane16), "s"(qrs), "s"(soff)
+          : "memory");   // (m0 cannot be listed: hipcc treats it as reserved and warns that the clobber is ignored; it never keeps a value in m0 on gfx950)
+    };
+#pragma unroll
+    for (int t = 0; t < FPW; ++t) dma_frag(8 * NKS + w * FPW + t, M::OFF_LOWF + (w * FPW + t) * 1024);
+    stamp();  // 1
+    // everything requested so far has landed (tables, coefficients, this wave's low fragments) ...
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" : "+v"(cf0[0]), "+v"(cf0[1]));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(vt1[i]), "+v"(vt2[i]), "+v"(vts[i]));
+    asm volatile("" : "+v"(vtm));
+    stamp();  // 2
+    // ... and the folded HIGH fragments follow, into the space of the two ring slots ([mb][ks][lane] as in memory), with the
+    // first block's latents behind them -- straight into registers (this lane's B-operand chunks: row n of the block, columns
+    // 16 ks + 8 hi; rows past the cache read its last row: their scores are never stored), the ring is not free yet
+#pragma unroll
+    for (int t = 0; t < FPW; ++t) dma_frag(w * FPW + t, M::OFF_X0 + (w * FPW + t) * 1024);
+    {
+      const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(xg), 0, (int)xrs[2], 0x00020000);
+      const unsigned vo = (unsigned)min(row00 + n, p.L - 1) * row_bytes + (unsigned)(hi * 16);
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(xr, (int)(vo + (unsigned)(ks * 32)), 0, 0);
+        xf[ks] = __builtin_bit_cast(h16x8, v);
       }
-      if constexpr (t >= FD) fold_high(std::integral_constant<int, t - FD>{});
-      __builtin_amdgcn_sched_barrier(0);
-    });
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
   // ---- RoPE state of this lane: (cs, sn)[q] = cos, sin of the exact angle of position n of the wave's first block -- one
   //      complex product per pair; M-block 7's pairs start one block early; (rc, rs) = the step of 32 positions
@@ -324,35 +388,6 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
     }
   }
   stamp();  // 3
-  stamp();  // 4
-  __syncthreads();                                 // #2: all folded fragments are in LDS, nobody reads the query any more
-
-  // the first block's latents LAST: a wave's loads return in issue order, and these come from HBM while 256 workgroups ask
-  // for theirs at once -- in front of the fragment loads they held every fold back by their latency (and ring slot 0 held the
-  // query until here); nothing reads the block before the main loop (>= 5 k cycles from here)
-  if (nblk > 0) {
-#pragma unroll
-    for (int k = 0; k < NKS; ++k) dma_piece(0, 0, k);
-  }
-
-  // ---- every wave takes ALL high fragments: 8 NKS AGPR quads, MFMA-only operands from here on
-  h16x8 bf[8][NKS];
-  {
-    const unsigned hsrc = lds0 + (unsigned)(M::OFF_HIF + lane * 16);
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb)
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks)             // (LDS -> AGPR directly; the asm order keeps the wait below behind the loads)
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(bf[mb][ks]) : "v"(hsrc), "n"((mb * NKS + ks) * 1024));
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
-  stamp();  // 5
-  __syncthreads();                                 // #3: ring slot 1 and the W images are free
-
-  if (nblk <= 0) return;                           // (no barrier below this line)
-
-#pragma unroll
-  for (int k = 0; k < NKS; ++k) dma_piece(1, 1, k);
 
   // ---- LDS addresses of this lane
   // X fragment of k-step ks: row n, 16-byte chunk swz(n, 2 ks + hi) (slot 0; slot 1 = + 4 BLK).  The chunk index is
@@ -375,7 +410,7 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
   //      r-block rb's fragments are requested one r-block ahead, its results are converted and stored behind the MFMAs of
   //      r-block rb + 1 (a full burst after their own: the asm-MFMA rule of this file), the four first halves of an r-block
   //      before the four second halves (no dependent pair back to back)
-  {
+  auto build_first_w = [&]() {
     h16x8 lfa[8];
     f32x4 waA[4], waB[4];
     auto load8 = [&](h16x8 (&lf)[8], int rb) {
@@ -409,6 +444,54 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
     });
     asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // the last burst's results (no MFMAs follow to cover them)
     store4(((NKS - 1) & 1) ? waB : waA, NKS - 1);
+  };
+  // every wave takes ALL high fragments from LDS: 8 NKS AGPR quads, MFMA-only operands from here on
+  auto take_high = [&](int off) {
+    const unsigned hsrc = lds0 + (unsigned)(off + lane * 16);
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks)             // (LDS -> AGPR directly; the asm order keeps the wait below behind the loads)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(bf[mb][ks]) : "v"(hsrc), "n"((mb * NKS + ks) * 1024));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+
+  if constexpr (!PREFOLD) {
+    stamp();  // 4
+    __syncthreads();                                 // #2: all folded fragments are in LDS, nobody reads the query any more
+
+    // the first block's latents LAST: a wave's loads return in issue order, and these come from HBM while 256 workgroups ask
+    // for theirs at once -- in front of the fragment loads they held every fold back by their latency (and ring slot 0 held the
+    // query until here); nothing reads the block before the main loop (>= 5 k cycles from here)
+    if (nblk > 0) {
+#pragma unroll
+      for (int k = 0; k < NKS; ++k) dma_piece(0, 0, k);
+    }
+    take_high(M::OFF_HIF);
+    stamp();  // 5
+    __syncthreads();                                 // #3: ring slot 1 and the W images are free
+
+    if (nblk <= 0) return;                           // (no barrier below this line)
+
+#pragma unroll
+    for (int k = 0; k < NKS; ++k) dma_piece(1, 1, k);
+    build_first_w();
+  } else {
+    __syncthreads();                                 // A: every wave's low fragments are in LDS
+    stamp();  // 4
+    build_first_w();                                 // (the high fragments land meanwhile)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(xf[ks]));
+    __syncthreads();                                 // B: every wave's high fragments are in LDS
+    take_high(M::OFF_X0);
+    stamp();  // 5
+    __syncthreads();                                 // C: the ring is free
+
+    if (nblk <= 0) return;                           // (no barrier below this line)
+
+#pragma unroll
+    for (int k = 0; k < NKS; ++k) dma_piece(1, 1, k);
   }
   stamp();  // 6
 
@@ -418,7 +501,7 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
   const unsigned ohead2 = (unsigned)(2 * p.so_h * 2);
 
   // ---- main-loop state
-  h16x8 xf[NKS], wfr[WD];
+  h16x8 wfr[WD];
   // two accumulator sets: phase k of block B (k = 0: the low band's stage 2, k = 1..8: high M-blocks 0..7) accumulates into
   // set (9 B + k) & 1 while the epilogue of the phase before reads the other one (36 phases per tile: the roles repeat)
   f32x16 accA, accB;
@@ -581,8 +664,16 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
           // range (clamped to its last block, which may be partly out of range), and such a re-read was seen retiring ahead of
           // the block's own, older request on cold launches -- rows of the wave's last block stale in 18 of 240 launches
           // (tools/stress_tail_cold.py).  (A compile-time choice: a run-time branch here makes hipcc spill around the asm MFMAs.)
-          if (LAST) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          // ... and so is the wait of a tile's LAST block (B = 3) in every tile: when the wave's next (= last) tile is a one-block
+          // tail, the pieces this block requested are already such re-reads (L % 128 in 1..32); the block carries
+          // stage 1, twice the time of the others lies between its requests and this wait -- it costs nothing (profiles/
+          // r06_abx_wait0.txt, which also times vmcnt(0) in EVERY block: -DABX3_WAIT0)
+#ifdef ABX3_WAIT0
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+          if (LAST || B == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NKS) : "memory");
+#endif
           if (B == 2) asm volatile("" : "+v"(cfr[0]), "+v"(cfr[1]));
         }
         constexpr bool BURST = S1 && mb % PSTEP == 0;  // this phase opens with the stage-1 burst of r-block mb / PSTEP
@@ -653,11 +744,15 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
     });
   };
 
-  // ---- first block: its fragments
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (both: block 1's request may be a re-read of block 0, see the blocks' own waits)
-  stamp();  // 7
+  // ---- first block: its fragments (PREFOLD: they came straight from memory in the prologue)
+  if constexpr (!PREFOLD) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (both: block 1's request may be a re-read of block 0, see the blocks' own waits)
+    stamp();  // 7
 #pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) xf[ks] = read_x(ks, 0);
+    for (int ks = 0; ks < NKS; ++ks) xf[ks] = read_x(ks, 0);
+  } else {
+    stamp();  // 7
+  }
 #pragma unroll
   for (int i = 0; i < WD; ++i) wfr[i] = read_w(i);
 
@@ -671,6 +766,11 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
     block(ABX3_IC(2), std::false_type{}, std::false_type{}, b + 2, tt + 1);
     block(ABX3_IC(3), std::true_type{}, std::false_type{}, b + 3, tt + 1);
     b += 4;
+  }
+  if constexpr (PREFOLD) {
+    // the peeled tile reads the lane's row index n directly (the loop's uses are strength-reduced away); kept live across the loop
+    // it was the one value of the R = 128 kernel hipcc sent to scratch (256 VGPRs + 256 AGPRs): derive it again from the lane id
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_and_b32 %0, 31, %0" : "=v"(n));
   }
   do {
     block(ABX3_IC(0), std::false_type{}, std::true_type{}, b, tt);

@@ -29,7 +29,7 @@
 
 #include <type_traits>
 
-#include "palu_common.h"
+#include "abx_fold.h"
 
 // two-band score kernel (abx_rope2.hip): launches it when the shape, the positions and a registered coefficient table
 // allow (gs = 4, R in {32, 64, 128}, pos0 % 128 == 0, pos0 + L <= 2^18, low-band angles below 2048 rad); returns
@@ -42,6 +42,9 @@ int palu_abx2_prepare_b(const void* b, int64_t sb_h, int64_t sb_r, int64_t sb_d,
 // position-split form of the two-band kernel (abx_rope3.hip, abx_rope3_kernel.h): fp16 latents, one launch (no column
 // windows); `params` as for palu_abx2_try_launch with the coefficient table filled in, nks = R / 16
 int palu_abx3_launch(const void* params, int nks, hipStream_t stream);
+// the query fold as its own launch (abx_fold.h): a [H, D] + the two-band fragments of B -> qfold [G][16 nks KB]
+int palu_abx3_fold_launch(const void* a, int64_t sa_h, int64_t sa_d, const void* bfrag2, void* qfold, int H, int G, int nks,
+                          hipStream_t stream);
 
 namespace {
 
@@ -89,6 +92,9 @@ struct AbxParams {
   // table (abx2_rope_start_kernel): rope_t1 [tile][hi 2][q 16] (cos, sin)(128 tile f_i), rope_t2 [n 0..32][hi][q] (cos, sin)(n f_i)
   const float* rope_t1;
   const float* rope_t2;
+  // the same kernel on PRE-FOLDED fragments (abx_fold.h; palu_abx_fold_f16 / palu_decode_qkv_fold_f16 wrote them earlier on the
+  // stream): [G][16 NKS KB]; null = the kernel folds `a` into bfrag2 in its own prologue
+  const u32x4* qfold;
 };
 
 // heads per workgroup = 2*NMB; each MFMA M-block carries 2 heads x 8 pairs x {i, i+64}

@@ -9,7 +9,7 @@
 namespace {
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 struct StepWs {
-  size_t q, scores, ctx, pv, knew, vnew, acc, total;
+  size_t q, scores, ctx, pv, knew, vnew, acc, qfold, total;
 };
 StepWs step_layout(int H, int G, int D, int Lcap, int Rv) {
   StepWs w;
@@ -20,11 +20,20 @@ StepWs step_layout(int H, int G, int D, int Lcap, int Rv) {
   w.pv = o;     o += align256(palu_pv_workspace_bytes(H, G, Lcap, Rv));
   w.knew = o;   o += align256((size_t)4096 * 2);   // new latent rows before quantisation (G*Rk <= 4096)
   w.vnew = o;   o += align256((size_t)16384 * 2);
-  w.acc = o;    o += align256((size_t)H * (((size_t)Lcap + 8 + 7) & ~(size_t)7) * 4);   // fp32 scores of a multi-pass rank (> 128)
+  const size_t acc_b = (size_t)H * (((size_t)Lcap + 8 + 7) & ~(size_t)7) * 4;            // fp32 scores of a multi-pass rank (> 128) ...
+  w.acc = o;    o += align256(acc_b > (size_t)H * 32 * 128 ? acc_b : (size_t)H * 32 * 128);  // ... and never less than palu_abx_scratch_bytes of a rank <= 128
+  w.qfold = o;  o += align256((size_t)H * 32 * 128);   // folded fragments of the position-split score kernel (palu_abx_fold_bytes: 4 KB per head and 16 columns, R <= 128)
   w.total = o;
   return w;
 }
 }  // namespace
+
+// The step's score launch takes the position-split kernel on fragments the projection kernel folds in its tail
+// (palu_decode_qkv_fold_f16 -> palu_abx_rope_pf_f16) whenever palu_abx_rope_ws_f16 would select that kernel anyway.
+static bool step_prefold(int H, int G, int L, int Rk, int D, const float* inv_freq) {
+  return D == 128 && palu_abx_fold_bytes(H, G, Rk) != 0 && palu_abx_set_fold(-1) != 0 &&
+         palu_abx_position_split_selected(inv_freq, H, G, L, Rk, 0) != 0;
+}
 
 extern "C" size_t palu_decode_workspace_bytes(int H, int G, int D, int Lcap, int Rv) {
   if (H <= 0 || G <= 0 || D <= 0 || Lcap <= 0 || Rv <= 0) return 0;
@@ -47,16 +56,20 @@ static int decode_step_impl(bool shared_b, const void* hidden, const void* wq, i
   void* pvws = ws + w.pv;
   const int L = cache_len + 1;
   const int64_t ss_h = ((int64_t)Lcap + 8) & ~(int64_t)7;
-  int rc = palu_decode_qkv_f16(wq, ldq, vtk, ldk, vtv, ldv, hidden, q, k_cache, sk_g, sk_l, v_cache, sv_g, sv_l,
-                               inv_freq, H, D, hidden_size, G, Rk, Rv, pos, cache_len, stream);
+  const bool fused = !shared_b && !probs && palu_decode_attn_preferred(H, G, L, Rk, Rv, D);
+  const bool prefold = !shared_b && !fused && step_prefold(H, G, L, Rk, D, inv_freq);
+  int rc = palu_decode_qkv_fold_f16(wq, ldq, nullptr, vtk, ldk, vtv, ldv, hidden, q, k_cache, sk_g, sk_l, v_cache, sv_g, sv_l,
+                                    inv_freq, H, D, hidden_size, G, Rk, Rv, pos, cache_len, prefold ? bfrag : nullptr,
+                                    prefold ? ws + w.qfold : nullptr, stream);
   if (rc) return rc;
-  if (!shared_b && !probs && palu_decode_attn_preferred(H, G, L, Rk, Rv, D)) {
+  if (fused) {
     rc = palu_decode_attn_mask_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, v_cache, sv_g, sv_l, mask, ctx, pvws, H, G, L, Rk,
                                    Rv, D, inv_freq, 0, sqrtf((float)D), stream);
   } else {
     rc = shared_b ? palu_abx_rope_shared_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, scores, ss_h, H, G, L, Rk, D, inv_freq, 0, stream)
-                  : palu_abx_rope_ws_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, scores, ss_h, H, G, L, Rk, D, inv_freq, 0,
-                                         ws + w.acc, stream);
+         : prefold ? palu_abx_rope_pf_f16(ws + w.qfold, k_cache, sk_g, sk_l, scores, ss_h, H, G, L, Rk, D, inv_freq, 0, stream)
+                   : palu_abx_rope_ws_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, scores, ss_h, H, G, L, Rk, D, inv_freq, 0,
+                                          ws + w.acc, stream);
     if (rc) return rc;
     rc = palu_softmax_pv_f16(scores, ss_h, mask, v_cache, sv_g, sv_l, ctx, probs, sp_h, pvws, H, G, L, Rv,
                              sqrtf((float)D), stream);
@@ -105,13 +118,17 @@ extern "C" int palu_decode_attend_f16(const void* hidden, const void* wq, int64_
   void* pvws = ws + w.pv;
   const int L = cache_len + 1;
   const int64_t ss_h = ((int64_t)Lcap + 8) & ~(int64_t)7;
-  int rc = palu_decode_qkv_f16(wq, ldq, vtk, ldk, vtv, ldv, hidden, q, k_cache, sk_g, sk_l, v_cache, sv_g, sv_l,
-                               inv_freq, H, D, hidden_size, G, Rk, Rv, pos, cache_len, stream);
+  const bool fused = palu_decode_attn_preferred(H, G, L, Rk, Rv, D) != 0;
+  const bool prefold = !fused && step_prefold(H, G, L, Rk, D, inv_freq);
+  int rc = palu_decode_qkv_fold_f16(wq, ldq, nullptr, vtk, ldk, vtv, ldv, hidden, q, k_cache, sk_g, sk_l, v_cache, sv_g, sv_l,
+                                    inv_freq, H, D, hidden_size, G, Rk, Rv, pos, cache_len, prefold ? bfrag : nullptr,
+                                    prefold ? ws + w.qfold : nullptr, stream);
   if (rc) return rc;
-  if (palu_decode_attn_preferred(H, G, L, Rk, Rv, D))
+  if (fused)
     return palu_decode_attn_mask_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, v_cache, sv_g, sv_l, mask, ctx, pvws, H, G, L, Rk,
                                      Rv, D, inv_freq, 0, sqrtf((float)D), stream);
-  rc = palu_abx_rope_ws_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, scores, ss_h, H, G, L, Rk, D, inv_freq, 0, ws + w.acc, stream);
+  rc = prefold ? palu_abx_rope_pf_f16(ws + w.qfold, k_cache, sk_g, sk_l, scores, ss_h, H, G, L, Rk, D, inv_freq, 0, stream)
+               : palu_abx_rope_ws_f16(q, D, 1, bfrag, k_cache, sk_g, sk_l, scores, ss_h, H, G, L, Rk, D, inv_freq, 0, ws + w.acc, stream);
   if (rc) return rc;
   return palu_softmax_pv_f16(scores, ss_h, mask, v_cache, sv_g, sv_l, ctx, nullptr, 0, pvws, H, G, L, Rv,
                              sqrtf((float)D), stream);

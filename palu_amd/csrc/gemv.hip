@@ -9,7 +9,7 @@
 // is shared between waves), x lives in LDS, products use v_dot2_f32_f16 with fp32 accumulation,
 // one wave-level shuffle reduction per row pair.  For q the two rows of a wave are (i, i+64) of one
 // head so that the rotation is applied in registers before the single fp16 rounding.
-#include "palu_common.h"
+#include "abx_fold.h"
 
 namespace {
 
@@ -148,6 +148,11 @@ struct QkvParams {
   int H, D, K, rank_k, rank_v, Rk, Rv;
   int pos, row;
   const h16* q_bias;          // optional [H*D]: q_proj.bias, added before the rotation
+  // optional tail of the q waves (abx_fold.h): fold the rotated (q_i, q_{i+64}) into the two-band fragments of B for the
+  // position-split score kernel that follows in the step (H = 4 G, D = 128, Rk = 16 fold_nks)
+  const u32x4* fold_b;        // two-band fragments of B (palu_abx_prepare_b's second part)
+  u32x4* qfold;               // folded fragments out, [G][16 fold_nks KB]; null = no fold
+  int fold_nks;
 };
 
 // cos/sin of the oracle's fp32-rounded angle fl32(pos * f)  (kernel/pytorch_reference.py:5-6)
@@ -181,18 +186,24 @@ __global__ __launch_bounds__(GV_THREADS) void decode_qkv_kernel(QkvParams p) {
   if (pair < nq) {
     const int h = pair / half, i = pair - h * half;
     const h16* r0 = p.wq + (int64_t)(h * p.D + i) * p.ldq;
+    // (the 512 B of B fragments this pair folds are requested in front of the weight stream: their L2 / HBM latency is
+    //  gone by the time the dot products are reduced)
+    AbxFoldSrc fsrc;
+    if (p.qfold) fsrc = abx_fold_load(p.fold_b, p.H / 4, p.fold_nks, h >> 2, h & 3, i, lane);
     row_pair_dot(r0, r0 + (int64_t)half * p.ldq, xs, p.K, lane, &y0, &y1);
-    if (lane == 0) {
-      float c, s;
-      if (p.q_bias) {
-        // HF adds the bias inside the fp16 linear (one rounding of W x + b) and rotates the fp16 result
-        y0 += (float)p.q_bias[h * p.D + i];
-        y1 += (float)p.q_bias[h * p.D + i + half];
-      }
-      rope_cs(p.pos, p.inv_freq[i], &c, &s);
-      p.q_out[h * p.D + i] = (h16)(y0 * c - y1 * s);
-      p.q_out[h * p.D + i + half] = (h16)(y1 * c + y0 * s);
+    float c, s;
+    if (p.q_bias) {
+      // HF adds the bias inside the fp16 linear (one rounding of W x + b) and rotates the fp16 result
+      y0 += (float)p.q_bias[h * p.D + i];
+      y1 += (float)p.q_bias[h * p.D + i + half];
     }
+    rope_cs(p.pos, p.inv_freq[i], &c, &s);
+    const h16 qa = (h16)(y0 * c - y1 * s), qb = (h16)(y1 * c + y0 * s);     // (every lane: wave_sum leaves the sums in all of them)
+    if (lane == 0) {
+      p.q_out[h * p.D + i] = qa;
+      p.q_out[h * p.D + i + half] = qb;
+    }
+    if (p.qfold) abx_fold_store(fsrc, p.qfold, p.fold_nks, h >> 2, h & 3, i, qa, qb, lane);
   } else if (pair < nq + nk) {
     const int n0 = 2 * (pair - nq);
     const h16* r0 = p.vtk + (int64_t)n0 * p.ldk;
@@ -289,6 +300,27 @@ extern "C" int palu_decode_qkv_bias_f16(const void* wq, int64_t ldq, const void*
                                         int64_t sk_g, int64_t sk_l, void* v_cache, int64_t sv_g, int64_t sv_l,
                                         const float* inv_freq, int H, int D, int hidden, int G, int Rk, int Rv, int pos,
                                         int row, palu_stream_t stream) {
+  return palu_decode_qkv_fold_f16(wq, ldq, q_bias, vtk, ldk, vtv, ldv, x, q_out, k_cache, sk_g, sk_l, v_cache, sv_g, sv_l,
+                                  inv_freq, H, D, hidden, G, Rk, Rv, pos, row, nullptr, nullptr, stream);
+}
+
+// The same launch with the query fold of the position-split score kernel in the tail of its q waves (abx_fold.h): `bfrag`
+// = palu_abx_prepare_b's fragments of B, `qfold` = palu_abx_fold_bytes(H, G, Rk) bytes that palu_abx_rope_pf_f16 consumes
+// later in the same stream.  bfrag = qfold = null: no fold (palu_decode_qkv_bias_f16).
+extern "C" int palu_decode_qkv_fold_f16(const void* wq, int64_t ldq, const void* q_bias, const void* vtk, int64_t ldk,
+                                        const void* vtv, int64_t ldv, const void* x, void* q_out, void* k_cache,
+                                        int64_t sk_g, int64_t sk_l, void* v_cache, int64_t sv_g, int64_t sv_l,
+                                        const float* inv_freq, int H, int D, int hidden, int G, int Rk, int Rv, int pos,
+                                        int row, const void* bfrag, void* qfold, palu_stream_t stream) {
+  const void* fold_b = nullptr;
+  if (bfrag || qfold) {
+    PALU_REQUIRE(bfrag && qfold && palu_abx_fold_bytes(H, G, Rk) != 0 && D == 128, PALU_ERR_UNSUPPORTED,
+                 "decode_qkv_fold: the fold needs 4 heads per group, head_dim 128 and rank_k / G in {32, 64, 128} (H=%d G=%d D=%d Rk=%d)",
+                 H, G, D, Rk);
+    PALU_REQUIRE(((uintptr_t)qfold & 15) == 0, PALU_ERR_ARG, "decode_qkv_fold: qfold must be 16-byte aligned");
+    fold_b = palu_abx_two_band_frags(bfrag, H, G, Rk);
+    PALU_REQUIRE(fold_b, PALU_ERR_ARG, "decode_qkv_fold: no two-band fragments for this shape");
+  }
   PALU_REQUIRE(wq && vtk && vtv && x && q_out && k_cache && v_cache && inv_freq, PALU_ERR_ARG, "decode_qkv: null pointer");
   PALU_REQUIRE(H > 0 && G > 0 && D > 0 && D % 2 == 0 && Rk % 2 == 0 && Rv % 2 == 0 && hidden % 8 == 0 && pos >= 0 &&
                    row >= 0,
@@ -307,6 +339,9 @@ extern "C" int palu_decode_qkv_bias_f16(const void* wq, int64_t ldq, const void*
   p.H = H; p.D = D; p.K = hidden; p.rank_k = G * Rk; p.rank_v = G * Rv; p.Rk = Rk; p.Rv = Rv;
   p.pos = pos; p.row = row;
   p.q_bias = (const h16*)q_bias;
+  p.fold_b = (const u32x4*)fold_b;
+  p.qfold = (u32x4*)qfold;
+  p.fold_nks = Rk / 16;
   const int pairs = H * D / 2 + p.rank_k / 2 + p.rank_v / 2;
   const int blocks = (pairs + GV_THREADS / 64 - 1) / (GV_THREADS / 64);
   hipLaunchKernelGGL(decode_qkv_kernel, dim3(blocks), dim3(GV_THREADS), (size_t)hidden * 2, (hipStream_t)stream, p);

@@ -53,6 +53,9 @@ void palu_set_error(const char* fmt, ...);
 int palu_num_cus();   // cached hipDeviceProp multiProcessorCount of the current device
 int palu_func_max_lds(const void* func, int bytes);   // MaxDynamicSharedMemorySize once per (kernel, current device); PALU_OK or error
 
+// internal cross-TU helper (abx_rope.hip): the two-band fragments inside a palu_abx_prepare_b allocation (null: none for this shape)
+const void* palu_abx_two_band_frags(const void* bfrag, int H, int G, int R);
+
 // internal cross-TU helper (quant.hip): both new latent rows of a decode step in one launch
 int palu_quantize_pack_kv(const void* k, int64_t sk_g, void* k_codes, int64_t skc_g, void* k_meta, int64_t skm_g, int Rk,
                           const void* v, int64_t sv_g, void* v_codes, int64_t svc_g, void* v_meta, int64_t svm_g, int Rv,

@@ -90,6 +90,22 @@ def position_split(min_tiles: int = 0):
         _lib.lib.palu_abx_set_position_split(old)
 
 
+_fold_once_per_launch = True
+
+
+@contextlib.contextmanager
+def in_kernel_fold():
+    """Run the enclosed `abx` calls without the scratch that lets the position-split kernel take fragments folded ONCE per
+    launch (csrc/abx_fold.h): the kernel then folds the query in every workgroup's prologue, as in round 5 -- same arithmetic,
+    bit-identical scores (tests/test_fold_gpu.py), for A/B measurements."""
+    global _fold_once_per_launch
+    old, _fold_once_per_launch = _fold_once_per_launch, False
+    try:
+        yield
+    finally:
+        _fold_once_per_launch = old
+
+
 def set_fold(enable: bool) -> bool:
     """Numerics switch of the fast path (palu_abx_set_fold): True (default) folds q into the B
     fragments (one extra fp16 operand rounding, fewer VALU ops); False keeps q in fp32."""
@@ -191,8 +207,11 @@ def abx(a: torch.Tensor, b: torch.Tensor, x: torch.Tensor, *, theta: float = 100
                                                          _lib.current_stream()), "palu_abx_rope_shared_f16")
             return out
         frag = prepare_b(b, G)
-        # ranks above 128: fp32 scratch for the multi-pass form of the fast kernel (0 bytes otherwise)
+        # ranks above 128: fp32 scratch for the multi-pass form of the fast kernel; 4 heads per group at R in {32, 64, 128}: the
+        # folded fragments of the position-split kernel (16 R KB per group); 0 bytes otherwise
         nscr = _lib.lib.palu_abx_scratch_bytes(H, G, L, R)
+        if R <= 128 and not _fold_once_per_launch:
+            nscr = 0
         scratch = torch.empty(nscr, dtype=torch.uint8, device=x.device) if nscr else None
         _lib.check(_lib.lib.palu_abx_rope_ws_f16(a.data_ptr(), a.stride(0), a.stride(2), frag.data_ptr(),
                                                  x.data_ptr(), x.stride(0), x.stride(1),

@@ -35,13 +35,33 @@ def _check(got, a, b, x, ref16=None, tol=1e-3):
     return err_mine, err_oracle
 
 
+# "default": the library's own selection (at these lengths the pair-split form of the two-band kernel, or the one-band kernel for
+# the shapes it does not take); the other forms are forced onto every case they take: the position-split
+# kernel on fragments folded once per launch (round 6) and with the fold in its own prologue (round 5), the pair-split
+# kernel, the one-band kernel -- each of them against the vectors the reference itself produced
+@pytest.mark.parametrize("form", ["default", "position_split", "position_split_in_kernel_fold", "pair_split", "one_band"])
 @pytest.mark.parametrize("case", gi.ABX_CASES, ids=[c[0] for c in gi.ABX_CASES])
-def test_abx_golden(golden_dir, case):
+def test_abx_golden(golden_dir, case, form):
+    import contextlib
+    from palu_amd import _lib
+    from palu_amd.kernel import abx_rope as ar
     tag, seed, H, D, gs, R, L, regime = case
     g = np.load(os.path.join(golden_dir, "g1_abx.npz"))
     a, b, x = gi.abx_inputs(seed, H, D, gs, R, L, regime)
     assert gi.digest(a, b, x) == str(g[tag + "/digest"])
-    got = _abx()(a.cuda(), b.cuda(), x.cuda())
+    with contextlib.ExitStack() as st:
+        if form.startswith("position_split"):
+            st.enter_context(ar.position_split(0))
+            if form.endswith("in_kernel_fold"):
+                st.enter_context(ar.in_kernel_fold())
+            if gs == 4 and R in (32, 64, 128):
+                inv = ar.rope_inv_freq(torch.device("cuda:0"), D)
+                assert _lib.lib.palu_abx_position_split_selected(inv.data_ptr(), H, H // gs, L, R, 0) == 1
+        elif form == "pair_split":
+            st.enter_context(ar.pair_split())
+        elif form == "one_band":
+            st.enter_context(ar.one_band())
+        got = _abx()(a.cuda(), b.cuda(), x.cuda())
     _check(got, a, b, x, ref16=torch.from_numpy(g[tag + "/out"]))
 
 

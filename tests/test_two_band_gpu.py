@@ -365,3 +365,47 @@ def test_tail_blocks_on_cold_launches(form):
                 if not err <= 2e-3:
                     bad.append((rep, R, L, err))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("fold", ["once_per_launch", "in_kernel"])
+def test_one_block_tails_behind_full_tiles_on_cold_launches(fold):
+    """a wave that owns full tiles AND a one-block tail (L % 128 in 1..32 with L large enough that the last wave has
+    both): block 3 of its penultimate tile requested the tail block a second time (clamped re-read) and then waited with a
+    counted vmcnt for the first request -- the pattern that left stale rows in test_tail_blocks_on_cold_launches' shapes, which
+    never reach this path.  Round 6 waits for every request in each tile's last block.  Cold launches, every row against fp64."""
+    _lib, ar = _mods()
+    import contextlib
+    dev = torch.device("cuda:0")
+    inv = ar.rope_inv_freq(dev)
+    big = torch.empty(1 << 28, device=dev, dtype=torch.float16)
+
+    def ref_rows(a, b, x, lo):
+        H, R, _ = b.shape
+        G, L, _ = x.shape
+        xs = x[:, lo:]
+        keys = torch.matmul(xs[:, None].double(), b.double().reshape(G, H // G, R, D))
+        ang = torch.outer(torch.arange(lo, L, device=dev).float(), inv).double()
+        c, s = ang.cos(), ang.sin()
+        k1, k2 = keys[..., :64], keys[..., 64:]
+        rot = torch.cat((k1 * c - k2 * s, k2 * c + k1 * s), -1)
+        return torch.einsum("ghd,ghld->ghl", a.double().reshape(G, H // G, D), rot).reshape(H, L - lo)
+
+    bad = []
+    with contextlib.ExitStack() as st:
+        st.enter_context(ar.position_split(0))
+        if fold == "in_kernel":
+            st.enter_context(ar.in_kernel_fold())
+        for rep in range(6):
+            for R, L in ((32, 16400), (64, 32790), (32, 65537), (64, 65537), (128, 65537), (32, 16416)):
+                g = torch.Generator().manual_seed(77 * rep + L + R)
+                a = torch.randn(32, 1, D, generator=g).half().to(dev)
+                b = (torch.randn(32, R, D, generator=g) * R ** -0.5).half().to(dev)
+                x = torch.randn(8, L, R, generator=g).half().to(dev)
+                lo = max(0, L - 4096)                        # the last waves' rows: full tiles + the tail
+                r = ref_rows(a, b, x, lo)
+                big[: 1 << 27].copy_(big[1 << 27:])          # 512 MB through the caches: the launch below starts cold
+                y = ar.abx(a, b, x).reshape(32, L)[:, lo:].double()
+                err = float((y - r).abs().max()) / float(r.abs().max())
+                if not err <= 2e-3:
+                    bad.append((rep, R, L, err))
+    assert not bad, bad
