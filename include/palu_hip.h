@@ -90,6 +90,8 @@ int palu_abx_rope_f16(const void* a, int64_t sa_h, int64_t sa_d,
  * inv_freq[32] * (pos0 + L) < 2700 rad (the band uses the exact angle l*f; the oracle's fp32 rounding of l*f is <= 2^-13 rad
  * there, measured at 262 145 positions: error and rms at the oracle's own level) and 64 * inv_freq[32] <= 0.7 rad (the polynomial's remainder: theta >= ~8400 at head_dim 128); otherwise, or with PALU_ABX_TWO_BAND=0 in the environment, it runs the one-band kernel -- same results within
  * the oracle's own fp16 rounding.  palu_abx_two_band_selected reports the decision for a launch. */
+/* (palu_rope_table_register takes the SAME (pos_first, npos) the table was built with: the start tables of the position-split
+ * kernel follow the table's own coefficient tiles; a table built in this process is checked, a mismatch is PALU_ERR_ARG.) */
 size_t palu_rope_table_bytes(int npos);
 int palu_rope_table_build(const float* inv_freq, int pos_first, int npos, void* table, palu_stream_t stream);
 int palu_rope_table_register(const float* inv_freq, const void* table, int pos_first, int npos, float inv_freq_32);

@@ -16,6 +16,11 @@ struct RopeTable {
 };
 std::mutex g_tab_mutex;
 std::vector<RopeTable> g_tabs;
+// what palu_rope_table_build wrote where: the T1 / T2 parts of a table sit behind ITS coefficient tiles, so a table must be
+// registered with the range it was built for (a prefix or sub-range pointed the position-split kernel at the wrong
+// start tables -- silently wrong scores)
+struct BuiltTable { const void* table; int tile_first, ntiles; };
+std::vector<BuiltTable> g_built;
 
 int two_band_enabled() {     // PALU_ABX_TWO_BAND=0 keeps every launch on abx_rope_kernel (A/B measurements)
   static int v = -1;
@@ -134,6 +139,16 @@ extern "C" int palu_rope_table_build(const float* inv_freq, int pos_first, int n
   hipLaunchKernelGGL(abx2_rope_start_kernel, dim3((unsigned)((total2 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, inv_freq,
                      pos_first / TL, ntiles, t1, (float*)((char*)t1 + tab_t1_bytes(ntiles)));
   PALU_LAUNCH_CHECK();
+  {
+    std::lock_guard<std::mutex> lk(g_tab_mutex);
+    bool found = false;
+    for (auto& b : g_built)
+      if (b.table == table) { b = BuiltTable{table, pos_first / TL, ntiles}; found = true; }
+    if (!found) {
+      if (g_built.size() > 256) g_built.erase(g_built.begin());
+      g_built.push_back(BuiltTable{table, pos_first / TL, ntiles});
+    }
+  }
   return PALU_OK;
 }
 
@@ -142,6 +157,12 @@ extern "C" int palu_rope_table_register(const float* inv_freq, const void* table
                "rope_table_register: bad arguments");
   PALU_REQUIRE(inv_freq_32 > 0.f, PALU_ERR_ARG, "rope_table_register: inv_freq[32] must be positive");
   std::lock_guard<std::mutex> lk(g_tab_mutex);
+  for (const auto& b : g_built)
+    if (b.table == table)
+      PALU_REQUIRE(b.tile_first == pos_first / TL && b.ntiles == (npos + TL - 1) / TL, PALU_ERR_ARG,
+                   "rope_table_register: the table was built for positions [%d, %d) and must be registered with that range "
+                   "(got pos_first %d, npos %d): its start tables follow its own coefficient tiles",
+                   b.tile_first * TL, (b.tile_first + b.ntiles) * TL, pos_first, npos);
   for (auto& t : g_tabs)
     if (t.inv_freq == inv_freq) {
       t = RopeTable{inv_freq, (const u32x4*)table, pos_first / TL, (npos + TL - 1) / TL, inv_freq_32};

@@ -22,8 +22,8 @@
 //   * the prologue is cooperative: every wave folds the query into a quarter of the fragments, the folded fragments go
 //     through LDS once (the high ones through the space the rings use later).  Its loads are ordered for in-order return (what
 //     comes from HBM is requested last), both folds run in one loop behind their loads, dot products as asm blocks.
-//   * the wave's last tile is a peeled copy of the loop body: no stage 1 for a tile that does not exist, and every request is
-//     waited for there (the counted waits of the loop rely on younger requests that, past the wave's range, are re-reads).
+//   * the wave's last tile is a peeled copy of the loop body: no stage 1 for a tile that does not exist.  Every block waits
+//     for ALL its outstanding requests (round 6: the counted waits of round 5 relied on an ordering that clamped re-reads broke).
 // Per 32-position block and wave: 8 NKS + NKS big MFMAs (+ 8 NKS small ones per tile in the tile's last block), 256 + 16
 // VALU of rotation work, 2 NKS LDS reads; at R = 128 about 6.3 issued instructions per big MFMA -- what one wave can
 // issue in a matrix-pipe slot (tools/ubench_issue.hip).
@@ -65,15 +65,19 @@ static __device__ __forceinline__ void abx3_for(F&& f) {
   }
 }
 
-// dbg (TIMING): [workgroup][wave 4][64] s_memtime stamps: 0 start, 1 low fragments requested, 2 query in LDS, 3 = 4 both folds
-// done, 5 fragments in AGPRs, 6 first W image, 7 first block landed, 8.. start of every block, then drain start, end.  (With the
-// peeled last tile the TIMING build no longer fits the register file: it spills and its numbers mean nothing -- use the PMC passes.)
+// dbg (TIMING): [workgroup][wave 4][64] s_memtime stamps.  In-kernel fold: 0 start, 1 low fragments requested, 2 query in LDS,
+// 3 RoPE state, 4 both folds done, 5 fragments in AGPRs, 6 first W image, 7 first block landed, 8.. start of every block, then
+// drain start, end.  PREFOLD: 0 start, 1 low fragments requested, 2 they have landed and the table values are in registers (barriers
+// A, A2), 3 high fragments and first block requested + RoPE state, 4 = 3, 5 first W image, 6 high fragments landed (barrier B), 7 fragments in AGPRs (barrier
+// C) + second block requested, 8.. blocks.  The stamps use scalar registers only: the TIMING build does not spill.
 // PREFOLD (round 6): the folded fragments come from p.qfold (abx_fold.h: written once per launch by the projection kernel's q
-// waves or by abx_fold_kernel) instead of being folded from (p.a, p.bfrag2) by every workgroup.  The prologue is then: tables +
-// the folded LOW fragments by LDS-DMA -> wait -> the folded HIGH fragments by LDS-DMA (into the ring's space) and the first
-// block's latents straight into registers -> barrier -> the first W image (needs the low fragments only: it runs while the high
-// ones land) -> wait, barrier -> LDS -> AGPRs -> barrier -> main loop.  Every wait is a vmcnt(0) (no counted wait on mixed
-// request types), and no VALU work, L2 read or LDS pass of the fold is left in the kernel.
+// waves or by abx_fold_kernel) instead of being folded from (p.a, p.bfrag2) by every workgroup.  The prologue is then: the
+// RoPE start tables (3 loads per wave, shared through LDS) + the folded LOW fragments by LDS-DMA -> wait, barrier -> table
+// values into registers, barrier -> the folded HIGH fragments by LDS-DMA (into the ring's space) and the first block's latents
+// straight into registers -> the first W image (needs the low fragments only: it runs while the high ones land) -> wait,
+// barrier -> LDS -> AGPRs -> barrier -> main loop.  Every wait is a vmcnt(0) (no counted wait on mixed request types), and
+// no VALU work, L2 read or LDS pass of the fold is left in the kernel.  The prologue is bound by what a CU takes in (~28 B per
+// clock): 64 + 64 KB of folded fragments, 32 KB of latents, 12 KB of tables.
 template <int NKS, bool TIMING = false, bool PREFOLD = false>
 __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void abx_rope3_kernel(AbxParams p) {
   using Geo = LdsGeom<NKS>;
@@ -96,12 +100,16 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
   const int hi = lane >> 5;
   const int g = blockIdx.x % p.G;
   const int cidx = blockIdx.x / p.G;
-  int stamp_i = 0;
+  // (TIMING: scalar registers only -- s_memtime into an SGPR pair, s_store_dwordx2 through the scalar cache, written back at
+  //  the kernel's end: the R = 128 kernel has no VGPR to spare, round 5's vector-store stamps made the TIMING build spill)
+  unsigned stamp_off = 0;
+  unsigned long long* const dbg_w = TIMING ? p.dbg + ((size_t)blockIdx.x * 4 + w) * 64 : nullptr;
   auto stamp = [&]() {
-    if (TIMING) {
-      const unsigned long long t = __builtin_readcyclecounter();
-      if (lane == 0 && stamp_i < 64) p.dbg[((size_t)blockIdx.x * 4 + w) * 64 + stamp_i] = t;
-      ++stamp_i;
+    if constexpr (TIMING) {
+      unsigned long long t;                         // (no branch: stamps past the 64th wrap around inside the wave's own row)
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t));
+      asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"(t), "s"(dbg_w), "s"(stamp_off) : "memory");
+      stamp_off = (stamp_off + 8) & (64 * 8 - 1);
     }
   };
   stamp();  // 0
@@ -321,7 +329,20 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
   } else {
     // ---- PREFOLD: tables, then this wave's quarter of the folded LOW fragments (LDS-DMA, 1 KB per instruction: fragment f of
     //      the group's buffer lands at OFF_LOWF + f KB as it lies in memory)
-    abx3_for<0, 25>([&](auto i_c) { tload(i_c); });
+    // (the RoPE start tables go through LDS: a lane needs 25 x 16 bytes of them -- 25 KB of loads per wave, 100 KB per CU,
+    //  as much as the fragments, on a prologue that is bound by what a CU takes in (~28 B per clock: profiles/
+    //  r06_abx_prefold_timeline.txt) -- but the workgroup only 8.25 KB of T2 + 256 B of T1 per wave: 3 loads per wave)
+    constexpr int TAB = M::OFF_X0;                   // [T2 rows 0..32: 33 x 256 B][T1 row of wave 0..3: 4 x 256 B], free until the high fragments arrive
+    static_assert(33 * 256 + 4 * 256 <= 8 * NKS * 1024, "the table image fits the two ring slots");
+    u32x4 tq[3];
+    {
+      const char* t2b = reinterpret_cast<const char*>(p.rope_t2);
+      const char* t1b = reinterpret_cast<const char*>(p.rope_t1 + (int64_t)(p.tab_tile0 + (ntile > 0 ? tile0 : 0)) * 64);
+      tq[0] = *reinterpret_cast<const u32x4*>(t2b + w * 2048 + lane * 16);
+      tq[1] = *reinterpret_cast<const u32x4*>(t2b + w * 2048 + 1024 + lane * 16);
+      const int l5 = lane & 31;                      // (lanes 32..63 mirror 0..31: same words to the same place)
+      tq[2] = *reinterpret_cast<const u32x4*>(l5 < 16 ? t2b + 8192 + l5 * 16 : t1b + (l5 - 16) * 16);
+    }
     u32x4 qrs;
     {
       const unsigned long long qb = reinterpret_cast<unsigned long long>(p.qfold + (int64_t)g * 16 * NKS * 64);
@@ -347,10 +368,29 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
     stamp();  // 1
     // everything requested so far has landed (tables, coefficients, this wave's low fragments) ...
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("" : "+v"(cf0[0]), "+v"(cf0[1]));
+    asm volatile("" : "+v"(cf0[0]), "+v"(cf0[1]), "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]));
+    {
+      const int l5 = lane & 31;
+      *(lds_u32x4*)(uintptr_t)(lds0 + (unsigned)(TAB + w * 2048 + lane * 16)) = tq[0];
+      *(lds_u32x4*)(uintptr_t)(lds0 + (unsigned)(TAB + w * 2048 + 1024 + lane * 16)) = tq[1];
+      *(lds_u32x4*)(uintptr_t)(lds0 + (unsigned)(TAB + (l5 < 16 ? 8192 + l5 * 16 : 33 * 256 + w * 256 + (l5 - 16) * 16))) = tq[2];
+    }
+    __syncthreads();                                 // A: every wave's low fragments and the tables are in LDS
+    {
+      typedef __attribute__((address_space(3))) f32x4 lds_f32x4;
+      const unsigned tb = lds0 + (unsigned)(TAB + hi * 128);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(vt1[i]), "+v"(vt2[i]), "+v"(vts[i]));
-    asm volatile("" : "+v"(vtm));
+      for (int i = 0; i < 8; ++i) {
+        vt1[i] = *(const lds_f32x4*)(uintptr_t)(tb + (unsigned)(33 * 256 + w * 256 + i * 16));
+        vt2[i] = *(const lds_f32x4*)(uintptr_t)(tb + (unsigned)(n * 256 + i * 16));
+        vts[i] = *(const lds_f32x4*)(uintptr_t)(tb + (unsigned)(32 * 256 + i * 16));
+      }
+      vtm = *(const lds_f32x4*)(uintptr_t)(tb + (unsigned)((32 - n) * 256 + 7 * 16));
+#pragma unroll
+      for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(vt1[i]), "+v"(vt2[i]), "+v"(vts[i]));
+      asm volatile("" : "+v"(vtm));                  // (the values are in registers ...)
+    }
+    __syncthreads();                                 // A2: ... in every wave: the table image may be overwritten
     stamp();  // 2
     // ... and the folded HIGH fragments follow, into the space of the two ring slots ([mb][ks][lane] as in memory), with the
     // first block's latents behind them -- straight into registers (this lane's B-operand chunks: row n of the block, columns
@@ -477,15 +517,15 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
     for (int k = 0; k < NKS; ++k) dma_piece(1, 1, k);
     build_first_w();
   } else {
-    __syncthreads();                                 // A: every wave's low fragments are in LDS
     stamp();  // 4
     build_first_w();                                 // (the high fragments land meanwhile)
+    stamp();  // 5
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(xf[ks]));
     __syncthreads();                                 // B: every wave's high fragments are in LDS
+    stamp();  // 6
     take_high(M::OFF_X0);
-    stamp();  // 5
     __syncthreads();                                 // C: the ring is free
 
     if (nblk <= 0) return;                           // (no barrier below this line)
@@ -493,7 +533,7 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
 #pragma unroll
     for (int k = 0; k < NKS; ++k) dma_piece(1, 1, k);
   }
-  stamp();  // 6
+  if constexpr (!PREFOLD) stamp();  // 6
 
   // scores leave through a buffer store (invalid lanes get an out-of-range offset the hardware drops)
   const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, p.out_bytes, 0x00020000);
@@ -656,23 +696,20 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
       abx3_for<0, NKS>([&](auto ks_c) {
         constexpr int ks = decltype(ks_c)::value;
         if (mb == 7 && ks == 0) {
-          // block b + 1 has landed: only the NKS LDS-DMA pieces of block b + 2 (issued above) may still be in flight.  The count
-          // is of DMA requests alone: block 1's two coefficient loads (plain loads, requested behind its pieces) and the
-          // stores may retire in any order relative to them -- counted in, a coefficient load that retires early would let the
-          // wait pass with two pieces of block b + 1 still on their way
-          // ... in the wave's LAST tile every request is waited for: there the younger requests are re-reads past the wave's
-          // range (clamped to its last block, which may be partly out of range), and such a re-read was seen retiring ahead of
-          // the block's own, older request on cold launches -- rows of the wave's last block stale in 18 of 240 launches
-          // (tools/stress_tail_cold.py).  (A compile-time choice: a run-time branch here makes hipcc spill around the asm MFMAs.)
-          // ... and so is the wait of a tile's LAST block (B = 3) in every tile: when the wave's next (= last) tile is a one-block
-          // tail, the pieces this block requested are already such re-reads (L % 128 in 1..32); the block carries
-          // stage 1, twice the time of the others lies between its requests and this wait -- it costs nothing (profiles/
-          // r06_abx_wait0.txt, which also times vmcnt(0) in EVERY block: -DABX3_WAIT0)
-#ifdef ABX3_WAIT0
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
+          // block b + 1 must have landed before its fragments are read below.  Round 5 waited with a COUNT here (vmcnt(NKS):
+          // "everything but the NKS pieces of block b + 2 requested above"), i.e. relied on LDS-DMA requests retiring in issue
+          // order -- and saw that fail on cold launches where the younger requests were clamped re-reads of a partly out-of-range
+          // tail block (stale rows in 18 of 240 launches, tools/stress_tail_cold.py; ADVICE r5 found one more such pattern in a
+          // non-last tile).  Round 6 measured the alternative the VERDICT asked for: waiting for EVERY request costs 0.0-0.6 %
+          // (C2 40.89 -> 41.14 us, R = 64 at 128k 43.80 -> 44.14, R = 32 17.50 -> 17.45, 16k positions 13.46 -> 13.40;
+          // profiles/r06_abx_wait0.txt) -- block b + 2's pieces were requested 7 phases (~2 k cycles) earlier and have
+          // mostly landed -- so the ordering assumption is gone: vmcnt(0) in every block.  (-DABX3_COUNTED_WAIT restores the
+          // counted wait in the tiles before a wave's last one, for A/B runs only.)
+#ifdef ABX3_COUNTED_WAIT
           if (LAST || B == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NKS) : "memory");
+#else
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
           if (B == 2) asm volatile("" : "+v"(cfr[0]), "+v"(cfr[1]));
         }
@@ -719,8 +756,7 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
           dma_piece(b + 2, SL, ks);
           if (B == 1 && ks == NKS - 1) {
             // coefficients of the next tile (its stage 1 runs in this tile's last block): requested behind this block's DMA
-            // pieces; this block's and the next block's vmcnt(NKS) cover them (most of a block time for a read that may miss
-            // every cache)
+            // pieces; this block's wait covers them (7 phases for a read that may miss every cache)
             const u32x4* src = tab0 + (int64_t)tnext * 64;             // (uniform: scalar base + the lane's offset)
             asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:512"
                          : "=&v"(cfr[0]), "=&v"(cfr[1])
@@ -790,6 +826,7 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
   finalize(b - 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the re-read pieces of the last blocks: nothing may land in LDS after the wave ends)
   stamp();
+  if constexpr (TIMING) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb" ::: "memory");
 #undef ABX3_MFMA_A0
 #undef ABX3_MFMA_A
 #undef ABX3_MFMA_V0

@@ -641,7 +641,7 @@ extern "C" int palu_prefill_attn_f16(const void* q, int64_t sq_h, int64_t sq_t, 
 // One kv PANEL of a prompt pass whose keys / values do not fit the workspace at once: k / vt hold the kv positions
 // [kv0, kv0 + Tk) only, `past_rel` = (absolute position of the first query) - kv0 (negative when the panel starts behind the
 // first query; a panel that lies entirely in a query tile's causal future leaves that tile's state untouched).  The
-// online-softmax state travels in state_o [H][Tq][Rv] fp32 and state_ml [H][Tq][8] fp32 (palu_prefill_state_bytes):
+// online-softmax state travels in state_o [H][Tq][Rv] fp32 and state_ml [Rv / 32][H][Tq][8] fp32 (one slice per 32-column block; size both with palu_prefill_state_bytes):
 // first != 0 starts from the empty state, last != 0 normalises and writes `out` (fp16) instead of the state.  Panels of one
 // (query chunk, head set) are launched in ascending kv order on one stream.  Same results as one launch over all panels
 // up to the fp32 rounding of the rescale order (the running maximum moves at panel boundaries exactly as at tile boundaries).

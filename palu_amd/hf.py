@@ -44,6 +44,7 @@ class PaluCacheHF(_HFCache):
                        else QuantLatentCache(bits, capacity, headroom, group_size=group_size))
         self.bits, self._capacity, self._headroom, self._group_size = bits, capacity, headroom, group_size
         self._mask_memo = None            # (mask identity, "is the plain causal mask") of the current forward pass
+        self._std_positions = None        # True / False: recorded by a prompt pass (or assume_standard_positions); None: unknown
 
     # -- what transformers' model code asks a cache ------------------------------------------------------------
     def get_seq_length(self, layer_idx: int = 0) -> int:
@@ -66,10 +67,18 @@ class PaluCacheHF(_HFCache):
     def update(self, key_states, value_states, layer_idx, cache_kwargs=None):
         raise RuntimeError("PaluCacheHF holds LATENT rows: it is updated by LlamaPaluAttention, not with reconstructed K/V")
 
+    def assume_standard_positions(self, flag: bool = True):
+        """For a cache filled WITHOUT a prompt pass through the model (load_cache, synthetic rows): declare that the decode
+        positions the caller will pass are the rows they append at (position == cache length).  Decode steps then never read
+        `position_ids` back from the device (a host sync per layer and token; illegal under graph capture).  A prompt pass
+        records this by itself; without either, device `position_ids` are passed through to the module."""
+        self._std_positions = bool(flag)
+
     def reset(self):
         self.latent = (LatentCache(self._capacity, self._headroom) if self.bits >= 16
                        else QuantLatentCache(self.bits, self._capacity, self._headroom, group_size=self._group_size))
         self._mask_memo = None
+        self._std_positions = None          # recorded by the next prompt pass (PaluAttentionHF.forward)
 
     def __len__(self):
         return len(getattr(self.latent, "_state", {})) if hasattr(self.latent, "_state") else 0
@@ -146,16 +155,23 @@ class PaluAttentionHF(nn.Module):
                 if position_ids.device.type == "cpu":
                     if int(position_ids.reshape(-1)[0]) == clen:
                         position_ids = None
-                elif getattr(past_key_values, "_std_positions", True):
-                    position_ids = None
+                elif getattr(past_key_values, "_std_positions", None) is True:
+                    position_ids = None            # (None = nothing recorded, e.g. a cache filled by load_cache: pass them through)
             is_causal = None
         elif attention_mask is None:
             is_causal = True               # the model is causal; without a mask tensor the module would apply none (:229)
-        if q_len > 1 and position_ids is not None and past_key_values is not None and self.layer_idx == 0:
-            # (one host read per PROMPT pass, first layer only: do this pass's positions start at the cache length?)
+        if q_len > 1 and past_key_values is not None and self.layer_idx == 0:
+            # (one host read per PROMPT pass, first layer only: are this pass's positions the rows it appends at, i.e.
+            #  arange(cache length, cache length + q_len)?  Judged from the WHOLE tensor -- left padding keeps element 0 at the
+            #  cache length often enough -- and recorded anew by every prompt pass, also one without position_ids: standard)
             try:
                 past0 = cache.get_seq_length(0) if cache is not None else 0
-                past_key_values._std_positions = bool(int(position_ids.reshape(-1)[0]) == past0)
+                if position_ids is None:
+                    past_key_values._std_positions = True
+                else:
+                    pid = position_ids.reshape(-1)
+                    want = torch.arange(past0, past0 + pid.numel(), device=pid.device, dtype=pid.dtype)
+                    past_key_values._std_positions = bool(pid.numel() == q_len and torch.equal(pid, want))
             except AttributeError:
                 pass
         out, weights, _ = self.inner(hidden_states, attention_mask=attention_mask, position_ids=position_ids,

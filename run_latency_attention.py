@@ -147,6 +147,46 @@ def step_algorithmic_bytes(config, prompt_len, bits=16):
     return latents + weights + b + scores
 
 
+class _DecodeStep:
+    """One decode token through `model` on a fixed token buffer, cache and position -- eager, or as the replay of a captured
+    hipGraph (the reference harness's --cache_graph, run_latency_attention.py:81-90 there).  The cache grows by one row per
+    eager call; a replay re-runs the captured launches (same row, same position: what the reference's replay does)."""
+
+    def __init__(self, model, cache, position_ids, token):
+        self.model, self.cache, self.position_ids, self.token = model, cache, position_ids, token
+        self.graph, self.out = None, None
+
+    @torch.no_grad()
+    def __call__(self):
+        if self.graph is not None:
+            self.graph.replay()
+            return self.out
+        return self.model(self.token, past_key_value=self.cache, position_ids=self.position_ids)
+
+    def run(self, n):
+        for _ in range(n):
+            self()
+        torch.cuda.synchronize()
+
+    @torch.no_grad()
+    def capture(self):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.out = self.model(self.token, past_key_value=self.cache, position_ids=self.position_ids)
+        self.graph = g
+
+
+def _device_ms(fn, reps):
+    """Device time of `reps` back-to-back calls between two events on the current stream (milliseconds, total)."""
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(reps):
+        fn()
+    t1.record()
+    torch.cuda.synchronize()
+    return t0.elapsed_time(t1)
+
+
 def profile_tpot(model, cache_size_k, cache_size_v, cache_type=torch.float16, batch_size=1, prompt_len=1024,
                  repeats=100, cache_graph=False, torch_profile=False, outfile="", bits=16):
     logging.info(">>> Profiling TPOT (generation stage)")
@@ -178,47 +218,20 @@ def profile_tpot(model, cache_size_k, cache_size_v, cache_type=torch.float16, ba
         position_ids = position_ids.to(device)
     input_token = torch.randn((batch_size, 1, hidden_dim), dtype=torch.float16, device=device)
 
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.no_grad():
-        with torch.cuda.stream(s):
-            for _ in range(warm):
-                _ = model(input_token, past_key_value=past_key_value, position_ids=position_ids)
-    torch.cuda.current_stream().wait_stream(s)
-
+    step = _DecodeStep(model, past_key_value, position_ids, input_token)
+    step.run(warm)                                           # warm-up: kernels loaded, B fragments and RoPE tables cached
     if cache_graph:
-        with torch.no_grad():
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = model(input_token, past_key_value=past_key_value, position_ids=position_ids)
-
-        def generate(new_input_token, past_key_value, position_ids):
-            input_token.copy_(new_input_token)
-            graph.replay()
-            return out
-    else:
-        def generate(new_input_token, past_key_value, position_ids):
-            return model(new_input_token, past_key_value=past_key_value, position_ids=position_ids)
-
-    new_input_token = torch.randn((batch_size, 1, hidden_dim), dtype=torch.float16, device=device)
-    with torch.no_grad():
-        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        start.record()
-        for _ in range(reps):
-            generate(new_input_token, past_key_value=past_key_value, position_ids=position_ids)
-        end.record()
-        torch.cuda.synchronize()
-    dur = start.elapsed_time(end)
+        step.capture()                                       # one hipGraph of the module's launches, replayed per token
+    step.token.copy_(torch.randn_like(step.token))           # a fresh token, as the generation loop would feed
+    dur = _device_ms(step, reps)
     logging.info(f"Finished, prompt_len: {prompt_len}, latency: {dur / reps:.2f} milliseconds (cache_graph={cache_graph})")
-
     if torch_profile:
         from torch.profiler import ProfilerActivity, profile, schedule
         with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA],
                      schedule=schedule(wait=1, warmup=5, active=6, repeat=1), record_shapes=True) as prof:
-            with torch.no_grad():
-                for _ in range(12):
-                    generate(new_input_token, past_key_value, position_ids=position_ids)
-                    prof.step()
+            for _ in range(12):
+                step()
+                prof.step()
         prof.export_chrome_trace(f"{outfile or 'tpot_palu_fp16'}.json.gz")
     return dur / reps
 

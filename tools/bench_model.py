@@ -75,6 +75,7 @@ def run(layers=32, rank_k=1024, rank_v=3072, group_size=4, prompt_len=65536, bit
     G = 32 // group_size
     cache = PaluCacheHF(bits=bits, capacity=prompt_len + 64)
     fill_cache(cache, layers, G, rank_k // G, rank_v // G, prompt_len, dev, bits)
+    cache.assume_standard_positions()      # (filled without a prompt pass: the decode position IS the cache length)
     torch.cuda.synchronize()
     setup_s = time.perf_counter() - t0
     tok = torch.randint(0, 32000, (1, 1), device=dev)

@@ -141,10 +141,14 @@ if "timeline" in what:
         sys.exit(0)
     fn.restype = None
     fn.argtypes = [C.c_void_p]
-    for (H, G, R, L) in [(32, 8, 128, 65536), (32, 8, 64, 131072)]:
+    from palu_amd.kernel.abx_rope import in_kernel_fold
+    import contextlib
+    for (H, G, R, L, prefold) in [(32, 8, 128, 65536, True), (32, 8, 128, 65536, False), (32, 8, 64, 131072, True)]:
+      with (contextlib.nullcontext() if prefold else in_kernel_fold()):
         a, b, x = inputs(H, G, R, L, 1)
         out = torch.empty(H, 1, L, device=dev, dtype=torch.float16)
         nwg = 256
+        print("fold:", "once per launch (fold kernel in front)" if prefold else "in every workgroup's prologue")
         dbg = torch.zeros(nwg * 4 * 64, dtype=torch.int64, device=dev)
         for _ in range(3):
             abx(a, b, x, out=out)
@@ -157,7 +161,9 @@ if "timeline" in what:
         d = dbg.cpu().numpy().reshape(nwg, 4, 64).astype(np.int64)
         nst = int((d[0, 0] != 0).sum())
         rel = d - d[:, :1, :1]
-        names = ["start", "loads issued", "rope init", "low fold", "high fold", "frags in AGPRs", "first W image", "first block landed"]
+        names = (["start", "low frags requested", "low frags + tables in", "high frags requested, rope", "barrier A", "first W image",
+                  "high frags in (barrier B)", "frags in AGPRs (barrier C)"] if prefold else
+                 ["start", "loads issued", "query in LDS", "rope init", "folds done", "frags in AGPRs", "first W image", "first block landed"])
         print(f"== timeline R={R} L={L}: {nst} stamps per wave; s_memtime ticks relative to the workgroup's wave 0 start, mean over workgroups [min .. max]")
         for i in range(nst):
             nm = names[i] if i < len(names) else (f"block {i - 8}" if i < nst - 2 else ("drain" if i == nst - 2 else "end"))
