@@ -171,19 +171,32 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
   }
   // lane (n, hi) holds the 16 high-band pairs i = 4 mb + 2 j + hi, q = 2 mb + j, of one position per block
   float fr[16];
+  if constexpr (!PREFOLD) {                        // (PREFOLD: from the LDS table image below -- 16 vector loads less in front of the fragments)
 #pragma unroll
-  for (int q = 0; q < 16; ++q) fr[q] = p.inv_freq[4 * (q >> 1) + 2 * (q & 1) + hi];
+    for (int q = 0; q < 16; ++q) fr[q] = p.inv_freq[4 * (q >> 1) + 2 * (q & 1) + hi];
+  }
   const float psimax = 64.0f * p.inv_freq[ABX2_I0];
   // stage 1 uses 8 of the 16 MFMA columns: lanes k + 8 load the coefficients of lane k, compute the same W values and store
   // them to the same LDS words (no exec masking, no zero fill)
   const u32x4* tab0 = p.rope_tab + (int64_t)(p.tab_tile0 + tile0) * 64;      // (uniform) this wave's first tile: 2 x 32 u32x4 per tile
   const unsigned tab_lane = (unsigned)(((lane >> 4) * 8 + (lane & 7)) * 16);  // this lane's 16 bytes of a coefficient fragment
-  h16x8 cf0[2];
+  // COOP (PREFOLD, NKS >= 4): the first W images of the workgroup's four waves are built together -- wave w takes NKS / 4 of the
+  // r-blocks for ALL four first tiles, so every low fragment is read from LDS once per workgroup instead of once per wave (the
+  // build is LDS-bound: 64 KB per wave = 256 KB per CU at 128 B per clock were 2.7 k of the prologue's cycles) -- and needs
+  // the coefficients of all four tiles
+  constexpr bool COOP = PREFOLD && NKS >= 4;
+  constexpr int NCF = COOP ? 4 : 1;
+  h16x8 cf0[NCF][2];                               // (COOP: [v4] = the first tile of wave v4, exchanged through LDS below; else [0] = this wave's)
+  h16x8 cfown[2];
+  {
+    // (a wave without tiles takes the coefficients of the launch's first tile: its image is never read)
+    const u32x4* tabv = p.rope_tab + (int64_t)(p.tab_tile0 + (ntile > 0 ? tile0 : 0)) * 64;
 #pragma unroll
-  for (int cs = 0; cs < 2; ++cs) {
-    u32x4 v = u32x4{0u, 0u, 0u, 0u};
-    if (ntile > 0) v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(tab0 + cs * 32) + tab_lane);
-    cf0[cs] = *reinterpret_cast<h16x8*>(&v);
+    for (int cs = 0; cs < 2; ++cs) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(tabv + cs * 32) + tab_lane);
+      cfown[cs] = __builtin_bit_cast(h16x8, v);
+      if constexpr (!COOP) cf0[0][cs] = cfown[cs];
+    }
   }
   // exact-angle (cos, sin) of: the wave's first tile start (T1), this lane's offset n, the one-block-early start of M-block 7
   // (its epilogue runs during the NEXT block) and the 32-position step (T2, abx2_rope_start_kernel): 25 loads of 16 bytes per
@@ -229,7 +242,7 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
     stamp();  // 2
 
     __syncthreads();                                 // #1: the query is in LDS
-    asm volatile("" : "+v"(cf0[0]), "+v"(cf0[1]));   // (hipcc's wait for these loads goes here, where nothing else is in flight)
+    asm volatile("" : "+v"(cf0[0][0]), "+v"(cf0[0][1]));   // (hipcc's wait for these loads goes here, where nothing else is in flight)
 
     // ---- (q_i, q_{i+64}) of this lane's rows in the two high M-blocks it folds
     unsigned qp0, qp1;                               // (two scalars, not an array: the fold below picks one by a run-time bit)
@@ -332,16 +345,23 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
     // (the RoPE start tables go through LDS: a lane needs 25 x 16 bytes of them -- 25 KB of loads per wave, 100 KB per CU,
     //  as much as the fragments, on a prologue that is bound by what a CU takes in (~28 B per clock: profiles/
     //  r06_abx_prefold_timeline.txt) -- but the workgroup only 8.25 KB of T2 + 256 B of T1 per wave: 3 loads per wave)
-    constexpr int TAB = M::OFF_X0;                   // [T2 rows 0..32: 33 x 256 B][T1 row of wave 0..3: 4 x 256 B], free until the high fragments arrive
-    static_assert(33 * 256 + 4 * 256 <= 8 * NKS * 1024, "the table image fits the two ring slots");
+    // table image: [T2 rows 0..32: 33 x 256 B][T1 row of wave 0..3: 4 x 256 B][inv_freq 0..31: 128 B] in the space of the ring
+    // slots, free until the high fragments are requested
+    constexpr int TAB = M::OFF_X0;
+    constexpr int TAB_T1 = 33 * 256, TAB_F = TAB_T1 + 4 * 256;
+    constexpr int TAB_CF = TAB_F + 128;              // COOP: [wave 4][cs 2][lane 64] x 16 B coefficient fragments of the waves' first tiles
+    static_assert(TAB_CF + (COOP ? 8 * 1024 : 0) <= 8 * NKS * 1024, "the table image fits the two ring slots");
     u32x4 tq[3];
     {
       const char* t2b = reinterpret_cast<const char*>(p.rope_t2);
       const char* t1b = reinterpret_cast<const char*>(p.rope_t1 + (int64_t)(p.tab_tile0 + (ntile > 0 ? tile0 : 0)) * 64);
       tq[0] = *reinterpret_cast<const u32x4*>(t2b + w * 2048 + lane * 16);
       tq[1] = *reinterpret_cast<const u32x4*>(t2b + w * 2048 + 1024 + lane * 16);
-      const int l5 = lane & 31;                      // (lanes 32..63 mirror 0..31: same words to the same place)
-      tq[2] = *reinterpret_cast<const u32x4*>(l5 < 16 ? t2b + 8192 + l5 * 16 : t1b + (l5 - 16) * 16);
+      // lanes 0..15: T2 row 32, 16..31: this wave's T1 row, 32..39: the 32 high-band frequencies, 40..63 mirror 0..15
+      const int l4 = lane & 15;
+      tq[2] = *reinterpret_cast<const u32x4*>(lane < 16 ? t2b + 8192 + lane * 16 : lane < 32 ? t1b + (lane - 16) * 16
+                                              : lane < 40 ? reinterpret_cast<const char*>(p.inv_freq) + (lane - 32) * 16
+                                                          : t2b + 8192 + l4 * 16);
     }
     u32x4 qrs;
     {
@@ -363,17 +383,29 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
           : "s"(dst), "v"(lane16), "s"(qrs), "s"(soff)
           : "memory");   // (m0 cannot be listed: hipcc treats it as reserved and warns that the clobber is ignored; it never keeps a value in m0 on gfx950)
     };
+    // the folded LOW fragments first.  (Requesting everything up front -- low, high, first block -- was measured and is slower:
+    // what a CU takes in (~20-28 B per clock) is the bound, all of it landed at 9.8 k cycles instead of the low fragments at 6.4 k
+    // with the high ones arriving under the W build, and the main loop started 1.4 k cycles later: profiles/r06_abx_prologue_variants.txt)
 #pragma unroll
     for (int t = 0; t < FPW; ++t) dma_frag(8 * NKS + w * FPW + t, M::OFF_LOWF + (w * FPW + t) * 1024);
     stamp();  // 1
     // everything requested so far has landed (tables, coefficients, this wave's low fragments) ...
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    asm volatile("" : "+v"(cf0[0]), "+v"(cf0[1]), "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]));
+    asm volatile("" : "+v"(cfown[0]), "+v"(cfown[1]), "+v"(tq[0]), "+v"(tq[1]), "+v"(tq[2]));
+    if constexpr (COOP) {
+#pragma unroll
+      for (int cs = 0; cs < 2; ++cs)
+        *(lds_h16x8*)(uintptr_t)(lds0 + (unsigned)(TAB + TAB_CF + ((w * 2 + cs) * 64 + lane) * 16)) = cfown[cs];
+    } else {
+      cf0[0][0] = cfown[0];
+      cf0[0][1] = cfown[1];
+    }
     {
-      const int l5 = lane & 31;
+      const int l4 = lane & 15;
       *(lds_u32x4*)(uintptr_t)(lds0 + (unsigned)(TAB + w * 2048 + lane * 16)) = tq[0];
       *(lds_u32x4*)(uintptr_t)(lds0 + (unsigned)(TAB + w * 2048 + 1024 + lane * 16)) = tq[1];
-      *(lds_u32x4*)(uintptr_t)(lds0 + (unsigned)(TAB + (l5 < 16 ? 8192 + l5 * 16 : 33 * 256 + w * 256 + (l5 - 16) * 16))) = tq[2];
+      *(lds_u32x4*)(uintptr_t)(lds0 + (unsigned)(TAB + (lane < 16 ? 8192 + lane * 16 : lane < 32 ? TAB_T1 + w * 256 + (lane - 16) * 16
+                                                            : lane < 40 ? TAB_F + (lane - 32) * 16 : 8192 + l4 * 16))) = tq[2];
     }
     __syncthreads();                                 // A: every wave's low fragments and the tables are in LDS
     {
@@ -381,11 +413,26 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
       const unsigned tb = lds0 + (unsigned)(TAB + hi * 128);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        vt1[i] = *(const lds_f32x4*)(uintptr_t)(tb + (unsigned)(33 * 256 + w * 256 + i * 16));
+        vt1[i] = *(const lds_f32x4*)(uintptr_t)(tb + (unsigned)(TAB_T1 + w * 256 + i * 16));
         vt2[i] = *(const lds_f32x4*)(uintptr_t)(tb + (unsigned)(n * 256 + i * 16));
         vts[i] = *(const lds_f32x4*)(uintptr_t)(tb + (unsigned)(32 * 256 + i * 16));
       }
       vtm = *(const lds_f32x4*)(uintptr_t)(tb + (unsigned)((32 - n) * 256 + 7 * 16));
+      typedef __attribute__((address_space(3))) float lds_f32s;
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+        fr[q] = *(const lds_f32s*)(uintptr_t)(lds0 + (unsigned)(TAB + TAB_F + (4 * (q >> 1) + 2 * (q & 1) + hi) * 4));
+#pragma unroll
+      for (int q = 0; q < 16; ++q) asm volatile("" : "+v"(fr[q]));
+      if constexpr (COOP) {
+#pragma unroll
+        for (int v4 = 0; v4 < 4; ++v4)
+#pragma unroll
+          for (int cs = 0; cs < 2; ++cs) {
+            cf0[v4][cs] = *(const lds_h16x8*)(uintptr_t)(lds0 + (unsigned)(TAB + TAB_CF + ((v4 * 2 + cs) * 64 + lane) * 16));
+            asm volatile("" : "+v"(cf0[v4][cs]));
+          }
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) asm volatile("" : "+v"(vt1[i]), "+v"(vt2[i]), "+v"(vts[i]));
       asm volatile("" : "+v"(vtm));                  // (the values are in registers ...)
@@ -457,33 +504,54 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
 #pragma unroll
       for (int i = 0; i < 8; ++i) lf[i] = read_lowf(rb * 8 + i);
     };
-    auto mfma8 = [&](const h16x8 (&lf)[8], f32x4 (&wa)[4]) {
+    auto mfma8 = [&](const h16x8 (&lf)[8], const h16x8 (&cf)[2], f32x4 (&wa)[4]) {
 #pragma unroll
-      for (int h4 = 0; h4 < 4; ++h4) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(wa[h4]) : "v"(lf[2 * h4]), "v"(cf0[0]));
+      for (int h4 = 0; h4 < 4; ++h4) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(wa[h4]) : "v"(lf[2 * h4]), "v"(cf[0]));
 #pragma unroll
-      for (int h4 = 0; h4 < 3; ++h4) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(wa[h4]) : "v"(lf[2 * h4 + 1]), "v"(cf0[1]));
-      asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\ts_nop 7" : "+v"(wa[3]) : "v"(lf[7]), "v"(cf0[1]));
+      for (int h4 = 0; h4 < 3; ++h4) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(wa[h4]) : "v"(lf[2 * h4 + 1]), "v"(cf[1]));
+      asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0\n\ts_nop 7" : "+v"(wa[3]) : "v"(lf[7]), "v"(cf[1]));
     };
-    auto store4 = [&](const f32x4 (&wa)[4], int rb) {
+    // (image of wave v4: OFF_W + v4 WIMG; w_st carries this wave's own)
+    auto store4 = [&](const f32x4 (&wa)[4], int rb, int v4) {
+      const unsigned base_v = w_st + (unsigned)((v4 - w) * M::WIMG);
 #pragma unroll
       for (int h4 = 0; h4 < 4; ++h4) {
         h16x4 wpk;
 #pragma unroll
         for (int j = 0; j < 4; ++j) wpk[j] = (h16)wa[h4][j];
-        write_w(rb, h4, wpk);
+        *(lds_h16x4*)(uintptr_t)(base_v + (unsigned)(rb * 1024 + h4 * 128)) = wpk;
       }
     };
-    load8(lfa, 0);
-    abx3_for<0, NKS>([&](auto rb_c) {
-      constexpr int rb = decltype(rb_c)::value;
-      mfma8(lfa, (rb & 1) ? waB : waA);
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (rb + 1 < NKS) load8(lfa, rb + 1);   // (an MFMA has read its sources long before an LDS load returns)
-      if constexpr (rb > 0) store4((rb & 1) ? waA : waB, rb - 1);
-      __builtin_amdgcn_sched_barrier(0);
-    });
-    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // the last burst's results (no MFMAs follow to cover them)
-    store4(((NKS - 1) & 1) ? waB : waA, NKS - 1);
+    if constexpr (COOP) {
+      // step s = (r-block rr of this wave's share, target wave v4): 8 MFMAs with that tile's coefficients; the results of step
+      // s - 1 are converted and stored behind them (the asm-MFMA rule: a full burst after their own)
+      constexpr int RPW = NKS / 4;
+      const int rb0 = w * RPW;
+      load8(lfa, rb0);
+      abx3_for<0, 4 * RPW>([&](auto s_c) {
+        constexpr int st = decltype(s_c)::value;
+        constexpr int rr = st / 4, v4 = st % 4;
+        mfma8(lfa, cf0[v4], (st & 1) ? waB : waA);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (v4 == 3 && rr + 1 < RPW) load8(lfa, rb0 + rr + 1);   // (an MFMA has read its sources long before an LDS load returns)
+        if constexpr (st > 0) store4((st & 1) ? waA : waB, rb0 + (st - 1) / 4, (st - 1) % 4);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // the last burst's results (no MFMAs follow to cover them)
+      store4(((4 * RPW - 1) & 1) ? waB : waA, rb0 + RPW - 1, 3);
+    } else {
+      load8(lfa, 0);
+      abx3_for<0, NKS>([&](auto rb_c) {
+        constexpr int rb = decltype(rb_c)::value;
+        mfma8(lfa, cf0[0], (rb & 1) ? waB : waA);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (rb + 1 < NKS) load8(lfa, rb + 1);   // (an MFMA has read its sources long before an LDS load returns)
+        if constexpr (rb > 0) store4((rb & 1) ? waA : waB, rb - 1, w);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");   // the last burst's results (no MFMAs follow to cover them)
+      store4(((NKS - 1) & 1) ? waB : waA, NKS - 1, w);
+    }
   };
   // every wave takes ALL high fragments from LDS: 8 NKS AGPR quads, MFMA-only operands from here on
   auto take_high = [&](int off) {
@@ -523,7 +591,7 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) asm volatile("" : "+v"(xf[ks]));
-    __syncthreads();                                 // B: every wave's high fragments are in LDS
+    __syncthreads();                                 // B: every wave's high fragments are in LDS, the W images are complete
     stamp();  // 6
     take_high(M::OFF_X0);
     __syncthreads();                                 // C: the ring is free
@@ -554,7 +622,7 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
   float ang_n = lfe * fr[14];
   float lo_cur = fmaf(lfe, fr[14], -ang_n);        // residual of the oracle's fp32 angle of the next pair to be rotated
   h16x8 cfr[2];                                    // coefficients of the next tile (stage-1 B operand)
-  cfr[0] = cfr[1] = cf0[0];
+  cfr[0] = cfr[1] = cf0[0][0];
 
   // chunk c (0..7) of the RoPE epilogue of high M-block mbp held in `ac`; its pairs q = 2 mbp + j, j = 0, 1:
   //   c = 0, 2 (j = 0, 1): cos/sin at the oracle's fp32-rounded angle fl(l f) (exact angle = ang + lo, first order in lo), start of
@@ -638,7 +706,11 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
     // stage-2 polynomial weights of this block: position d = 32 B + n of the tile, terms k = 4 hi + c
     float pw[4];
     {
-      const float tau = (float)(2 * (32 * B + n) + 1 - TL) * (1.0f / TL);
+      int nn = n;
+      if constexpr (PREFOLD) {                       // (the lane's row, derived again from the lane id: see behind the main loop)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0\n\tv_and_b32 %0, 31, %0" : "=v"(nn));
+      }
+      const float tau = (float)(2 * (32 * B + nn) + 1 - TL) * (1.0f / TL);
       const float t = tau * psimax;
       const float t2 = t * t;
       pw[0] = hi ? t2 * t2 * (1.0f / 24.0f) : 1.0f;
@@ -758,9 +830,14 @@ __global__ __launch_bounds__(ABX3_THREADS) __attribute__((amdgpu_waves_per_eu(1,
             // coefficients of the next tile (its stage 1 runs in this tile's last block): requested behind this block's DMA
             // pieces; this block's wait covers them (7 phases for a read that may miss every cache)
             const u32x4* src = tab0 + (int64_t)tnext * 64;             // (uniform: scalar base + the lane's offset)
+            // (the lane's offset ((lane >> 4) * 8 + (lane & 7)) * 16 is derived again from the lane id right here: kept in a register
+            //  across the loop it was one of the two values the R = 128 PREFOLD kernel sent to scratch)
+            unsigned tl;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(tl));
+            tl = ((tl >> 4) * 8 + (tl & 7)) * 16;
             asm volatile("global_load_dwordx4 %0, %2, %3\n\tglobal_load_dwordx4 %1, %2, %3 offset:512"
                          : "=&v"(cfr[0]), "=&v"(cfr[1])
-                         : "v"(tab_lane), "s"(src)
+                         : "v"(tl), "s"(src)
                          : "memory");
           }
         } else {

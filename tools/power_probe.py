@@ -64,7 +64,7 @@ def arm(name, fn):
     pw = [s[1] for s in ss if s[1] > 0]
     ck = [s[2] for s in ss if s[2] > 0]
     p = sum(pw) / len(pw) if pw else float("nan")
-    print(f"{name:34s} {us:8.2f} us/launch   power {p:7.1f} W ({len(pw)} samples, min {min(pw) if pw else 0:.0f} max {max(pw) if pw else 0:.0f})   "
+    print(f"{name:40s} {us:8.2f} us/launch   power {p:7.1f} W ({len(pw)} samples, min {min(pw) if pw else 0:.0f} max {max(pw) if pw else 0:.0f})   "
           f"sclk {sum(ck) / len(ck) if ck else float('nan'):6.0f} MHz   energy/launch {p * us * 1e-3:7.2f} mJ", flush=True)
 
 
@@ -72,10 +72,28 @@ th = threading.Thread(target=sampler, daemon=True)
 th.start()
 time.sleep(1.0)
 print("idle:", samples[-1] if samples else None, flush=True)
-arm("position-split, randn latents", lambda: abx(a, b, x, out=out))
+# the position-split kernel on fragments folded once (what a decode step launches behind its projection kernel), and with the
+# fold in every workgroup's prologue (round 5's form)
+from palu_amd.kernel.abx_rope import prepare_b, in_kernel_fold
+lib, S = _lib.lib, _lib.current_stream
+frag = prepare_b(b, G)
+qf = torch.zeros(lib.palu_abx_fold_bytes(H, G, R), dtype=torch.uint8, device=dev)
+inv = rope_inv_freq(dev)
+_lib.check(lib.palu_abx_fold_f16(a.data_ptr(), a.stride(0), 1, frag.data_ptr(), qf.data_ptr(), H, G, R, S()), "fold")
+out2 = out.view(H, L)
+
+
+def prefolded(xx):
+    _lib.check(lib.palu_abx_rope_pf_f16(qf.data_ptr(), xx.data_ptr(), xx.stride(0), xx.stride(1), out2.data_ptr(), out2.stride(0),
+                                        H, G, L, R, D, inv.data_ptr(), 0, S()), "abx_pf")
+
+
+arm("position-split, prefolded, randn", lambda: prefolded(x))
+with in_kernel_fold():
+    arm("position-split, in-kernel fold, randn", lambda: abx(a, b, x, out=out))
+arm("position-split, prefolded, zero latents", lambda: prefolded(xz))
 with pair_split():
     arm("pair-split, randn latents", lambda: abx(a, b, x, out=out))
-arm("position-split, zero latents", lambda: abx(a, b, xz, out=out))
 with pair_split():
     arm("pair-split, zero latents", lambda: abx(a, b, xz, out=out))
 big = torch.randn(1 << 28, device=dev, dtype=torch.float16)
