@@ -433,6 +433,21 @@ int palu_prefill_attn_panel_f16(const void* q, int64_t sq_h, int64_t sq_t, const
                                 int D, int Tq, int Tk, int Rv, int past_rel, int causal, float scale,
                                 void* state_o, void* state_ml, int first, int last, palu_stream_t stream);
 size_t palu_prefill_state_bytes(int H, int Tq, int Rv, int which);
+/* Prompt attention straight from the latent caches (round 6, csrc/prefill_lat.hip): the keys of every 64-position
+ * kv tile are rebuilt INSIDE the kernel, K~ = RoPE(X_k . B_h) (kernel/palu_attention.py:67-77, :199-205: reconstruct GEMM rounded to
+ * fp16, HF rotary with fp16 cos / sin and fp16 products), and the latent values are read in the cache's row-major layout -- no
+ * [H, kv, D] key workspace and no transposed value copy.  q [H][Tq][128] rotated queries (first one at absolute position `past`),
+ * xk [G][>= Tk][128] / xv [G][>= Tk][Rv] fp16 latent caches (row l = position l), bt = B^T [H][128 d][128 r] contiguous (the rows
+ * of U_h), cs = the rotary cache of the key positions 0 .. Tk - 1, [pos][2][64] fp16 (cos row, sin row), built once by
+ * palu_rope_cs_table_build (palu_rope_cs_table_bytes(npos) bytes); out [Tq][H * Rv] fp16.  Needs head_dim 128, rank_k / G = 128,
+ * rank_v / G in {128, 256, 384} (palu_prefill_attn_lat_supported); causal as palu_prefill_attn_f16. */
+size_t palu_rope_cs_table_bytes(int npos);
+int palu_rope_cs_table_build(const float* inv_freq, int pos0, int npos, void* table, palu_stream_t stream);
+int palu_prefill_attn_lat_supported(int H, int G, int D, int Rk, int Rv);
+int palu_prefill_attn_lat_f16(const void* q, int64_t sq_h, int64_t sq_t, const void* xk, int64_t sxk_g, int64_t sxk_l,
+                              const void* xv, int64_t sxv_g, int64_t sxv_l, const void* bt, const void* cs, void* out,
+                              int64_t so_t, int H, int G, int D, int Tq, int Tk, int Rk, int Rv, int past, int causal,
+                              float scale, palu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * One-shot peer-to-peer exchange for the head-group-parallel decode step (the reference is single-GPU and

@@ -1,0 +1,546 @@
+// Prompt attention straight from the LATENT caches (SURVEY 8(f) N1 as the survey wrote it): the prompt branch of
+// LlamaPaluAttention.forward (kernel/palu_attention.py:196-257) with
+//   * K~ = RoPE(X_k . B_h) rebuilt per 64-position kv tile INSIDE the flash kernel (the reference reconstructs the full keys,
+//     :67-77, :199-205, and prefill_attn.hip read them from a [H, kv, D] workspace: 512 MiB at 64k positions), and
+//   * the latent values read in the cache's own row-major layout [G, L, Rv] (prefill_attn.hip needs a transposed, zero-padded
+//     copy: 384 MiB) through the hardware transpose read,
+// so that no transient of a prompt pass grows with the number of cached positions.
+//
+// Same flash formulation as prefill_attn.hip (S^T = K~ . Q~^T, O^T = V^T . P^T, fp32 online softmax, lane = query), but the
+// eight waves of a workgroup (128 queries x one head) are SPLIT BY ROLE instead of by kv half / column half -- the pair kernel
+// sits at 251 of its 256 registers at Rv = 384 and has no room for the rebuild's operands:
+//   S-waves (0-3, one per SIMD, 32 queries each): the scores of the whole 64-position tile, the online softmax, and the rebuild
+//       of a quarter of the NEXT K~ tile -- wave w: kv half w & 1 x RoPE pairs 32 (w >> 1) .. + 31, i.e. 64 rows of B_h^T resident as
+//       64 registers of MFMA A fragments (these waves have the registers), the X tile's B fragments from LDS (each read feeds two
+//       MFMAs), rotary values prefetched from the rotary cache one phase ahead; fp32 -> fp16 -> rotation with the reference's fp16
+//       roundings -> the other K~ tile image in LDS (double-buffered).  Probabilities (fp16, already in B-operand order) and the
+//       rescale factor go to LDS;
+//   O-waves (4-7, the partner on the same SIMD): O^T += V^T . P^T for all Rv columns (192 accumulator registers), V rows staged
+//       by LDS-DMA in half tiles of 32 positions, A operand by ds_read_b64_tr_b16 (32-byte granules XOR-swizzled by row & 3:
+//       the four rows of a transpose read fall on different bank groups).  They run half a tile behind the S-waves, so ONE
+//       probability buffer serves: each k-step pair is written in one phase and read in the next.
+// Both forms of the kernel are bound by LDS bandwidth (~2.8 k cycles of LDS traffic per tile in the pair kernel, of which 1.5 k are
+// the P.V A operands); what the rebuild adds is counted in LDS bytes, not MFMAs: X tile in (16 KB) + 32 KB of B-fragment reads +
+// 16 KB of K~ writes.  Measured steps (profiles/r06_prefill_lat_variants.txt): rebuild on the S-waves by d quarters with its rotary
+// values straight from L2 105 ms at 64k tokens (workspace form: 72-75 ms); rebuild on the O-waves with B^T fragments and rotary rows
+// through LDS 105-114 ms (4.2 k cycles of LDS traffic per tile); this form: see there.
+// Two workgroup barriers per tile; every DMA is waited for with vmcnt(0) at the barrier that publishes it.
+// MFMAs per tile and workgroup: 64 (rebuild) + 64 (scores) + 192 (P.V): the rebuild is the +25 % DESIGN 4.6 estimated.
+#include <type_traits>
+
+#include "palu_common.h"
+#include "pv_mfma.h"
+
+#ifndef PL_EXP
+#define PL_EXP 0   // timing experiments only (results are wrong when set): 1 = no K~ rebuild, 2 = no exponentials, 4 = no P.V MFMAs
+#endif
+
+namespace {
+
+constexpr int PL_THREADS = 512;
+constexpr int PL_BM = 128;   // queries per workgroup
+constexpr int PL_BN = 64;    // kv positions per tile
+
+struct PfLatParams {
+  const h16* q;            // rotated queries [H][Tq][128]
+  int64_t sq_h, sq_t;
+  const h16* xk;           // latent keys   [G][>= Tk][128]
+  int64_t sxk_g, sxk_l;
+  const h16* xv;           // latent values [G][>= Tk][Rv]
+  int64_t sxv_g, sxv_l;
+  const h16* bt;           // B^T [H][128 d][128 r]: row d of head h = the weights that rebuild K[., d]
+  const h16* cs;           // [pos][2][64] fp16: cos row, sin row of key position pos (0 .. Tk - 1)
+  h16* out;
+  int64_t so_t;
+  int H, G, gs, Tq, Tk, past, causal;
+  float scale_log2;
+  int nqt, head_major;
+};
+
+typedef __attribute__((address_space(3))) h16x8 lds_h16x8_t;
+typedef __attribute__((address_space(3))) h16x4 lds_h16x4_t;
+typedef __attribute__((address_space(3))) float lds_f32_t;
+
+template <int NCB>
+__global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams p) {
+  constexpr int RV = 32 * NCB;
+  constexpr int RVB = RV * 2;                       // bytes of a V row
+  constexpr int XS_BYTES = PL_BN * 256;             // X tile: 64 rows x 128 fp16 (16 chunks per row, XOR-swizzled by row & 15)
+  constexpr int KS_BYTES = PL_BN * 256;             // K~ tile, same geometry
+  constexpr int VH_BYTES = 32 * RVB;                // half a V tile: 32 rows, row-major, 32-byte granules XOR-swizzled by row & 3
+  constexpr int VPW = VH_BYTES / 1024 / 8;          // DMA pieces per wave and half tile
+  static_assert(VH_BYTES % 8192 == 0 && (4 * RVB) % 1024 == 0, "a wave stages whole groups of 4 rows");
+  constexpr int OFF_XS = 0;
+  constexpr int OFF_VS = OFF_XS + XS_BYTES;         // (the DMA targets first: LDS offsets below 128 KB)
+  constexpr int OFF_KS = OFF_VS + 2 * VH_BYTES;     // two K~ tile images: tile jt in image jt & 1
+  constexpr int OFF_PS = OFF_KS + 2 * KS_BYTES;     // [qblk 4][ks 4][lane 64] x 16 B probabilities (B-operand order); k-steps 0, 1 are written in
+                                                    // phase alpha and read in phase beta, k-steps 2, 3 written in beta and read in the next alpha
+  constexpr int OFF_AL = OFF_PS + 4 * 4096;         // [qblk 4][32] floats: rescale factor of the tile (at the end: the row sums)
+  constexpr int OFF_QF = OFF_AL + 4 * 32 * 4;       // [qblk 4][ks 8][lane 64] x 16 B: the Q~ fragments (B operand of the scores) -- the S-wave's
+                                                    // registers hold the rebuild's 64 B^T fragments instead
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>(smem);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool swave = w < 4;
+  const int qblk = w & 3;
+  const int n = lane & 31, hi = lane >> 5;
+  int qt_rev, h;
+  if (p.head_major == 2) {   // 8 heads at a time, one per XCD; within them heavy (late) query tiles first (prefill_attn.hip)
+    const int id = blockIdx.x;
+    qt_rev = (id >> 3) % p.nqt;
+    h = ((id >> 3) / p.nqt) * 8 + (id & 7);
+  } else {
+    qt_rev = p.head_major ? blockIdx.y : blockIdx.x;
+    h = p.head_major ? blockIdx.x : blockIdx.y;
+  }
+  const int qt = p.nqt - 1 - qt_rev;
+  const int g = h / p.gs;
+  const int qrow = qt * PL_BM + qblk * 32 + n;
+  const bool qvalid = qrow < p.Tq;
+  const int qpos = p.past + qrow;
+
+  int kv_end = p.Tk;
+  if (p.causal) {
+    const int last_q = min(p.Tq, (qt + 1) * PL_BM) - 1;
+    kv_end = min(p.Tk, p.past + last_q + 1);
+  }
+  const int njt = (kv_end + PL_BN - 1) / PL_BN;
+
+  // ---- staging by LDS-DMA (buffer_load_dwordx4 ... lds): a wave-instruction fills 64 consecutive 16-byte LDS slots, the
+  //      swizzle sits in the per-lane SOURCE offset, tile / piece selection is scalar
+  auto make_rsrc = [](const void* base, int64_t bytes) {
+    u32x4 r;
+    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+    r[0] = __builtin_amdgcn_readfirstlane((unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+    r[2] = __builtin_amdgcn_readfirstlane((unsigned)bytes);
+    r[3] = 0x00020000u;
+    return r;
+  };
+  const h16* xkg = p.xk + (int64_t)g * p.sxk_g;
+  const h16* xvg = p.xv + (int64_t)g * p.sxv_g;
+  const u32x4 xrs = make_rsrc(xkg, ((int64_t)(p.Tk - 1) * p.sxk_l + 128) * 2);
+  const u32x4 vrs = make_rsrc(xvg, ((int64_t)(p.Tk - 1) * p.sxv_l + RV) * 2);
+  auto dma = [&](unsigned dst, unsigned voff, const u32x4& rs, unsigned soff) {
+    asm volatile(
+        "s_mov_b32 m0, %0\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %3 offen lds"
+        :
+        : "s"(dst), "v"(voff), "s"(rs), "s"(soff)
+        : "memory");
+  };
+  // X tile: piece (w + 8 i) = rows 4 (w + 8 i) .. + 3, 16 chunks each (rows past Tk are outside the descriptor: their scores are masked)
+  const int xrow_l = 4 * w + (lane >> 4);
+  const unsigned xvo = (unsigned)((xrow_l * p.sxk_l + (((lane & 15) ^ (xrow_l & 15)) << 3)) * 2);
+  const unsigned xtile_bytes = __builtin_amdgcn_readfirstlane((unsigned)(PL_BN * p.sxk_l * 2));
+  const unsigned xstep_bytes = __builtin_amdgcn_readfirstlane((unsigned)(32 * p.sxk_l * 2));
+  auto dma_x = [&](int jt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_XS + (w + 8 * i) * 1024), xvo, xrs,
+          __builtin_amdgcn_readfirstlane((unsigned)jt * xtile_bytes + i * xstep_bytes));
+  };
+  // V half tile: wave w stages rows 4 w' .. of each group of 4 rows it owns: piece k = VPW w + i covers LDS slots
+  // [64 k, 64 k + 64); slot s: row s / SPR, 16-byte slot s % SPR of the row; LDS granule (32 B) gl of row r holds source granule
+  // gl ^ (r & 3).  VPW pieces = (VPW * 64 / SPR) whole rows, a multiple of 4: the pattern of a piece is a lane constant.
+  constexpr int SPR = RVB / 16;                     // 16-byte slots per row
+  unsigned vvo[VPW];
+#pragma unroll
+  for (int i = 0; i < VPW; ++i) {
+    const int s = (VPW * w + i) * 64 + lane;
+    const int r = s / SPR, sr = s % SPR;
+    vvo[i] = (unsigned)(r * (int)(p.sxv_l * 2) + ((((sr >> 1) ^ (r & 3)) << 1) + (sr & 1)) * 16);
+  }
+  const unsigned vhalf_bytes = __builtin_amdgcn_readfirstlane((unsigned)(32 * p.sxv_l * 2));
+  auto dma_v = [&](int jt, int half) {              // half tile (jt, half) into slot `half`
+    const int row0 = jt * PL_BN + 32 * half;
+    if (row0 + 32 <= p.Tk) {
+#pragma unroll
+      for (int i = 0; i < VPW; ++i)
+        dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_VS + half * VH_BYTES + (VPW * w + i) * 1024), vvo[i], vrs,
+            __builtin_amdgcn_readfirstlane((unsigned)(2 * jt + half) * vhalf_bytes));
+    } else {
+      // the cache's last rows: rows past Tk re-read row Tk - 1 (finite data; their probabilities are exactly zero)
+#pragma unroll
+      for (int i = 0; i < VPW; ++i) {
+        const int s = (VPW * w + i) * 64 + lane;
+        const int r = s / SPR, sr = s % SPR;
+        const int row = min(row0 + r, p.Tk - 1);
+        dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_VS + half * VH_BYTES + (VPW * w + i) * 1024),
+            (unsigned)(row * (int)(p.sxv_l * 2) + ((((sr >> 1) ^ (r & 3)) << 1) + (sr & 1)) * 16), vrs, 0u);
+      }
+    }
+  };
+  auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+  // ================================================================================================ S-wave state
+  // Q~ fragments (B operand of S^T): lane (t, hi) holds Q~[t][16 ks + 8 hi .. + 7]; parked in LDS (this wave's own 8 KB)
+  const unsigned qfa = lds0 + OFF_QF + (unsigned)((qblk * 8 * 64 + lane) * 16);
+  // B_h^T fragments of this wave's 64 rows (A operand of the rebuild), two M-blocks mbk: MFMA row m = 8 a + 4 hb + b  <->
+  // d = 32 dh + 16 mbk + 8 (a & 1) + 4 hb + b + 64 (a >> 1): after the MFMA lane (kv, hi) holds register 4 a + b = K[kv][d(a, hi, b)] --
+  // both halves of 8 RoPE pairs per M-block
+  h16x8 af[2][8];
+  h16x4 cs_c[2][2], cs_s[2][2];                       // rotary values of this lane's kv row of the tile rebuilt next: [mbk][a1] x 4 pairs
+  float m_run = -INFINITY, l_run = 0.f;
+  const int kvh = w & 1, dh = (w >> 1) & 1;
+  if (swave) {
+    const h16* qp = p.q + (int64_t)h * p.sq_h + (int64_t)(qvalid ? qrow : 0) * p.sq_t + 8 * hi;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      u32x4 v = *reinterpret_cast<const u32x4*>(qp + 16 * ks);
+      if (!qvalid) v = u32x4{0, 0, 0, 0};
+      *(lds_h16x8_t*)(uintptr_t)(qfa + (unsigned)(ks * 1024)) = __builtin_bit_cast(h16x8, v);
+    }
+    const int a = n >> 3, hb = (n >> 2) & 1, b = n & 3;
+#pragma unroll
+    for (int mbk = 0; mbk < 2; ++mbk) {
+      const int d = 32 * dh + 16 * mbk + 8 * (a & 1) + 4 * hb + b + 64 * (a >> 1);
+      const h16* bp = p.bt + ((int64_t)h * 128 + d) * 128 + 8 * hi;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) af[mbk][ks] = __builtin_bit_cast(h16x8, *reinterpret_cast<const u32x4*>(bp + 16 * ks));
+    }
+  }
+  // K~ A-fragment row of this lane for the scores: bits 2 and 3 of the MFMA row swapped, so that the 8 registers of a k-step
+  // hold 8 CONSECUTIVE kv positions (prefill_attn.hip)
+  const int krow = (n & 0x13) | ((n & 4) << 1) | ((n & 8) >> 1);
+
+  // rotary values for the rebuild of tile jt: requested a phase ahead (plain loads; the phase's vmcnt(0) covers them)
+  auto load_cs = [&](int jt) {
+    const int pos = min(jt * PL_BN + 32 * kvh + n, p.Tk - 1);
+    const h16* cr = p.cs + (int64_t)pos * 128 + 32 * dh + 4 * hi;
+#pragma unroll
+    for (int mbk = 0; mbk < 2; ++mbk)
+#pragma unroll
+      for (int a1 = 0; a1 < 2; ++a1) {
+        cs_c[mbk][a1] = *reinterpret_cast<const h16x4*>(cr + 16 * mbk + 8 * a1);
+        cs_s[mbk][a1] = *reinterpret_cast<const h16x4*>(cr + 64 + 16 * mbk + 8 * a1);
+      }
+  };
+  // rebuild of this wave's quarter of K~ tile jt from the X tile in LDS: 8 B-fragment reads, 16 MFMAs, fp16 rounding (the
+  // reference's reconstruct GEMM rounds K to fp16, :67-77), rotation with fp16 cos / sin and fp16 products / sum (HF
+  // apply_rotary_pos_emb on fp16 tensors, :204-205; rope.hip's arithmetic), 8 x 8 bytes per lane into tile image jt & 1
+  auto build = [&](int jt) {
+    const int row = 32 * kvh + n;                                       // this lane's kv row of the tile (B-operand column)
+    const unsigned xbase = lds0 + OFF_XS + (unsigned)(row * 256 + ((hi ^ (row & 15)) << 4));
+    const unsigned kbase = lds0 + OFF_KS + (unsigned)((jt & 1) * KS_BYTES + row * 256 + ((row & 15) << 4) + 8 * hi);
+    f32x16 kacc[2];
+#pragma unroll
+    for (int mbk = 0; mbk < 2; ++mbk)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) kacc[mbk][e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const h16x8 xf = *(const lds_h16x8_t*)(uintptr_t)(xbase ^ (unsigned)(ks << 5));     // chunk (2 ks + hi) ^ (row & 15)
+      kacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][ks], xf, kacc[0], 0, 0, 0);
+      kacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][ks], xf, kacc[1], 0, 0, 0);
+    }
+#pragma unroll
+    for (int mbk = 0; mbk < 2; ++mbk) {
+      h16x4 k4[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) k4[a][b] = (h16)kacc[mbk][4 * a + b];
+#pragma unroll
+      for (int a1 = 0; a1 < 2; ++a1) {
+#pragma clang fp contract(off)   // two fp16 products and one fp16 sum, never an fma (rope.hip)
+        const h16x4 lo = k4[a1], hh = k4[a1 + 2];
+        const h16x4 olo = lo * cs_c[mbk][a1] + (-hh) * cs_s[mbk][a1];
+        const h16x4 ohi = hh * cs_c[mbk][a1] + lo * cs_s[mbk][a1];
+        // d = 32 dh + 16 mbk + 8 a1 + 4 hi + b (+ 64): 16-byte chunk 4 dh + 2 mbk + a1 (+ 8), bytes 8 hi .. 8 hi + 7
+        *(lds_h16x4_t*)(uintptr_t)(kbase ^ (unsigned)((4 * dh + 2 * mbk + a1) << 4)) = olo;
+        *(lds_h16x4_t*)(uintptr_t)(kbase ^ (unsigned)((4 * dh + 2 * mbk + a1 + 8) << 4)) = ohi;
+      }
+    }
+  };
+
+  // scores + online softmax of tile jt in two parts (the workgroup's mid-tile barrier lies between them): part 1 = the score MFMAs,
+  // mask, running maximum, rescale factor and the probabilities of the tile's first 32 positions; part 2 = the other 32 and the
+  // running sum.  Probabilities (fp16, B-operand order) and the rescale factor go to LDS buffer jt & 1.
+  f32x16 sacc[2];
+  float sm_moff = 0.f, sm_alpha = 1.f, sm_lsum = 0.f;
+  auto softmax_rows = [&](int jt, auto rb_c) {
+    constexpr int rb = decltype(rb_c)::value;
+    const unsigned pdst = lds0 + OFF_PS + (unsigned)((qblk * 4) * 1024 + lane * 16);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      h16x8 pk;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+#if PL_EXP & 2
+        const float pv = fmaf(sacc[rb][8 * s2 + e], p.scale_log2, sm_moff);
+#else
+        const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[rb][8 * s2 + e], p.scale_log2, sm_moff));
+#endif
+        sm_lsum += pv;
+        pk[e] = (h16)pv;
+      }
+      *(lds_h16x8_t*)(uintptr_t)(pdst + (unsigned)((2 * rb + s2) * 1024)) = pk;
+    }
+  };
+  auto scores_part1 = [&](int jt) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sacc[rb][e] = 0.f;
+      const int row = rb * 32 + krow;
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        const h16x8 kf = *(const lds_h16x8_t*)(uintptr_t)(lds0 + OFF_KS + (jt & 1) * KS_BYTES + row * 256 + (((2 * kk + hi) ^ (row & 15)) << 4));
+        const h16x8 qk = *(const lds_h16x8_t*)(uintptr_t)(qfa + (unsigned)(kk * 1024));
+        sacc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qk, sacc[rb], 0, 0, 0);
+      }
+    }
+    // register r of block rb in lane (t, hi) is kv = jt*64 + 32 rb + 16 (r >> 3) + 8 hi + (r & 7)
+    const int j0 = jt * PL_BN + 8 * hi;
+    const bool need_mask = (jt * PL_BN + PL_BN > p.Tk) || (p.causal && jt * PL_BN + PL_BN - 1 > p.past + qt * PL_BM + qblk * 32);
+    if (need_mask) {
+      const int lim = p.causal ? min(p.Tk - 1, qpos) : p.Tk - 1;
+#pragma unroll
+      for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = j0 + 32 * rb + 16 * (r >> 3) + (r & 7);
+          if (j > lim) sacc[rb][r] = -INFINITY;
+        }
+    }
+    float mloc = sacc[0][0];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, sacc[rb][r]);
+    {
+      const unsigned mb = __float_as_uint(mloc);
+      auto sw = __builtin_amdgcn_permlane32_swap(mb, mb, false, false);   // both halves of query t see both maxima
+      mloc = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    const float m_new = fmaxf(m_run, mloc);
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;                // fully masked so far (padding rows)
+    sm_alpha = __builtin_amdgcn_exp2f((m_run - m_use) * p.scale_log2);     // m_run = -inf -> 0
+    sm_moff = -m_use * p.scale_log2;
+    sm_lsum = 0.f;
+    m_run = m_new;
+    if (hi == 0) *(lds_f32_t*)(uintptr_t)(lds0 + OFF_AL + (unsigned)((qblk * 32 + n) * 4)) = sm_alpha;
+    softmax_rows(jt, std::integral_constant<int, 0>{});
+  };
+  auto scores_part2 = [&](int jt) {
+    softmax_rows(jt, std::integral_constant<int, 1>{});
+    l_run = fmaf(l_run, sm_alpha, sm_lsum);
+  };
+
+  // ================================================================================================ O-wave state
+  f32x16 acc_o[NCB];                                  // (zeroed at the top of the O-wave's branch)
+  // transpose-read address of this lane inside a half tile (k-step 0, first 4 rows): 16-lane group j = lane >> 4 covers columns
+  // 16 (j & 1) .. + 15 of a 32-column block for the k-half kg = j >> 1; lane i of the group reads 8 bytes of row 8 kg + (i >> 2)
+  // at columns 4 (i & 3) .. + 3 and receives column i's four rows.  Granule of (cb, j & 1): 2 cb + (j & 1), XOR (row & 3) = i >> 2
+  // on its low two bits (even / odd cb differ in bit 1: two lane constants), the rest rides in the instruction offsets.
+  const int tj = lane >> 4, ti = lane & 15;
+  const unsigned tbase = lds0 + OFF_VS + (unsigned)((8 * (tj >> 1) + (ti >> 2)) * RVB + 8 * (ti & 3));
+  const unsigned tr_e = tbase + (unsigned)((((tj & 1)) ^ (ti >> 2)) * 32);
+  const unsigned tr_o = tbase + (unsigned)((((2 + (tj & 1))) ^ (ti >> 2)) * 32);
+  auto pv_half = [&](auto half_c) {         // O^T += V^T(jt, half) . P^T(jt, half): k-steps 2 half, 2 half + 1
+    constexpr int half = decltype(half_c)::value;
+    const unsigned psrc = lds0 + OFF_PS + (unsigned)((qblk * 4) * 1024 + lane * 16);
+    if (half == 0) {
+      const float al = *(const lds_f32_t*)(uintptr_t)(lds0 + OFF_AL + (unsigned)((qblk * 32 + n) * 4));
+      if (__builtin_amdgcn_ballot_w64(al != 1.0f) != 0) {                // wave-uniform: rescale only when a maximum moved
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc_o[cb][e] *= al;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const h16x8 pf = *(const lds_h16x8_t*)(uintptr_t)(psrc + (unsigned)((2 * half + s) * 1024));
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        // (constant offsets on an LDS pointer: they ride in the instructions' offset fields instead of 24 address registers)
+        typedef __attribute__((address_space(3))) char lds_char;
+        lds_char* ap = (lds_char*)(uintptr_t)((cb & 1) ? tr_o : tr_e) + (half * VH_BYTES + s * 16 * RVB + (cb >> 1) * 128);
+        const h16x4 lo = __builtin_bit_cast(h16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((pvm::lds_s16x4*)ap));
+        const h16x4 hh = __builtin_bit_cast(h16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((pvm::lds_s16x4*)(ap + 4 * RVB)));
+        const h16x8 vf = __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
+#if !(PL_EXP & 4)
+        acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, acc_o[cb], 0, 0, 0);
+#else
+        acc_o[cb][0] += (float)vf[0] + (float)pf[0];
+#endif
+        // (192 accumulators leave ~50 registers: keep hipcc from hoisting every fragment of the k-step in front of its MFMAs)
+        if (cb % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
+  // ================================================================================================ pipeline
+  // (the two roles run their own copy of the loop -- same barriers, same DMA schedule -- so that the S-wave's operand fragments
+  //  and the O-wave's 192 accumulators never share a live range: the kernel needs max(S, O) registers, not their sum)
+  if (njt > 0) {
+    dma_x(0);
+    if (swave) load_cs(0);
+    dma_wait();
+    if (swave) {
+#pragma unroll
+      for (int mbk = 0; mbk < 2; ++mbk)
+        asm volatile("" : "+v"(cs_c[mbk][0]), "+v"(cs_c[mbk][1]), "+v"(cs_s[mbk][0]), "+v"(cs_s[mbk][1]));
+    }
+  }
+  __syncthreads();
+  if (swave && njt > 0) build(0);
+  __syncthreads();                                    // K~(0) visible, the X buffer free
+  // The O-wave runs half a tile behind the S-wave: alpha(jt) = second half of P.V of tile jt - 1, beta(jt) = first half of tile jt
+  // (whose probabilities the S-wave wrote in alpha(jt)) -- so one probability buffer serves, each k-step pair written in one phase
+  // and read in the next.
+  auto stage_alpha = [&](int jt) {
+    if (jt + 1 < njt) dma_x(jt + 1);                  // consumed by the rebuild in phase beta
+    if (jt < njt) dma_v(jt, 0);                       // consumed in phase beta (slot 0 was read in the last phase beta)
+  };
+  auto stage_beta = [&](int jt) {
+    if (jt < njt) dma_v(jt, 1);                       // consumed in the next phase alpha (slot 1 was read in this one)
+  };
+  if (swave) {
+    for (int jt = 0; jt <= njt; ++jt) {               // iteration njt only drains the last tile's P.V
+      stage_alpha(jt);                                // ---- phase alpha: scores of tile jt, first half of its softmax
+      if (jt + 1 < njt) load_cs(jt + 1);
+      if (jt < njt) scores_part1(jt);
+      dma_wait();
+      // (hipcc's own wait for the rotary loads goes HERE, where nothing is in flight: placed in front of their first use it
+      //  would be a vmcnt(0) behind the next phase's DMA requests)
+#pragma unroll
+      for (int mbk = 0; mbk < 2; ++mbk)
+        asm volatile("" : "+v"(cs_c[mbk][0]), "+v"(cs_c[mbk][1]), "+v"(cs_s[mbk][0]), "+v"(cs_s[mbk][1]));
+      __syncthreads();
+      stage_beta(jt);                                 // ---- phase beta: second half, then the rebuild of K~ tile jt + 1 (other image)
+      if (jt < njt) scores_part2(jt);
+#if !(PL_EXP & 1)
+      if (jt + 1 < njt) build(jt + 1);
+#endif
+      dma_wait();
+      __syncthreads();
+    }
+    // the row sums (both hi halves) for the O-wave
+    const unsigned lb = __float_as_uint(l_run);
+    auto sw = __builtin_amdgcn_permlane32_swap(lb, lb, false, false);
+    const float l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+    if (hi == 0) *(lds_f32_t*)(uintptr_t)(lds0 + OFF_AL + (unsigned)((qblk * 32 + n) * 4)) = l_tot;
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc_o[cb][e] = 0.f;
+    for (int jt = 0; jt <= njt; ++jt) {
+      stage_alpha(jt);                                // ---- phase alpha: second half of P.V of tile jt - 1
+      if (jt >= 1) pv_half(std::integral_constant<int, 1>{});
+      dma_wait();
+      __syncthreads();
+      stage_beta(jt);                                 // ---- phase beta: rescale, first half of tile jt
+      if (jt < njt) pv_half(std::integral_constant<int, 0>{});
+      dma_wait();
+      __syncthreads();
+    }
+    __syncthreads();
+    // ---- epilogue: normalise and store fp16; lane (t, hi) register r of block cb is column 32 cb + (r & 3) + 8 (r >> 2) + 4 hi
+    const float l_tot = *(const lds_f32_t*)(uintptr_t)(lds0 + OFF_AL + (unsigned)((qblk * 32 + n) * 4));
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    if (qvalid) {
+      h16* op = p.out + (int64_t)qrow * p.so_t + (int64_t)h * RV + 4 * hi;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+        for (int r2 = 0; r2 < 4; ++r2) {
+          h16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = (h16)(acc_o[cb][4 * r2 + e] * inv);
+          *reinterpret_cast<h16x4*>(op + 32 * cb + 8 * r2) = o;
+        }
+    }
+  }
+}
+
+// cos / sin of the key positions as the reference's rotary cache holds them (kernel/palu_attention.py:204: rotary_emb; HF
+// LlamaRotaryEmbedding: angle = fl32(pos) * inv_freq in fp32, cos / sin in fp32, cast to the activation dtype): [pos][2][64] fp16
+__global__ void rope_cs_table_kernel(const float* __restrict__ inv_freq, int pos0, int npos, h16* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= npos * 64) return;
+  const int t = idx >> 6, i = idx & 63;
+  const float ang = (float)(pos0 + t) * inv_freq[i];
+  float sn, cs;
+  sincosf(ang, &sn, &cs);
+  out[(int64_t)t * 128 + i] = (h16)cs;
+  out[(int64_t)t * 128 + 64 + i] = (h16)sn;
+}
+
+template <int NCB>
+int launch_prefill_lat(const PfLatParams& p, hipStream_t stream) {
+  constexpr int smem = 3 * PL_BN * 256 + 2 * 32 * 64 * NCB + 4 * 4096 + 4 * 32 * 4 + 32 * 1024;
+  auto kern = prefill_lat_kernel<NCB>;
+  const int rca = palu_func_max_lds(reinterpret_cast<const void*>(kern), smem);
+  if (rca) return rca;
+  dim3 grid(p.head_major == 2 ? p.H * p.nqt : (p.head_major ? p.H : p.nqt), p.head_major == 2 ? 1 : (p.head_major ? p.nqt : p.H), 1);
+  hipLaunchKernelGGL(kern, grid, dim3(PL_THREADS), smem, stream, p);
+  PALU_LAUNCH_CHECK();
+  return PALU_OK;
+}
+
+}  // namespace
+
+extern "C" size_t palu_rope_cs_table_bytes(int npos) { return npos > 0 ? (size_t)npos * 128 * sizeof(h16) : 0; }
+
+extern "C" int palu_rope_cs_table_build(const float* inv_freq, int pos0, int npos, void* table, palu_stream_t stream) {
+  PALU_REQUIRE(inv_freq && table && pos0 >= 0 && npos > 0 && (int64_t)pos0 + npos < (1 << 24), PALU_ERR_ARG,
+               "rope_cs_table_build: bad arguments");
+  PALU_REQUIRE(((uintptr_t)table & 15) == 0, PALU_ERR_ARG, "rope_cs_table_build: table must be 16-byte aligned");
+  hipLaunchKernelGGL(rope_cs_table_kernel, dim3((unsigned)((npos * 64 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, inv_freq,
+                     pos0, npos, (h16*)table);
+  PALU_LAUNCH_CHECK();
+  return PALU_OK;
+}
+
+extern "C" int palu_prefill_attn_lat_supported(int H, int G, int D, int Rk, int Rv) {
+  return (H > 0 && G > 0 && H % G == 0 && D == 128 && Rk == 128 && (Rv == 384 || Rv == 256 || Rv == 128)) ? 1 : 0;
+}
+
+// Prompt attention of Tq queries (rotated, [H][Tq][128]; the first at absolute position `past`) over the first Tk rows of the
+// latent caches xk [G][.][128], xv [G][.][Rv] (fp16, row l = position l, 16-byte aligned rows); bt = B^T [H][128][128] contiguous;
+// cs = palu_rope_cs_table_build(inv_freq, 0, >= Tk).  out [Tq][H * Rv] fp16.  No workspace.
+extern "C" int palu_prefill_attn_lat_f16(const void* q, int64_t sq_h, int64_t sq_t, const void* xk, int64_t sxk_g, int64_t sxk_l,
+                                         const void* xv, int64_t sxv_g, int64_t sxv_l, const void* bt, const void* cs, void* out,
+                                         int64_t so_t, int H, int G, int D, int Tq, int Tk, int Rk, int Rv, int past, int causal,
+                                         float scale, palu_stream_t stream) {
+  PALU_REQUIRE(q && xk && xv && bt && cs && out, PALU_ERR_ARG, "prefill_attn_lat: null pointer");
+  PALU_REQUIRE(palu_prefill_attn_lat_supported(H, G, D, Rk, Rv), PALU_ERR_UNSUPPORTED,
+               "prefill_attn_lat: needs head_dim 128, rank_k / G = 128, rank_v / G in {128, 256, 384} (H=%d G=%d D=%d Rk=%d Rv=%d)", H, G, D,
+               Rk, Rv);
+  PALU_REQUIRE(Tq >= 0 && Tk >= 0 && past >= 0 && (int64_t)past + Tq < (1 << 30), PALU_ERR_ARG, "prefill_attn_lat: bad lengths");
+  if (Tq == 0) return PALU_OK;
+  PALU_REQUIRE(Tk > 0, PALU_ERR_ARG, "prefill_attn_lat: no keys");
+  PALU_REQUIRE(scale > 0.f, PALU_ERR_ARG, "prefill_attn_lat: scale must be positive");
+  PALU_REQUIRE((((uintptr_t)q | (uintptr_t)xk | (uintptr_t)xv | (uintptr_t)bt | (uintptr_t)cs) & 15) == 0 && sq_h % 8 == 0 &&
+                   sq_t % 8 == 0 && sxk_g % 8 == 0 && sxk_l % 8 == 0 && sxv_g % 8 == 0 && sxv_l % 8 == 0 && sxk_l >= Rk &&
+                   sxv_l >= Rv && ((uintptr_t)out & 7) == 0 && so_t % 4 == 0,
+               PALU_ERR_ARG, "prefill_attn_lat: rows must be 16-byte aligned (out 8-byte)");
+  PALU_REQUIRE(((int64_t)Tk + PL_BN) * sxk_l * 2 < ((int64_t)1 << 32) && ((int64_t)Tk + PL_BN) * sxv_l * 2 < ((int64_t)1 << 32),
+               PALU_ERR_UNSUPPORTED, "prefill_attn_lat: one group's latent slab must stay below 4 GiB");
+  PfLatParams p;
+  p.q = (const h16*)q; p.sq_h = sq_h; p.sq_t = sq_t;
+  p.xk = (const h16*)xk; p.sxk_g = sxk_g; p.sxk_l = sxk_l;
+  p.xv = (const h16*)xv; p.sxv_g = sxv_g; p.sxv_l = sxv_l;
+  p.bt = (const h16*)bt; p.cs = (const h16*)cs;
+  p.out = (h16*)out; p.so_t = so_t;
+  p.H = H; p.G = G; p.gs = H / G; p.Tq = Tq; p.Tk = Tk; p.past = past; p.causal = causal ? 1 : 0;
+  p.scale_log2 = scale * 1.4426950408889634f;
+  p.nqt = (Tq + PL_BM - 1) / PL_BM;
+  p.head_major = (int64_t)p.nqt * H <= 2048 ? 1 : 2;
+  if (p.head_major == 2 && H % 8 != 0) p.head_major = 0;
+  hipStream_t s = (hipStream_t)stream;
+  switch (Rv / 32) {
+    case 4: return launch_prefill_lat<4>(p, s);
+    case 8: return launch_prefill_lat<8>(p, s);
+    default: return launch_prefill_lat<12>(p, s);
+  }
+}
