@@ -35,6 +35,27 @@ def rope_inv_freq(device, head_dim: int = 128, theta: float = 10000.0) -> torch.
     return t
 
 
+_cs_tables = {}
+
+
+def rope_cs_table(device, head_dim: int, theta: float, npos: int) -> torch.Tensor:
+    """The rotary cache of the key positions 0 .. npos - 1 as the latent prefill kernel reads it (csrc/prefill_lat.hip):
+    [pos][cos 64 | sin 64] fp16 with HF's arithmetic (fp32 angle fl32(pos) * inv_freq, fp32 cos / sin, cast to fp16: the
+    `cos_cached` / `sin_cached` of LlamaRotaryEmbedding, kernel/palu_attention.py:204).  One per (device, theta), grown in steps of
+    4096 positions and kept (16 MiB at 64k positions) -- persistent like HF's cache, not a transient of a prompt pass."""
+    key = (str(device), head_dim, float(theta))
+    t = _cs_tables.get(key)
+    if t is None or t.shape[0] < npos:
+        n = (npos + 4095) // 4096 * 4096
+        inv = rope_inv_freq(device, head_dim, theta)
+        with _lib.on_device(inv):
+            t = torch.empty((n, head_dim), dtype=torch.float16, device=inv.device)
+            _lib.check(_lib.lib.palu_rope_cs_table_build(inv.data_ptr(), 0, n, t.data_ptr(), _lib.current_stream()),
+                       "palu_rope_cs_table_build")
+        _cs_tables[key] = t
+    return t
+
+
 ROPE_TABLE_POSITIONS = (1 << 18) + 4096      # what the two-band score kernels cover (csrc/abx_rope2.hip): a 256k prompt + 4096 generated tokens; 2.6 MB per (device, theta)
 _rope_tables = {}
 

@@ -28,7 +28,7 @@ from torch import nn
 
 from .. import _lib
 from .abx_rope import abx as recompute_k_gemv  # same alias as kernel/palu_attention.py:13
-from .abx_rope import invalidate_b, prepare_b, rope_inv_freq, shared_b
+from .abx_rope import invalidate_b, prepare_b, rope_cs_table, rope_inv_freq, shared_b
 
 __all__ = ["HeadwiseLowRankModule", "LlamaPaluAttention", "LatentCache", "QuantLatentCache", "DynamicCache",
            "build_b", "fuse_wo"]
@@ -785,6 +785,75 @@ class LlamaPaluAttention(nn.Module):
     PREFILL_PANEL_QUERY = 512
     PREFILL_PANEL_GROUPS = 4
 
+    # The LATENT form of the prompt pass (round 6, csrc/prefill_lat.hip): the flash kernel rebuilds
+    # K~ = RoPE(X_k . B_h) per 64-position kv tile itself and reads the latent values from the cache rows -- no [H, kv, D] key
+    # workspace, no transposed value copy: the only transients are the rotated queries and context rows of ONE query chunk
+    # (2 t H (D + Rv) bytes: 64 MiB at PREFILL_LATENT_QUERY_CHUNK = 2048 and the config-2 ranks), whatever the prompt length.  It costs
+    # the rebuild's +25 % of matrix work (64k tokens: ~105 ms against ~82 ms for the one-launch workspace form with its 2.4 GiB of
+    # transients), so it is selected when the workspace form would exceed PREFILL_LATENT_ABOVE bytes of transients; 0 = always,
+    # None = never.  fp16 caches at head_dim 128, rank_k / G = 128, rank_v / G in {128, 256, 384}.
+    PREFILL_LATENT_ABOVE = 256 << 20
+    PREFILL_LATENT_QUERY_CHUNK = 2048
+
+    def _bt_fragments(self):
+        """B^T [H, D, Rk] contiguous (row d of head h = the weights that rebuild K[., d]): cached like the abx fragments."""
+        b = self.k_proj.B
+        hit = getattr(self, "_bt_cache", None)
+        if hit is not None and hit[0] == (b._version, b.data_ptr()):
+            return hit[1]
+        bt = b.detach().transpose(1, 2).contiguous()
+        self._bt_cache = ((b._version, b.data_ptr()), bt)
+        return bt
+
+    def _prefill_latent(self, hidden_states, pos, cache, causal: bool):
+        """Prompt branch (:196-257) in query chunks on palu_prefill_attn_lat_f16: projections of the chunk (latents straight
+        into the cache rows), rotation of q, attention over the cache rows 0 .. kv - 1, o_proj of the chunk."""
+        H, G, D = self.num_heads, self.num_groups, self.head_dim
+        Rk, Rv = self.group_rank_k, self.group_rank_v
+        q_len = hidden_states.shape[1]
+        li = self.layer_idx
+        past = cache.get_seq_length(li)
+        dev, dt = hidden_states.device, hidden_states.dtype
+        kv_all = past + q_len
+        qc = max(128, int(self.PREFILL_LATENT_QUERY_CHUNK))
+        inv = rope_inv_freq(dev, D, self.rope_theta)
+        cs = rope_cs_table(dev, D, self.rope_theta, kv_all)
+        bt = self._bt_fragments()
+        stream = _lib.current_stream()
+        p0 = int(pos.reshape(-1)[0])
+        all_first = (not causal) and q_len > qc        # no mask: every query attends every key of the pass (see _prefill_flash)
+        if all_first:
+            for c0 in range(0, q_len, qc):
+                self._project_into_cache(hidden_states[:, c0:min(q_len, c0 + qc)], cache)
+        out = None
+        for c0 in range(0, q_len, qc):
+            c1 = min(q_len, c0 + qc)
+            t = c1 - c0
+            hs = hidden_states[:, c0:c1]
+            q = self.q_proj(hs).view(t, H, D).transpose(0, 1)                             # [H,t,D] view of [t, H*D]
+            if not all_first:
+                self._project_into_cache(hs, cache)
+            kv = kv_all if all_first else past + c1
+            _lib.check(_lib.lib.palu_rope_f16(q.data_ptr(), q.stride(0), q.stride(1), H, t, D, p0 + c0, inv.data_ptr(), stream),
+                       "palu_rope_f16")
+            kbuf, vbuf = cache.buffers(li)
+            ctx = torch.empty((t, H * Rv), dtype=dt, device=dev)
+            _lib.check(_lib.lib.palu_prefill_attn_lat_f16(q.data_ptr(), q.stride(0), q.stride(1), kbuf.data_ptr(), kbuf.stride(1),
+                                                          kbuf.stride(2), vbuf.data_ptr(), vbuf.stride(1), vbuf.stride(2),
+                                                          bt.data_ptr(), cs.data_ptr(), ctx.data_ptr(), ctx.stride(0), H, G, D, t, kv,
+                                                          Rk, Rv, past + c0, 1 if causal else 0, 1.0 / math.sqrt(D), stream),
+                       "palu_prefill_attn_lat_f16")
+            o = self.o_proj(ctx)
+            del ctx, q
+            if c0 == 0 and c1 == q_len:
+                out = o
+            else:
+                if out is None:
+                    out = torch.empty((q_len, o.shape[-1]), dtype=o.dtype, device=dev)
+                out[c0:c1].copy_(o)
+            del o
+        return out.view(1, q_len, -1)
+
     def _prefill_flash(self, hidden_states, pos, cache, causal: bool):
         """Prompt branch (:196-257) on the flash-style HIP kernel: scores are never materialised.
 
@@ -807,6 +876,13 @@ class LlamaPaluAttention(nn.Module):
         packed = not isinstance(cache, LatentCache)
         if packed:
             one_launch_bytes += 2 * kv_all * G * (Rk + Rv)          # the dequantised rows
+        lat_above = self.PREFILL_LATENT_ABOVE
+        pos_flat = pos.reshape(-1)
+        if (lat_above is not None and not packed and panel_rows == 0 and one_launch_bytes > lat_above and dt == torch.float16
+                and self.n_rep == 1 and _lib.lib.palu_prefill_attn_lat_supported(H, G, D, Rk, Rv)
+                and bool((pos_flat == torch.arange(int(pos_flat[0]), int(pos_flat[0]) + q_len, device=pos_flat.device)).all())
+                and self.q_proj.weight.dtype == dt):
+            return self._prefill_latent(hidden_states, pos, cache, causal)
         grouped = one_launch_bytes > self.PREFILL_WORKSPACE_BUDGET or panel_rows > 0
         qc = self.PREFILL_QUERY_CHUNK if grouped else q_len
         if panel_rows > 0:

@@ -111,3 +111,95 @@ def test_latent_prefill_rejects_unsupported_shapes():
     rc = lib.palu_prefill_attn_lat_f16(t.data_ptr(), 128, 128, t.data_ptr(), 128, 128, t.data_ptr(), 192, 192, t.data_ptr(), t.data_ptr(),
                                        t.data_ptr(), 192, 4, 1, 128, 1, 1, 64, 192, 0, 1, 0.1, torch.cuda.current_stream().cuda_stream)
     assert rc != 0
+
+
+# ------------------------------------------------------------------------------------------------- module level
+def _module(hidden, H, gs, Rk, Rv, seed=0):
+    from torch import nn
+    from palu_amd.kernel.palu_attention import LlamaPaluAttention, build_b
+
+    class Cfg:
+        pass
+    cfg = Cfg()
+    G = H // gs
+    cfg.hidden_size, cfg.num_attention_heads, cfg.attention_bias = hidden, H, False
+    cfg.group_size, cfg.num_groups, cfg.total_rank_k, cfg.total_rank_v = gs, G, Rk * G, Rv * G
+    torch.manual_seed(seed)
+    with torch.device(DEV):
+        m = LlamaPaluAttention(cfg, 0).half()
+        with torch.no_grad():
+            for lin in (m.q_proj, m.k_proj.VT, m.v_proj.VT, m.o_proj):
+                lin.weight.normal_(0.0, 0.03)
+            for u in m.k_proj.U_list:
+                u.weight.normal_(0.0, Rk ** -0.5)
+        m.k_proj.B = nn.Parameter(build_b([u.weight for u in m.k_proj.U_list], gs, D))
+    return m.eval().prepare_decode()
+
+
+@pytest.mark.parametrize("causal", [True, False])
+def test_prompt_pass_in_latent_form_equals_workspace_form_and_feeds_decode(causal):
+    """LlamaPaluAttention.forward with the latent kernel forced (PREFILL_LATENT_ABOVE = 0, query chunks of 256 -- and 200, not a
+    multiple of the kernel's 128-query tile) against the workspace form (None): same output, identical cache contents, a second
+    prompt pass on top of the first (past > 0), and a decode step from either cache."""
+    from palu_amd.kernel.palu_attention import LatentCache
+    hidden, H, gs, Rk, Rv, T1, T2 = 1024, 8, 4, 128, 384, 700, 333
+    m = _module(hidden, H, gs, Rk, Rv)
+    x1 = torch.randn(1, T1, hidden, device=DEV, dtype=torch.float16)
+    x2 = torch.randn(1, T2, hidden, device=DEV, dtype=torch.float16)
+    xd = torch.randn(1, 1, hidden, device=DEV, dtype=torch.float16)
+    outs = {}
+    for mode, above, chunk in (("workspace", None, 2048), ("latent", 0, 256), ("latent200", 0, 200)):
+        cache = LatentCache()
+        m.PREFILL_LATENT_ABOVE, m.PREFILL_LATENT_QUERY_CHUNK = above, chunk
+        try:
+            with torch.no_grad():
+                o1, _, _ = m(x1, past_key_value=cache, is_causal=causal)
+                o2, _, _ = m(x2, past_key_value=cache, is_causal=causal, position_ids=torch.arange(T1, T1 + T2).unsqueeze(0))
+                od, _, _ = m(xd, past_key_value=cache, position_ids=torch.tensor([[T1 + T2]]))
+        finally:
+            del m.PREFILL_LATENT_ABOVE, m.PREFILL_LATENT_QUERY_CHUNK
+        outs[mode] = (o1, o2, od, [b[:, :, :T1 + T2 + 1].clone() for b in cache.buffers(0)])
+    ref = outs["workspace"]
+    for mode in ("latent", "latent200"):
+        got = outs[mode]
+        for a, b in zip(got[:3], ref[:3]):
+            torch.testing.assert_close(a.float(), b.float(), rtol=2e-3, atol=2e-3)
+        for a, b in zip(got[3], ref[3]):
+            assert torch.equal(a, b)
+
+
+def test_latent_prompt_pass_needs_128_mib_of_transients_at_32k_tokens():
+    """the prompt pass without the [H, kv, D] key workspace and the transposed value copy.  32k tokens at the
+    config-2 ranks into an fp16 cache: the latent form's transients (rotated queries + context rows of one 2048-query chunk, the
+    chunk's q_proj / o_proj outputs) stay below 128 MiB; the one-launch workspace form needs > 1 GiB; same output."""
+    from palu_amd.kernel.palu_attention import LatentCache
+    hidden, H, gs, Rk, Rv, T = 4096, 32, 4, 128, 384, 32768
+    m = _module(hidden, H, gs, Rk, Rv)
+    x = torch.randn(1, T, hidden, device=DEV, dtype=torch.float16)
+    with torch.no_grad():
+        m(x[:, :256], past_key_value=LatentCache(), is_causal=True)             # warm-up: library handles, fragments, rotary cache
+    from palu_amd.kernel.abx_rope import rope_cs_table
+    rope_cs_table(torch.device(DEV), D, m.rope_theta, T)                         # (persistent, like HF's cos / sin cache)
+
+    def run(above):
+        cache = LatentCache(capacity=T + 512)
+        cache.reserve(0, T + 512, torch.empty((1, H // gs, 0, Rk), dtype=torch.float16, device=DEV),
+                      torch.empty((1, H // gs, 0, Rv), dtype=torch.float16, device=DEV))
+        m.PREFILL_LATENT_ABOVE = above
+        try:
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+            torch.cuda.reset_peak_memory_stats()
+            base = torch.cuda.memory_allocated()
+            with torch.no_grad():
+                out, _, _ = m(x, past_key_value=cache, is_causal=True)
+            torch.cuda.synchronize()
+            extra = torch.cuda.max_memory_allocated() - base - out.numel() * 2
+        finally:
+            del m.PREFILL_LATENT_ABOVE
+        assert cache.get_seq_length(0) == T
+        return out, extra
+    lat, mem_lat = run(0)
+    one, mem_one = run(None)
+    torch.testing.assert_close(lat.float(), one.float(), rtol=2e-3, atol=2e-3)
+    assert mem_lat <= 128 << 20 and mem_one > 1 << 30, (mem_lat / 2 ** 20, mem_one / 2 ** 20)
