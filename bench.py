@@ -392,13 +392,22 @@ def bench_prefill(rank_k, rank_v, T, dev):
     m = m.eval().prepare_decode()
     x = torch.randn(1, T, HIDDEN, device=dev, dtype=torch.float16)
     rec = {"workload": "prompt pass of one attention module, %d tokens, rank_k=%d rank_v=%d gs=%d, causal" % (T, rank_k, rank_v, GS)}
-    for tag, bits, budget in (("fp16_cache", 16, None), ("fp16_cache_bounded_workspace", 16, 0), ("packed_4bit_cache", 4, None),
-                              ("packed_4bit_cache_bounded_workspace", 4, 0), ("packed_4bit_cache_kv_panels", 4, "panels")):
+    # "fp16_cache" = the module's default: from 256 MiB of workspace-form transients on, the LATENT form (csrc/prefill_lat.hip: keys
+    # rebuilt per kv tile inside the flash kernel, V from the cache rows; transients = one 2048-query chunk); "..._workspace_form" =
+    # the one-launch form with its [H, kv, D] key workspace and transposed value copy (PREFILL_LATENT_ABOVE = None)
+    for tag, bits, budget in (("fp16_cache", 16, None), ("fp16_cache_workspace_form", 16, "ws"), ("fp16_cache_bounded_workspace", 16, 0),
+                              ("packed_4bit_cache", 4, None), ("packed_4bit_cache_bounded_workspace", 4, 0),
+                              ("packed_4bit_cache_kv_panels", 4, "panels")):
         mk = (lambda: LatentCache(capacity=T + 512)) if bits >= 16 else (lambda: QuantLatentCache(bits, capacity=T + 512))
         panels = budget == "panels"         # kv panels with carried softmax state: transients independent of T (<= 64 MiB)
         if panels:
             budget = None
             m.PREFILL_PANEL_ROWS = 2048
+        nolat = budget == "ws" or budget == 0
+        if budget == "ws":
+            budget = None
+        if nolat:
+            m.PREFILL_LATENT_ABOVE = None
         if budget is not None:
             m.PREFILL_WORKSPACE_BUDGET = budget
         try:
@@ -436,6 +445,8 @@ def bench_prefill(rank_k, rank_v, T, dev):
                 del m.PREFILL_WORKSPACE_BUDGET
             if panels:
                 del m.PREFILL_PANEL_ROWS
+            if nolat:
+                del m.PREFILL_LATENT_ABOVE
         torch.cuda.empty_cache()
     return rec
 

@@ -448,6 +448,16 @@ int palu_prefill_attn_lat_f16(const void* q, int64_t sq_h, int64_t sq_t, const v
                               const void* xv, int64_t sxv_g, int64_t sxv_l, const void* bt, const void* cs, void* out,
                               int64_t so_t, int H, int G, int D, int Tq, int Tk, int Rk, int Rv, int past, int causal,
                               float scale, palu_stream_t stream);
+/* The same over PACKED 4-bit latent caches (the reference's README.md:24 TODO; values defined by palu/model/modules/quant.py:37-39):
+ * codes [G][>= Tk][R / 2] bytes (byte strides s*c_g, s*c_l), meta [G][>= Tk][2] fp16 (scale, zero) per (token, group) row (element
+ * strides) -- palu_quantize_pack's layout.  The codes are de-quantised inside the kernel with palu_unpack_dequant's arithmetic (keys
+ * in the rebuild's registers, values into the kernel's half-tile image): no fp16 copy of the cache exists.  bt_perm = B^T
+ * [H][128][128] with the columns of every group of 8 in the order 0 4 1 5 2 6 3 7 (the order the nibbles leave a dword).  bits = 4. */
+int palu_prefill_attn_lat_q(const void* q, int64_t sq_h, int64_t sq_t, const void* k_codes, int64_t skc_g, int64_t skc_l,
+                            const void* k_meta, int64_t skm_g, int64_t skm_l, const void* v_codes, int64_t svc_g,
+                            int64_t svc_l, const void* v_meta, int64_t svm_g, int64_t svm_l, const void* bt_perm,
+                            const void* cs, void* out, int64_t so_t, int H, int G, int D, int Tq, int Tk, int Rk, int Rv,
+                            int bits, int past, int causal, float scale, palu_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * One-shot peer-to-peer exchange for the head-group-parallel decode step (the reference is single-GPU and

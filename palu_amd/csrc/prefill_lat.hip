@@ -55,14 +55,25 @@ struct PfLatParams {
   int H, G, gs, Tq, Tk, past, causal;
   float scale_log2;
   int nqt, head_major;
+  // packed 4-bit caches (QB = 4; quant.hip's layout): codes [G][>= Tk][R / 2 bytes], meta [G][>= Tk][2] fp16 (scale, zero) per row;
+  // bt then holds B^T with the columns of every group of 8 in the order 0 4 1 5 2 6 3 7 (the order the nibbles come out of a dword)
+  const unsigned char* kc;
+  int64_t skc_g, skc_l;    // bytes
+  const h16* km;
+  int64_t skm_g, skm_l;    // elements
+  const unsigned char* vc;
+  int64_t svc_g, svc_l;
+  const h16* vm;
+  int64_t svm_g, svm_l;
 };
 
 typedef __attribute__((address_space(3))) h16x8 lds_h16x8_t;
 typedef __attribute__((address_space(3))) h16x4 lds_h16x4_t;
 typedef __attribute__((address_space(3))) float lds_f32_t;
 
-template <int NCB>
+template <int NCB, int QB = 0>
 __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams p) {
+  static_assert(QB == 0 || QB == 4, "fp16 or packed 4-bit latents");
   constexpr int RV = 32 * NCB;
   constexpr int RVB = RV * 2;                       // bytes of a V row
   constexpr int XS_BYTES = PL_BN * 256;             // X tile: 64 rows x 128 fp16 (16 chunks per row, XOR-swizzled by row & 15)
@@ -78,6 +89,9 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
   constexpr int OFF_AL = OFF_PS + 4 * 4096;         // [qblk 4][32] floats: rescale factor of the tile (at the end: the row sums)
   constexpr int OFF_QF = OFF_AL + 4 * 32 * 4;       // [qblk 4][ks 8][lane 64] x 16 B: the Q~ fragments (B operand of the scores) -- the S-wave's
                                                     // registers hold the rebuild's 64 B^T fragments instead
+  constexpr int VC_BYTES = 16 * RV;                 // packed caches: the codes of half a V tile (32 rows x RV / 2 bytes), two of them
+  constexpr int NVC = VC_BYTES / 1024;              // = DMA pieces = waves that de-quantise a half tile (16-byte chunk 64 w + lane)
+  constexpr int OFF_VC = OFF_QF + 32 * 1024;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>(smem);
 
@@ -144,6 +158,54 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
       dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_XS + (w + 8 * i) * 1024), xvo, xrs,
           __builtin_amdgcn_readfirstlane((unsigned)jt * xtile_bytes + i * xstep_bytes));
   };
+  // packed keys: the tile's codes (64 rows x 64 bytes) as 4 pieces of 16 rows, waves 0-3 one each; 16-byte chunk c of row r lands at
+  // chunk position c ^ ((r >> 1) & 3) (the rebuild reads 4 bytes per lane and k-step: rows two apart would share a bank)
+  const u32x4 xqrs = QB ? make_rsrc(p.kc + (int64_t)g * p.skc_g, (int64_t)(p.Tk - 1) * p.skc_l + 64) : xrs;
+  const unsigned xqvo = QB ? (unsigned)((lane >> 2) * (int)p.skc_l + (((lane & 3) ^ ((lane >> 3) & 3)) << 4)) : 0u;
+  auto dma_xq = [&](int jt) {
+    if (w < 4)
+      dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_XS + w * 1024), xqvo, xqrs,
+          __builtin_amdgcn_readfirstlane((unsigned)(jt * PL_BN + 16 * w) * (unsigned)p.skc_l));
+  };
+  // packed values: the codes of half a tile, linear ([row][RV / 2 bytes] as in memory): piece w = 16-byte chunks 64 w .. 64 w + 63; the
+  // lane that de-quantises chunk q = 64 w + lane (row q / NCB, columns 32 (q % NCB) ..) also fetches that row's (scale, zero)
+  const u32x4 vqrs = QB ? make_rsrc(p.vc + (int64_t)g * p.svc_g, (int64_t)(p.Tk - 1) * p.svc_l + RV / 2) : vrs;
+  const int vq_row = (64 * w + lane) / NCB, vq_c = (64 * w + lane) % NCB;
+  unsigned vmeta_next = 0, vmeta_cur = 0;
+  auto vc_issue = [&](int jt, int half) {           // codes of half tile (jt, half) into staging `half` + the row's meta
+    if (QB == 0 || w >= NVC) return;
+    const int row = min(jt * PL_BN + 32 * half + vq_row, p.Tk - 1);     // (rows past Tk re-read row Tk - 1: finite values x probability 0)
+    dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_VC + half * VC_BYTES + w * 1024), (unsigned)(row * (int)p.svc_l + vq_c * 16), vqrs, 0u);
+    vmeta_next = *reinterpret_cast<const unsigned*>(p.vm + (int64_t)g * p.svm_g + (int64_t)row * p.svm_l);
+  };
+  // (a + nb) * s on pairs: a = 0x6400 | code = 1024 + code exactly, nb = -(1024 + zero): the difference is exact, one rounding in the
+  // product -- unpack_dequant's arithmetic (quant.hip; quantize_tensor's `(q - zero) * scale` in fp16, quant.py:37-39)
+  auto deq2 = [](unsigned w2, h16x2 nb2, h16x2 sc2) {
+    h16x2 v = __builtin_bit_cast(h16x2, w2 | 0x64006400u);
+    v = (v + nb2) * sc2;
+    return __builtin_bit_cast(unsigned, v);
+  };
+  auto vc_dequant = [&](int half) {                 // staging `half` -> fp16 row-major image slot `half` (granule-swizzled like the DMA form)
+    if (QB == 0 || w >= NVC) return;
+    const u32x4 cd = *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)(lds0 + OFF_VC + half * VC_BYTES + (64 * w + lane) * 16);
+    const h16x2 m2 = __builtin_bit_cast(h16x2, vmeta_cur);
+    const h16x2 sc2 = h16x2{m2[0], m2[0]};
+    const h16 nb = -((h16)1024.f + m2[1]);
+    const h16x2 nb2 = h16x2{nb, nb};
+    const unsigned rowb = lds0 + OFF_VS + (unsigned)(half * VH_BYTES + vq_row * RVB);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                   // dword j = columns 32 c + 8 j .. + 7 in natural order
+      const unsigned d = cd[j];
+      const unsigned t0 = d & 0x0F0F0F0Fu, t1 = (d >> 4) & 0x0F0F0F0Fu;    // codes 0 2 4 6 / 1 3 5 7 in bytes
+      u32x4 o;
+      o[0] = deq2(__builtin_amdgcn_perm(t1, t0, 0x0c040c00u), nb2, sc2);   // (c0, c1): byte 0 of t0, byte 0 of t1
+      o[1] = deq2(__builtin_amdgcn_perm(t1, t0, 0x0c050c01u), nb2, sc2);
+      o[2] = deq2(__builtin_amdgcn_perm(t1, t0, 0x0c060c02u), nb2, sc2);
+      o[3] = deq2(__builtin_amdgcn_perm(t1, t0, 0x0c070c03u), nb2, sc2);
+      const int gran = 2 * vq_c + (j >> 1);
+      *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(rowb + (unsigned)(((gran ^ (vq_row & 3)) << 5) + 16 * (j & 1))) = o;
+    }
+  };
   // V half tile: wave w stages rows 4 w' .. of each group of 4 rows it owns: piece k = VPW w + i covers LDS slots
   // [64 k, 64 k + 64); slot s: row s / SPR, 16-byte slot s % SPR of the row; LDS granule (32 B) gl of row r holds source granule
   // gl ^ (r & 3).  VPW pieces = (VPW * 64 / SPR) whole rows, a multiple of 4: the pattern of a piece is a lane constant.
@@ -209,8 +271,10 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
   const int krow = (n & 0x13) | ((n & 4) << 1) | ((n & 8) >> 1);
 
   // rotary values for the rebuild of tile jt: requested a phase ahead (plain loads; the phase's vmcnt(0) covers them)
+  unsigned kmeta = 0;                                 // packed keys: (scale, zero) of this lane's kv row of the tile rebuilt next
   auto load_cs = [&](int jt) {
     const int pos = min(jt * PL_BN + 32 * kvh + n, p.Tk - 1);
+    if (QB) kmeta = *reinterpret_cast<const unsigned*>(p.km + (int64_t)g * p.skm_g + (int64_t)pos * p.skm_l);
     const h16* cr = p.cs + (int64_t)pos * 128 + 32 * dh + 4 * hi;
 #pragma unroll
     for (int mbk = 0; mbk < 2; ++mbk)
@@ -234,7 +298,23 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
       for (int e = 0; e < 16; ++e) kacc[mbk][e] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      const h16x8 xf = *(const lds_h16x8_t*)(uintptr_t)(xbase ^ (unsigned)(ks << 5));     // chunk (2 ks + hi) ^ (row & 15)
+      h16x8 xf;
+      if constexpr (QB == 0) {
+        xf = *(const lds_h16x8_t*)(uintptr_t)(xbase ^ (unsigned)(ks << 5));               // chunk (2 ks + hi) ^ (row & 15)
+      } else {
+        // 8 codes = 4 bytes at byte 8 ks + 4 hi of the row's 64: chunk ks >> 1 (at position ^ ((row >> 1) & 3)), nibble e of the dword =
+        // column 16 ks + 8 hi + e; the pairs come out as (0, 4) (1, 5) (2, 6) (3, 7): bt carries its columns in that order
+        const unsigned d = *(const __attribute__((address_space(3))) unsigned*)(uintptr_t)(
+            lds0 + OFF_XS + (unsigned)(row * 64 + ((((ks >> 1) ^ ((row >> 1) & 3))) << 4) + 8 * (ks & 1) + 4 * hi));
+        const h16x2 m2 = __builtin_bit_cast(h16x2, kmeta);
+        const h16x2 sc2 = h16x2{m2[0], m2[0]};
+        const h16 nb = -((h16)1024.f + m2[1]);
+        const h16x2 nb2 = h16x2{nb, nb};
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = deq2((d >> (4 * e)) & 0x000F000Fu, nb2, sc2);
+        xf = __builtin_bit_cast(h16x8, o);
+      }
       kacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[0][ks], xf, kacc[0], 0, 0, 0);
       kacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[1][ks], xf, kacc[1], 0, 0, 0);
     }
@@ -379,15 +459,26 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
   // ================================================================================================ pipeline
   // (the two roles run their own copy of the loop -- same barriers, same DMA schedule -- so that the S-wave's operand fragments
   //  and the O-wave's 192 accumulators never share a live range: the kernel needs max(S, O) registers, not their sum)
-  if (njt > 0) {
-    dma_x(0);
-    if (swave) load_cs(0);
-    dma_wait();
+  auto pin_prefetched = [&]() {
+    // (hipcc's own waits for the plain loads of a phase go HERE, behind the phase's vmcnt(0), where nothing is in flight: in front of
+    //  their first use they would be a vmcnt(0) behind the next phase's DMA requests)
     if (swave) {
 #pragma unroll
       for (int mbk = 0; mbk < 2; ++mbk)
         asm volatile("" : "+v"(cs_c[mbk][0]), "+v"(cs_c[mbk][1]), "+v"(cs_s[mbk][0]), "+v"(cs_s[mbk][1]));
+      if (QB) asm volatile("" : "+v"(kmeta));
     }
+    if (QB) {
+      asm volatile("" : "+v"(vmeta_next));
+      vmeta_cur = vmeta_next;
+    }
+  };
+  if (njt > 0) {
+    if (QB) dma_xq(0); else dma_x(0);
+    vc_issue(0, 0);
+    if (swave) load_cs(0);
+    dma_wait();
+    pin_prefetched();
   }
   __syncthreads();
   if (swave && njt > 0) build(0);
@@ -395,12 +486,24 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
   // The O-wave runs half a tile behind the S-wave: alpha(jt) = second half of P.V of tile jt - 1, beta(jt) = first half of tile jt
   // (whose probabilities the S-wave wrote in alpha(jt)) -- so one probability buffer serves, each k-step pair written in one phase
   // and read in the next.
+  // (packed values: the codes arrive one phase earlier in a staging buffer and waves 0 .. NVC - 1 write the fp16 image of the half
+  //  tile at the start of the phase in which the DMA form would have requested it)
   auto stage_alpha = [&](int jt) {
-    if (jt + 1 < njt) dma_x(jt + 1);                  // consumed by the rebuild in phase beta
-    if (jt < njt) dma_v(jt, 0);                       // consumed in phase beta (slot 0 was read in the last phase beta)
+    if (jt + 1 < njt) { if (QB) dma_xq(jt + 1); else dma_x(jt + 1); }   // consumed by the rebuild in phase beta
+    if (QB == 0) {
+      if (jt < njt) dma_v(jt, 0);                     // consumed in phase beta (slot 0 was read in the last phase beta)
+    } else if (jt < njt) {
+      vc_dequant(0);                                  // codes of (jt, 0): staged in the last phase beta (or the prologue)
+      vc_issue(jt, 1);
+    }
   };
   auto stage_beta = [&](int jt) {
-    if (jt < njt) dma_v(jt, 1);                       // consumed in the next phase alpha (slot 1 was read in this one)
+    if (QB == 0) {
+      if (jt < njt) dma_v(jt, 1);                     // consumed in the next phase alpha (slot 1 was read in this one)
+    } else {
+      if (jt < njt) vc_dequant(1);
+      if (jt + 1 < njt) vc_issue(jt + 1, 0);
+    }
   };
   if (swave) {
     for (int jt = 0; jt <= njt; ++jt) {               // iteration njt only drains the last tile's P.V
@@ -408,11 +511,7 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
       if (jt + 1 < njt) load_cs(jt + 1);
       if (jt < njt) scores_part1(jt);
       dma_wait();
-      // (hipcc's own wait for the rotary loads goes HERE, where nothing is in flight: placed in front of their first use it
-      //  would be a vmcnt(0) behind the next phase's DMA requests)
-#pragma unroll
-      for (int mbk = 0; mbk < 2; ++mbk)
-        asm volatile("" : "+v"(cs_c[mbk][0]), "+v"(cs_c[mbk][1]), "+v"(cs_s[mbk][0]), "+v"(cs_s[mbk][1]));
+      pin_prefetched();
       __syncthreads();
       stage_beta(jt);                                 // ---- phase beta: second half, then the rebuild of K~ tile jt + 1 (other image)
       if (jt < njt) scores_part2(jt);
@@ -420,6 +519,7 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
       if (jt + 1 < njt) build(jt + 1);
 #endif
       dma_wait();
+      pin_prefetched();
       __syncthreads();
     }
     // the row sums (both hi halves) for the O-wave
@@ -437,10 +537,12 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
       stage_alpha(jt);                                // ---- phase alpha: second half of P.V of tile jt - 1
       if (jt >= 1) pv_half(std::integral_constant<int, 1>{});
       dma_wait();
+      pin_prefetched();
       __syncthreads();
       stage_beta(jt);                                 // ---- phase beta: rescale, first half of tile jt
       if (jt < njt) pv_half(std::integral_constant<int, 0>{});
       dma_wait();
+      pin_prefetched();
       __syncthreads();
     }
     __syncthreads();
@@ -475,10 +577,10 @@ __global__ void rope_cs_table_kernel(const float* __restrict__ inv_freq, int pos
   out[(int64_t)t * 128 + 64 + i] = (h16)sn;
 }
 
-template <int NCB>
+template <int NCB, int QB>
 int launch_prefill_lat(const PfLatParams& p, hipStream_t stream) {
-  constexpr int smem = 3 * PL_BN * 256 + 2 * 32 * 64 * NCB + 4 * 4096 + 4 * 32 * 4 + 32 * 1024;
-  auto kern = prefill_lat_kernel<NCB>;
+  constexpr int smem = 3 * PL_BN * 256 + 2 * 32 * 64 * NCB + 4 * 4096 + 4 * 32 * 4 + 32 * 1024 + (QB ? 2 * 16 * 32 * NCB : 0);
+  auto kern = prefill_lat_kernel<NCB, QB>;
   const int rca = palu_func_max_lds(reinterpret_cast<const void*>(kern), smem);
   if (rca) return rca;
   dim3 grid(p.head_major == 2 ? p.H * p.nqt : (p.head_major ? p.H : p.nqt), p.head_major == 2 ? 1 : (p.head_major ? p.nqt : p.H), 1);
@@ -537,10 +639,60 @@ extern "C" int palu_prefill_attn_lat_f16(const void* q, int64_t sq_h, int64_t sq
   p.nqt = (Tq + PL_BM - 1) / PL_BM;
   p.head_major = (int64_t)p.nqt * H <= 2048 ? 1 : 2;
   if (p.head_major == 2 && H % 8 != 0) p.head_major = 0;
+  p.kc = p.vc = nullptr; p.km = p.vm = nullptr;
+  p.skc_g = p.skc_l = p.skm_g = p.skm_l = p.svc_g = p.svc_l = p.svm_g = p.svm_l = 0;
   hipStream_t s = (hipStream_t)stream;
   switch (Rv / 32) {
-    case 4: return launch_prefill_lat<4>(p, s);
-    case 8: return launch_prefill_lat<8>(p, s);
-    default: return launch_prefill_lat<12>(p, s);
+    case 4: return launch_prefill_lat<4, 0>(p, s);
+    case 8: return launch_prefill_lat<8, 0>(p, s);
+    default: return launch_prefill_lat<12, 0>(p, s);
+  }
+}
+
+// The same over PACKED 4-bit caches (quant.hip's layout: codes [G][.][R / 2] bytes, meta [G][.][2] fp16 (scale, zero) per (token,
+// group) row; byte strides for the codes, element strides for the meta): the codes are de-quantised inside the kernel -- keys in the
+// rebuild's registers, values into the half-tile image -- with unpack_dequant's arithmetic; no fp16 copy of the cache exists.
+// bt = B^T [H][128][128] with the columns of every group of 8 in the order 0 4 1 5 2 6 3 7.
+extern "C" int palu_prefill_attn_lat_q(const void* q, int64_t sq_h, int64_t sq_t, const void* k_codes, int64_t skc_g, int64_t skc_l,
+                                       const void* k_meta, int64_t skm_g, int64_t skm_l, const void* v_codes, int64_t svc_g,
+                                       int64_t svc_l, const void* v_meta, int64_t svm_g, int64_t svm_l, const void* bt_perm,
+                                       const void* cs, void* out, int64_t so_t, int H, int G, int D, int Tq, int Tk, int Rk, int Rv,
+                                       int bits, int past, int causal, float scale, palu_stream_t stream) {
+  PALU_REQUIRE(q && k_codes && k_meta && v_codes && v_meta && bt_perm && cs && out, PALU_ERR_ARG, "prefill_attn_lat_q: null pointer");
+  PALU_REQUIRE(bits == 4, PALU_ERR_UNSUPPORTED, "prefill_attn_lat_q: 4-bit codes only (got %d)", bits);
+  PALU_REQUIRE(palu_prefill_attn_lat_supported(H, G, D, Rk, Rv), PALU_ERR_UNSUPPORTED,
+               "prefill_attn_lat_q: needs head_dim 128, rank_k / G = 128, rank_v / G in {128, 256, 384} (H=%d G=%d D=%d Rk=%d Rv=%d)", H,
+               G, D, Rk, Rv);
+  PALU_REQUIRE(Tq >= 0 && Tk >= 0 && past >= 0 && (int64_t)past + Tq < (1 << 30), PALU_ERR_ARG, "prefill_attn_lat_q: bad lengths");
+  if (Tq == 0) return PALU_OK;
+  PALU_REQUIRE(Tk > 0, PALU_ERR_ARG, "prefill_attn_lat_q: no keys");
+  PALU_REQUIRE(scale > 0.f, PALU_ERR_ARG, "prefill_attn_lat_q: scale must be positive");
+  PALU_REQUIRE((((uintptr_t)q | (uintptr_t)k_codes | (uintptr_t)v_codes | (uintptr_t)bt_perm | (uintptr_t)cs) & 15) == 0 &&
+                   (((uintptr_t)k_meta | (uintptr_t)v_meta) & 3) == 0 && sq_h % 8 == 0 && sq_t % 8 == 0 && skc_g % 16 == 0 &&
+                   skc_l % 16 == 0 && svc_g % 16 == 0 && svc_l % 16 == 0 && skm_g % 2 == 0 && skm_l % 2 == 0 && svm_g % 2 == 0 &&
+                   svm_l % 2 == 0 && skc_l >= Rk / 2 && svc_l >= Rv / 2 && ((uintptr_t)out & 7) == 0 && so_t % 4 == 0,
+               PALU_ERR_ARG, "prefill_attn_lat_q: code rows must be 16-byte aligned, meta pairs 4-byte aligned (out 8-byte)");
+  PALU_REQUIRE(((int64_t)Tk + PL_BN) * skc_l < ((int64_t)1 << 32) && ((int64_t)Tk + PL_BN) * svc_l < ((int64_t)1 << 32),
+               PALU_ERR_UNSUPPORTED, "prefill_attn_lat_q: one group's code slab must stay below 4 GiB");
+  PfLatParams p;
+  p.q = (const h16*)q; p.sq_h = sq_h; p.sq_t = sq_t;
+  p.xk = (const h16*)k_codes; p.sxk_g = 0; p.sxk_l = 128;      // (fp16 staging geometry unused)
+  p.xv = (const h16*)v_codes; p.sxv_g = 0; p.sxv_l = Rv;
+  p.kc = (const unsigned char*)k_codes; p.skc_g = skc_g; p.skc_l = skc_l;
+  p.km = (const h16*)k_meta; p.skm_g = skm_g; p.skm_l = skm_l;
+  p.vc = (const unsigned char*)v_codes; p.svc_g = svc_g; p.svc_l = svc_l;
+  p.vm = (const h16*)v_meta; p.svm_g = svm_g; p.svm_l = svm_l;
+  p.bt = (const h16*)bt_perm; p.cs = (const h16*)cs;
+  p.out = (h16*)out; p.so_t = so_t;
+  p.H = H; p.G = G; p.gs = H / G; p.Tq = Tq; p.Tk = Tk; p.past = past; p.causal = causal ? 1 : 0;
+  p.scale_log2 = scale * 1.4426950408889634f;
+  p.nqt = (Tq + PL_BM - 1) / PL_BM;
+  p.head_major = (int64_t)p.nqt * H <= 2048 ? 1 : 2;
+  if (p.head_major == 2 && H % 8 != 0) p.head_major = 0;
+  hipStream_t s = (hipStream_t)stream;
+  switch (Rv / 32) {
+    case 4: return launch_prefill_lat<4, 4>(p, s);
+    case 8: return launch_prefill_lat<8, 4>(p, s);
+    default: return launch_prefill_lat<12, 4>(p, s);
   }
 }

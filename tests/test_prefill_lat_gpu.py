@@ -203,3 +203,54 @@ def test_latent_prompt_pass_needs_128_mib_of_transients_at_32k_tokens():
     one, mem_one = run(None)
     torch.testing.assert_close(lat.float(), one.float(), rtol=2e-3, atol=2e-3)
     assert mem_lat <= 128 << 20 and mem_one > 1 << 30, (mem_lat / 2 ** 20, mem_one / 2 ** 20)
+
+
+# ------------------------------------------------------------------------------------------------- packed 4-bit caches
+def bt_perm_of(b):
+    """B^T [H, D, R] with the columns of every group of 8 in the order the nibbles of a dword leave it: 0 4 1 5 2 6 3 7."""
+    H, R, _ = b.shape
+    idx = torch.tensor([0, 4, 1, 5, 2, 6, 3, 7], device=b.device)
+    return b.transpose(1, 2).reshape(H, D, R // 8, 8)[..., idx].reshape(H, D, R).contiguous()
+
+
+@pytest.mark.parametrize("H,gs,Tq,Tk,Rv,causal", [
+    (4, 4, 128, 128, 384, True), (8, 4, 257, 257, 128, True), (32, 4, 300, 300, 384, True), (8, 4, 129, 1000, 384, True),
+    (4, 4, 200, 70, 384, False), (8, 4, 333, 333, 256, True), (8, 2, 64, 4097, 384, True),
+])
+def test_latent_prefill_kernel_on_packed_4bit_caches(H, gs, Tq, Tk, Rv, causal):
+    """palu_prefill_attn_lat_q de-quantises the codes inside the kernel: same result as the fp16 kernel on unpack_dequant()'s rows
+    (identical fp16 values enter the MFMAs; only the rebuild's summation order differs through the permuted B^T columns), and the
+    fp32 evaluation on those rows."""
+    from palu_amd.kernel.quant import quantize_pack, unpack_dequant
+    _lib, ar = _mods()
+    lib, S = _lib.lib, torch.cuda.current_stream().cuda_stream
+    G, Rk = H // gs, 128
+    g = torch.Generator().manual_seed(7 * H + Tq + Tk + Rv)
+    past = Tk - Tq if causal and Tk >= Tq else 0
+    q = torch.randn(H, Tq, D, generator=g).half().to(DEV)
+    cap = Tk + 5
+    xk = torch.randn(G, cap, Rk, generator=g).half().to(DEV)
+    xv = torch.randn(G, cap, Rv, generator=g).half().to(DEV)
+    b = (torch.randn(H, Rk, D, generator=g) * Rk ** -0.5).half().to(DEV)
+    kc, km = quantize_pack(xk, 4)
+    vc, vm = quantize_pack(xv, 4)
+    kc[:, Tk:], vc[:, Tk:] = 0xFF, 0xFF                                      # rows beyond Tk hold garbage
+    km[:, Tk:], vm[:, Tk:] = float("nan"), float("nan")
+    xkd, xvd = unpack_dequant(kc[:, :Tk].contiguous(), km[:, :Tk].contiguous(), 4, Rk), unpack_dequant(vc[:, :Tk].contiguous(), vm[:, :Tk].contiguous(), 4, Rv)
+    inv = ar.rope_inv_freq(torch.device(DEV))
+    ref16 = _lat_form(q, xkd, xvd, b, past, causal, inv, Tk)
+    cs = torch.empty(lib.palu_rope_cs_table_bytes(Tk), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.palu_rope_cs_table_build(inv.data_ptr(), 0, Tk, cs.data_ptr(), S), "cs")
+    btp = bt_perm_of(b)
+    out = torch.empty(Tq, H * Rv, dtype=torch.float16, device=DEV)
+    _lib.check(lib.palu_prefill_attn_lat_q(q.data_ptr(), q.stride(0), q.stride(1), kc.data_ptr(), kc.stride(0), kc.stride(1),
+                                           km.data_ptr(), km.stride(0), km.stride(1), vc.data_ptr(), vc.stride(0), vc.stride(1),
+                                           vm.data_ptr(), vm.stride(0), vm.stride(1), btp.data_ptr(), cs.data_ptr(), out.data_ptr(),
+                                           out.stride(0), H, G, D, Tq, Tk, Rk, Rv, 4, past, 1 if causal else 0, 1.0 / math.sqrt(D), S),
+               "prefill_attn_lat_q")
+    assert torch.isfinite(out).all()
+    scale = ref16.float().abs().max().item()
+    assert (out.float() - ref16.float()).abs().max().item() <= 1e-3 * scale + 1e-3
+    _, keys = _workspace_form(q, xkd, xvd, b, past, causal, inv)
+    ref = _ref_f32(q, keys, xvd, past, causal)
+    assert (out.float() - ref).abs().max().item() <= 2e-3 * scale + 1e-3
