@@ -32,7 +32,7 @@
 #include "pv_mfma.h"
 
 #ifndef PL_EXP
-#define PL_EXP 0   // timing experiments only (results are wrong when set): 1 = no K~ rebuild, 2 = no exponentials, 4 = no P.V MFMAs
+#define PL_EXP 0   // timing experiments only (results are wrong when set): 1 = no K~ rebuild, 2 = no exponentials, 4 = no P.V MFMAs, 8 = no LDS-DMA staging
 #endif
 
 namespace {
@@ -139,6 +139,9 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
   const u32x4 xrs = make_rsrc(xkg, ((int64_t)(p.Tk - 1) * p.sxk_l + 128) * 2);
   const u32x4 vrs = make_rsrc(xvg, ((int64_t)(p.Tk - 1) * p.sxv_l + RV) * 2);
   auto dma = [&](unsigned dst, unsigned voff, const u32x4& rs, unsigned soff) {
+#if PL_EXP & 8
+    return;                                           // (timing experiment: no staging traffic at all)
+#endif
     asm volatile(
         "s_mov_b32 m0, %0\n\t"
         "s_nop 0\n\t"
@@ -364,16 +367,18 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
   };
   auto scores_part1 = [&](int jt) {
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) {
+    for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
       for (int e = 0; e < 16; ++e) sacc[rb][e] = 0.f;
-      const int row = rb * 32 + krow;
+    // (k-step outer, the two row blocks inner: two independent accumulator chains, one Q~ fragment read for both)
+    const unsigned kt = lds0 + OFF_KS + (unsigned)((jt & 1) * KS_BYTES + krow * 256 + ((hi ^ (krow & 15)) << 4));
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
-        const h16x8 kf = *(const lds_h16x8_t*)(uintptr_t)(lds0 + OFF_KS + (jt & 1) * KS_BYTES + row * 256 + (((2 * kk + hi) ^ (row & 15)) << 4));
-        const h16x8 qk = *(const lds_h16x8_t*)(uintptr_t)(qfa + (unsigned)(kk * 1024));
-        sacc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qk, sacc[rb], 0, 0, 0);
-      }
+    for (int kk = 0; kk < 8; ++kk) {
+      const h16x8 qk = *(const lds_h16x8_t*)(uintptr_t)(qfa + (unsigned)(kk * 1024));
+      const h16x8 kf0 = *(const lds_h16x8_t*)(uintptr_t)(kt ^ (unsigned)(kk << 5));                    // row krow: chunk (2 kk + hi) ^ (row & 15)
+      const h16x8 kf1 = *(const lds_h16x8_t*)(uintptr_t)((kt ^ (unsigned)(kk << 5)) + 32 * 256);     // row 32 + krow (same row & 15)
+      sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf0, qk, sacc[0], 0, 0, 0);
+      sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf1, qk, sacc[1], 0, 0, 0);
     }
     // register r of block rb in lane (t, hi) is kv = jt*64 + 32 rb + 16 (r >> 3) + 8 hi + (r & 7)
     const int j0 = jt * PL_BN + 8 * hi;

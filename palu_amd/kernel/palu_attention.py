@@ -795,14 +795,25 @@ class LlamaPaluAttention(nn.Module):
     PREFILL_LATENT_ABOVE = 256 << 20
     PREFILL_LATENT_QUERY_CHUNK = 2048
 
-    def _bt_fragments(self):
-        """B^T [H, D, Rk] contiguous (row d of head h = the weights that rebuild K[., d]): cached like the abx fragments."""
+    def _bt_fragments(self, permuted: bool = False):
+        """B^T [H, D, Rk] contiguous (row d of head h = the weights that rebuild K[., d]): cached like the abx fragments.
+        permuted: the columns of every group of 8 in the order 0 4 1 5 2 6 3 7 -- the order the nibbles of a dword of 4-bit codes come
+        out in the packed form of the latent prefill kernel."""
         b = self.k_proj.B
+        key = (b._version, b.data_ptr(), bool(permuted))
         hit = getattr(self, "_bt_cache", None)
-        if hit is not None and hit[0] == (b._version, b.data_ptr()):
-            return hit[1]
-        bt = b.detach().transpose(1, 2).contiguous()
-        self._bt_cache = ((b._version, b.data_ptr()), bt)
+        if hit is not None and key in hit:
+            return hit[key]
+        bt = b.detach().transpose(1, 2)
+        if permuted:
+            H, Dd, R = bt.shape
+            idx = torch.tensor([0, 4, 1, 5, 2, 6, 3, 7], device=bt.device)
+            bt = bt.reshape(H, Dd, R // 8, 8)[..., idx].reshape(H, Dd, R)
+        bt = bt.contiguous()
+        if hit is None or next(iter(hit))[:2] != key[:2]:
+            hit = {}
+        hit[key] = bt
+        self._bt_cache = hit
         return bt
 
     def _prefill_latent(self, hidden_states, pos, cache, causal: bool):
@@ -818,13 +829,23 @@ class LlamaPaluAttention(nn.Module):
         qc = max(128, int(self.PREFILL_LATENT_QUERY_CHUNK))
         inv = rope_inv_freq(dev, D, self.rope_theta)
         cs = rope_cs_table(dev, D, self.rope_theta, kv_all)
-        bt = self._bt_fragments()
+        packed = not isinstance(cache, LatentCache)
+        bt = self._bt_fragments(permuted=packed)
         stream = _lib.current_stream()
         p0 = int(pos.reshape(-1)[0])
+
+        def project(hs):
+            t_ = hs.shape[1]
+            if not packed:
+                self._project_into_cache(hs, cache)                                       # latents straight into the rows
+            elif not self._project_into_packed_cache(hs, cache):
+                kh = self.k_proj.project_to_latent(hs).view(1, t_, G, Rk).transpose(1, 2)
+                vh = self.v_proj.project_to_latent(hs).view(1, t_, G, Rv).transpose(1, 2)
+                cache.append_rows(kh, vh, li)                                             # quantise + pack this chunk's rows
         all_first = (not causal) and q_len > qc        # no mask: every query attends every key of the pass (see _prefill_flash)
         if all_first:
             for c0 in range(0, q_len, qc):
-                self._project_into_cache(hidden_states[:, c0:min(q_len, c0 + qc)], cache)
+                project(hidden_states[:, c0:min(q_len, c0 + qc)])
         out = None
         for c0 in range(0, q_len, qc):
             c1 = min(q_len, c0 + qc)
@@ -832,17 +853,27 @@ class LlamaPaluAttention(nn.Module):
             hs = hidden_states[:, c0:c1]
             q = self.q_proj(hs).view(t, H, D).transpose(0, 1)                             # [H,t,D] view of [t, H*D]
             if not all_first:
-                self._project_into_cache(hs, cache)
+                project(hs)
             kv = kv_all if all_first else past + c1
             _lib.check(_lib.lib.palu_rope_f16(q.data_ptr(), q.stride(0), q.stride(1), H, t, D, p0 + c0, inv.data_ptr(), stream),
                        "palu_rope_f16")
-            kbuf, vbuf = cache.buffers(li)
             ctx = torch.empty((t, H * Rv), dtype=dt, device=dev)
-            _lib.check(_lib.lib.palu_prefill_attn_lat_f16(q.data_ptr(), q.stride(0), q.stride(1), kbuf.data_ptr(), kbuf.stride(1),
-                                                          kbuf.stride(2), vbuf.data_ptr(), vbuf.stride(1), vbuf.stride(2),
-                                                          bt.data_ptr(), cs.data_ptr(), ctx.data_ptr(), ctx.stride(0), H, G, D, t, kv,
-                                                          Rk, Rv, past + c0, 1 if causal else 0, 1.0 / math.sqrt(D), stream),
-                       "palu_prefill_attn_lat_f16")
+            if not packed:
+                kbuf, vbuf = cache.buffers(li)
+                _lib.check(_lib.lib.palu_prefill_attn_lat_f16(q.data_ptr(), q.stride(0), q.stride(1), kbuf.data_ptr(), kbuf.stride(1),
+                                                              kbuf.stride(2), vbuf.data_ptr(), vbuf.stride(1), vbuf.stride(2),
+                                                              bt.data_ptr(), cs.data_ptr(), ctx.data_ptr(), ctx.stride(0), H, G, D, t, kv,
+                                                              Rk, Rv, past + c0, 1 if causal else 0, 1.0 / math.sqrt(D), stream),
+                           "palu_prefill_attn_lat_f16")
+            else:
+                st = cache.buffers(li)
+                kc, km, vc, vm = st["kc"], st["km"], st["vc"], st["vm"]
+                _lib.check(_lib.lib.palu_prefill_attn_lat_q(q.data_ptr(), q.stride(0), q.stride(1), kc.data_ptr(), kc.stride(1),
+                                                            kc.stride(2), km.data_ptr(), km.stride(1), km.stride(2), vc.data_ptr(),
+                                                            vc.stride(1), vc.stride(2), vm.data_ptr(), vm.stride(1), vm.stride(2),
+                                                            bt.data_ptr(), cs.data_ptr(), ctx.data_ptr(), ctx.stride(0), H, G, D, t, kv,
+                                                            Rk, Rv, cache.n_bits, past + c0, 1 if causal else 0, 1.0 / math.sqrt(D),
+                                                            stream), "palu_prefill_attn_lat_q")
             o = self.o_proj(ctx)
             del ctx, q
             if c0 == 0 and c1 == q_len:
@@ -878,7 +909,8 @@ class LlamaPaluAttention(nn.Module):
             one_launch_bytes += 2 * kv_all * G * (Rk + Rv)          # the dequantised rows
         lat_above = self.PREFILL_LATENT_ABOVE
         pos_flat = pos.reshape(-1)
-        if (lat_above is not None and not packed and panel_rows == 0 and one_launch_bytes > lat_above and dt == torch.float16
+        lat_packed_ok = packed and getattr(cache, "n_bits", 0) == 4 and not getattr(cache, "group_size", 0)
+        if (lat_above is not None and (not packed or lat_packed_ok) and panel_rows == 0 and one_launch_bytes > lat_above and dt == torch.float16
                 and self.n_rep == 1 and _lib.lib.palu_prefill_attn_lat_supported(H, G, D, Rk, Rv)
                 and bool((pos_flat == torch.arange(int(pos_flat[0]), int(pos_flat[0]) + q_len, device=pos_flat.device)).all())
                 and self.q_proj.weight.dtype == dt):

@@ -360,6 +360,8 @@ def test_prefill_transient_memory_is_bounded():
     with torch.no_grad():
         m(x[:, :256], past_key_value=QuantLatentCache(4), is_causal=True)       # warm-up: library handles, fragments
 
+    m.PREFILL_LATENT_ABOVE = None               # (the workspace forms: the latent form has its own bound, tests/test_prefill_lat_gpu.py)
+
     def run(budget):
         cache = QuantLatentCache(4, capacity=T + 512)
         cache.reserve(0, T + 512, H // gs, rank_k // (H // gs), rank_v // (H // gs), x.device)

@@ -136,12 +136,13 @@ def _module(hidden, H, gs, Rk, Rv, seed=0):
     return m.eval().prepare_decode()
 
 
+@pytest.mark.parametrize("bits", [16, 4])
 @pytest.mark.parametrize("causal", [True, False])
-def test_prompt_pass_in_latent_form_equals_workspace_form_and_feeds_decode(causal):
+def test_prompt_pass_in_latent_form_equals_workspace_form_and_feeds_decode(causal, bits):
     """LlamaPaluAttention.forward with the latent kernel forced (PREFILL_LATENT_ABOVE = 0, query chunks of 256 -- and 200, not a
     multiple of the kernel's 128-query tile) against the workspace form (None): same output, identical cache contents, a second
     prompt pass on top of the first (past > 0), and a decode step from either cache."""
-    from palu_amd.kernel.palu_attention import LatentCache
+    from palu_amd.kernel.palu_attention import LatentCache, QuantLatentCache
     hidden, H, gs, Rk, Rv, T1, T2 = 1024, 8, 4, 128, 384, 700, 333
     m = _module(hidden, H, gs, Rk, Rv)
     x1 = torch.randn(1, T1, hidden, device=DEV, dtype=torch.float16)
@@ -149,7 +150,7 @@ def test_prompt_pass_in_latent_form_equals_workspace_form_and_feeds_decode(causa
     xd = torch.randn(1, 1, hidden, device=DEV, dtype=torch.float16)
     outs = {}
     for mode, above, chunk in (("workspace", None, 2048), ("latent", 0, 256), ("latent200", 0, 200)):
-        cache = LatentCache()
+        cache = LatentCache() if bits == 16 else QuantLatentCache(bits)
         m.PREFILL_LATENT_ABOVE, m.PREFILL_LATENT_QUERY_CHUNK = above, chunk
         try:
             with torch.no_grad():
@@ -158,7 +159,8 @@ def test_prompt_pass_in_latent_form_equals_workspace_form_and_feeds_decode(causa
                 od, _, _ = m(xd, past_key_value=cache, position_ids=torch.tensor([[T1 + T2]]))
         finally:
             del m.PREFILL_LATENT_ABOVE, m.PREFILL_LATENT_QUERY_CHUNK
-        outs[mode] = (o1, o2, od, [b[:, :, :T1 + T2 + 1].clone() for b in cache.buffers(0)])
+        bufs = cache.buffers(0) if bits == 16 else [cache.buffers(0)[k] for k in ("kc", "km", "vc", "vm")]
+        outs[mode] = (o1, o2, od, [b[:, :, :T1 + T2 + 1].clone() for b in bufs])
     ref = outs["workspace"]
     for mode in ("latent", "latent200"):
         got = outs[mode]
@@ -168,23 +170,28 @@ def test_prompt_pass_in_latent_form_equals_workspace_form_and_feeds_decode(causa
             assert torch.equal(a, b)
 
 
-def test_latent_prompt_pass_needs_128_mib_of_transients_at_32k_tokens():
+@pytest.mark.parametrize("bits", [16, 4])
+def test_latent_prompt_pass_needs_128_mib_of_transients_at_32k_tokens(bits):
     """the prompt pass without the [H, kv, D] key workspace and the transposed value copy.  32k tokens at the
     config-2 ranks into an fp16 cache: the latent form's transients (rotated queries + context rows of one 2048-query chunk, the
     chunk's q_proj / o_proj outputs) stay below 128 MiB; the one-launch workspace form needs > 1 GiB; same output."""
-    from palu_amd.kernel.palu_attention import LatentCache
+    from palu_amd.kernel.palu_attention import LatentCache, QuantLatentCache
     hidden, H, gs, Rk, Rv, T = 4096, 32, 4, 128, 384, 32768
     m = _module(hidden, H, gs, Rk, Rv)
     x = torch.randn(1, T, hidden, device=DEV, dtype=torch.float16)
     with torch.no_grad():
-        m(x[:, :256], past_key_value=LatentCache(), is_causal=True)             # warm-up: library handles, fragments, rotary cache
+        m(x[:, :256], past_key_value=LatentCache() if bits == 16 else QuantLatentCache(bits), is_causal=True)   # warm-up: handles, fragments
     from palu_amd.kernel.abx_rope import rope_cs_table
     rope_cs_table(torch.device(DEV), D, m.rope_theta, T)                         # (persistent, like HF's cos / sin cache)
 
     def run(above):
-        cache = LatentCache(capacity=T + 512)
-        cache.reserve(0, T + 512, torch.empty((1, H // gs, 0, Rk), dtype=torch.float16, device=DEV),
-                      torch.empty((1, H // gs, 0, Rv), dtype=torch.float16, device=DEV))
+        if bits == 16:
+            cache = LatentCache(capacity=T + 512)
+            cache.reserve(0, T + 512, torch.empty((1, H // gs, 0, Rk), dtype=torch.float16, device=DEV),
+                          torch.empty((1, H // gs, 0, Rv), dtype=torch.float16, device=DEV))
+        else:
+            cache = QuantLatentCache(bits, capacity=T + 512)
+            cache.reserve(0, T + 512, H // gs, Rk, Rv, torch.device(DEV))
         m.PREFILL_LATENT_ABOVE = above
         try:
             torch.cuda.synchronize()
