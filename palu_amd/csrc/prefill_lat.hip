@@ -71,16 +71,24 @@ typedef __attribute__((address_space(3))) h16x8 lds_h16x8_t;
 typedef __attribute__((address_space(3))) h16x4 lds_h16x4_t;
 typedef __attribute__((address_space(3))) float lds_f32_t;
 
-template <int NCB, int QB = 0>
+template <int NCB, int KSR, int QB = 0>
 __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams p) {
   static_assert(QB == 0 || QB == 4, "fp16 or packed 4-bit latents");
+  static_assert(NCB % 2 == 0 && NCB >= 2 && NCB <= 12, "rank_v / G = 32 NCB, a multiple of 64 (whole groups of four 32-byte granules per row)");
+  static_assert(KSR == 4 || KSR == 8, "rank_k / G = 16 KSR in {64, 128}");
+  constexpr int RK = 16 * KSR;
+  constexpr int RKB = 2 * RK;                       // bytes of an fp16 X row
+  constexpr int CPRX = 2 * KSR;                     // its 16-byte chunks (XOR-swizzled by row & (CPRX - 1))
+  constexpr int NXP = PL_BN * RKB / 1024;           // DMA pieces of an fp16 X tile (8 or 16)
+  constexpr int RQB = RK / 2;                       // bytes of a packed X row
+  constexpr int CQ = RQB / 16;                      // its 16-byte chunks (2 or 4)
   constexpr int RV = 32 * NCB;
   constexpr int RVB = RV * 2;                       // bytes of a V row
   constexpr int XS_BYTES = PL_BN * 256;             // X tile: 64 rows x 128 fp16 (16 chunks per row, XOR-swizzled by row & 15)
   constexpr int KS_BYTES = PL_BN * 256;             // K~ tile, same geometry
   constexpr int VH_BYTES = 32 * RVB;                // half a V tile: 32 rows, row-major, 32-byte granules XOR-swizzled by row & 3
-  constexpr int VPW = VH_BYTES / 1024 / 8;          // DMA pieces per wave and half tile
-  static_assert(VH_BYTES % 8192 == 0 && (4 * RVB) % 1024 == 0, "a wave stages whole groups of 4 rows");
+  constexpr int NVP = VH_BYTES / 1024;              // DMA pieces of half a V tile: piece w + 8 i belongs to wave w
+  constexpr int VPW = (NVP + 7) / 8;
   constexpr int OFF_XS = 0;
   constexpr int OFF_VS = OFF_XS + XS_BYTES;         // (the DMA targets first: LDS offsets below 128 KB)
   constexpr int OFF_KS = OFF_VS + 2 * VH_BYTES;     // two K~ tile images: tile jt in image jt & 1
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
   };
   const h16* xkg = p.xk + (int64_t)g * p.sxk_g;
   const h16* xvg = p.xv + (int64_t)g * p.sxv_g;
-  const u32x4 xrs = make_rsrc(xkg, ((int64_t)(p.Tk - 1) * p.sxk_l + 128) * 2);
+  const u32x4 xrs = make_rsrc(xkg, ((int64_t)(p.Tk - 1) * p.sxk_l + RK) * 2);
   const u32x4 vrs = make_rsrc(xvg, ((int64_t)(p.Tk - 1) * p.sxv_l + RV) * 2);
   auto dma = [&](unsigned dst, unsigned voff, const u32x4& rs, unsigned soff) {
 #if PL_EXP & 8
@@ -150,25 +158,27 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
         : "s"(dst), "v"(voff), "s"(rs), "s"(soff)
         : "memory");
   };
-  // X tile: piece (w + 8 i) = rows 4 (w + 8 i) .. + 3, 16 chunks each (rows past Tk are outside the descriptor: their scores are masked)
-  const int xrow_l = 4 * w + (lane >> 4);
-  const unsigned xvo = (unsigned)((xrow_l * p.sxk_l + (((lane & 15) ^ (xrow_l & 15)) << 3)) * 2);
+  // X tile: piece (w + 8 i) = rows (64 / CPRX) (w + 8 i) .. , CPRX chunks each (rows past Tk are outside the descriptor: their scores
+  // are masked); 8 pieces are a multiple of CPRX rows, so the swizzle key of a lane's row does not depend on i
+  const int xrow_l = (64 / CPRX) * w + lane / CPRX;
+  const unsigned xvo = (unsigned)((xrow_l * p.sxk_l + (((lane % CPRX) ^ (xrow_l & (CPRX - 1))) << 3)) * 2);
   const unsigned xtile_bytes = __builtin_amdgcn_readfirstlane((unsigned)(PL_BN * p.sxk_l * 2));
-  const unsigned xstep_bytes = __builtin_amdgcn_readfirstlane((unsigned)(32 * p.sxk_l * 2));
+  const unsigned xstep_bytes = __builtin_amdgcn_readfirstlane((unsigned)(8 * (64 / CPRX) * p.sxk_l * 2));
   auto dma_x = [&](int jt) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NXP / 8; ++i)
       dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_XS + (w + 8 * i) * 1024), xvo, xrs,
           __builtin_amdgcn_readfirstlane((unsigned)jt * xtile_bytes + i * xstep_bytes));
   };
-  // packed keys: the tile's codes (64 rows x 64 bytes) as 4 pieces of 16 rows, waves 0-3 one each; 16-byte chunk c of row r lands at
-  // chunk position c ^ ((r >> 1) & 3) (the rebuild reads 4 bytes per lane and k-step: rows two apart would share a bank)
-  const u32x4 xqrs = QB ? make_rsrc(p.kc + (int64_t)g * p.skc_g, (int64_t)(p.Tk - 1) * p.skc_l + 64) : xrs;
-  const unsigned xqvo = QB ? (unsigned)((lane >> 2) * (int)p.skc_l + (((lane & 3) ^ ((lane >> 3) & 3)) << 4)) : 0u;
+  // packed keys: the tile's codes (64 rows x RK / 2 bytes) as CQ pieces of 64 / CQ rows, waves 0 .. CQ - 1 one each; 16-byte chunk c of
+  // row r lands at chunk position c ^ ((r >> 1) & (CQ - 1)) (the rebuild reads 4 bytes per lane and k-step: rows two apart would
+  // share a bank)
+  const u32x4 xqrs = QB ? make_rsrc(p.kc + (int64_t)g * p.skc_g, (int64_t)(p.Tk - 1) * p.skc_l + RQB) : xrs;
+  const unsigned xqvo = QB ? (unsigned)((lane / CQ) * (int)p.skc_l + (((lane % CQ) ^ (((lane / CQ) >> 1) & (CQ - 1))) << 4)) : 0u;
   auto dma_xq = [&](int jt) {
-    if (w < 4)
+    if (w < CQ)
       dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_XS + w * 1024), xqvo, xqrs,
-          __builtin_amdgcn_readfirstlane((unsigned)(jt * PL_BN + 16 * w) * (unsigned)p.skc_l));
+          __builtin_amdgcn_readfirstlane((unsigned)(jt * PL_BN + (64 / CQ) * w) * (unsigned)p.skc_l));
   };
   // packed values: the codes of half a tile, linear ([row][RV / 2 bytes] as in memory): piece w = 16-byte chunks 64 w .. 64 w + 63; the
   // lane that de-quantises chunk q = 64 w + lane (row q / NCB, columns 32 (q % NCB) ..) also fetches that row's (scale, zero)
@@ -216,7 +226,7 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
   unsigned vvo[VPW];
 #pragma unroll
   for (int i = 0; i < VPW; ++i) {
-    const int s = (VPW * w + i) * 64 + lane;
+    const int s = (w + 8 * i) * 64 + lane;
     const int r = s / SPR, sr = s % SPR;
     vvo[i] = (unsigned)(r * (int)(p.sxv_l * 2) + ((((sr >> 1) ^ (r & 3)) << 1) + (sr & 1)) * 16);
   }
@@ -226,16 +236,18 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
     if (row0 + 32 <= p.Tk) {
 #pragma unroll
       for (int i = 0; i < VPW; ++i)
-        dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_VS + half * VH_BYTES + (VPW * w + i) * 1024), vvo[i], vrs,
-            __builtin_amdgcn_readfirstlane((unsigned)(2 * jt + half) * vhalf_bytes));
+        if (w + 8 * i < NVP)
+          dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_VS + half * VH_BYTES + (w + 8 * i) * 1024), vvo[i], vrs,
+              __builtin_amdgcn_readfirstlane((unsigned)(2 * jt + half) * vhalf_bytes));
     } else {
       // the cache's last rows: rows past Tk re-read row Tk - 1 (finite data; their probabilities are exactly zero)
 #pragma unroll
       for (int i = 0; i < VPW; ++i) {
-        const int s = (VPW * w + i) * 64 + lane;
+        if (w + 8 * i >= NVP) continue;
+        const int s = (w + 8 * i) * 64 + lane;
         const int r = s / SPR, sr = s % SPR;
         const int row = min(row0 + r, p.Tk - 1);
-        dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_VS + half * VH_BYTES + (VPW * w + i) * 1024),
+        dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_VS + half * VH_BYTES + (w + 8 * i) * 1024),
             (unsigned)(row * (int)(p.sxv_l * 2) + ((((sr >> 1) ^ (r & 3)) << 1) + (sr & 1)) * 16), vrs, 0u);
       }
     }
@@ -248,7 +260,7 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
   // B_h^T fragments of this wave's 64 rows (A operand of the rebuild), two M-blocks mbk: MFMA row m = 8 a + 4 hb + b  <->
   // d = 32 dh + 16 mbk + 8 (a & 1) + 4 hb + b + 64 (a >> 1): after the MFMA lane (kv, hi) holds register 4 a + b = K[kv][d(a, hi, b)] --
   // both halves of 8 RoPE pairs per M-block
-  h16x8 af[2][8];
+  h16x8 af[2][KSR];
   h16x4 cs_c[2][2], cs_s[2][2];                       // rotary values of this lane's kv row of the tile rebuilt next: [mbk][a1] x 4 pairs
   float m_run = -INFINITY, l_run = 0.f;
   const int kvh = w & 1, dh = (w >> 1) & 1;
@@ -264,9 +276,9 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
 #pragma unroll
     for (int mbk = 0; mbk < 2; ++mbk) {
       const int d = 32 * dh + 16 * mbk + 8 * (a & 1) + 4 * hb + b + 64 * (a >> 1);
-      const h16* bp = p.bt + ((int64_t)h * 128 + d) * 128 + 8 * hi;
+      const h16* bp = p.bt + ((int64_t)h * 128 + d) * RK + 8 * hi;
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) af[mbk][ks] = __builtin_bit_cast(h16x8, *reinterpret_cast<const u32x4*>(bp + 16 * ks));
+      for (int ks = 0; ks < KSR; ++ks) af[mbk][ks] = __builtin_bit_cast(h16x8, *reinterpret_cast<const u32x4*>(bp + 16 * ks));
     }
   }
   // K~ A-fragment row of this lane for the scores: bits 2 and 3 of the MFMA row swapped, so that the 8 registers of a k-step
@@ -292,7 +304,7 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
   // apply_rotary_pos_emb on fp16 tensors, :204-205; rope.hip's arithmetic), 8 x 8 bytes per lane into tile image jt & 1
   auto build = [&](int jt) {
     const int row = 32 * kvh + n;                                       // this lane's kv row of the tile (B-operand column)
-    const unsigned xbase = lds0 + OFF_XS + (unsigned)(row * 256 + ((hi ^ (row & 15)) << 4));
+    const unsigned xbase = lds0 + OFF_XS + (unsigned)(row * RKB + ((hi ^ (row & (CPRX - 1))) << 4));
     const unsigned kbase = lds0 + OFF_KS + (unsigned)((jt & 1) * KS_BYTES + row * 256 + ((row & 15) << 4) + 8 * hi);
     f32x16 kacc[2];
 #pragma unroll
@@ -300,15 +312,15 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
 #pragma unroll
       for (int e = 0; e < 16; ++e) kacc[mbk][e] = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
+    for (int ks = 0; ks < KSR; ++ks) {
       h16x8 xf;
       if constexpr (QB == 0) {
-        xf = *(const lds_h16x8_t*)(uintptr_t)(xbase ^ (unsigned)(ks << 5));               // chunk (2 ks + hi) ^ (row & 15)
+        xf = *(const lds_h16x8_t*)(uintptr_t)(xbase ^ (unsigned)(ks << 5));               // chunk (2 ks + hi) ^ (row & (CPRX - 1))
       } else {
         // 8 codes = 4 bytes at byte 8 ks + 4 hi of the row's 64: chunk ks >> 1 (at position ^ ((row >> 1) & 3)), nibble e of the dword =
         // column 16 ks + 8 hi + e; the pairs come out as (0, 4) (1, 5) (2, 6) (3, 7): bt carries its columns in that order
         const unsigned d = *(const __attribute__((address_space(3))) unsigned*)(uintptr_t)(
-            lds0 + OFF_XS + (unsigned)(row * 64 + ((((ks >> 1) ^ ((row >> 1) & 3))) << 4) + 8 * (ks & 1) + 4 * hi));
+            lds0 + OFF_XS + (unsigned)(row * RQB + ((((ks >> 1) ^ ((row >> 1) & (CQ - 1)))) << 4) + 8 * (ks & 1) + 4 * hi));
         const h16x2 m2 = __builtin_bit_cast(h16x2, kmeta);
         const h16x2 sc2 = h16x2{m2[0], m2[0]};
         const h16 nb = -((h16)1024.f + m2[1]);
@@ -582,16 +594,30 @@ __global__ void rope_cs_table_kernel(const float* __restrict__ inv_freq, int pos
   out[(int64_t)t * 128 + 64 + i] = (h16)sn;
 }
 
-template <int NCB, int QB>
+template <int NCB, int KSR, int QB>
 int launch_prefill_lat(const PfLatParams& p, hipStream_t stream) {
   constexpr int smem = 3 * PL_BN * 256 + 2 * 32 * 64 * NCB + 4 * 4096 + 4 * 32 * 4 + 32 * 1024 + (QB ? 2 * 16 * 32 * NCB : 0);
-  auto kern = prefill_lat_kernel<NCB, QB>;
+  auto kern = prefill_lat_kernel<NCB, KSR, QB>;
   const int rca = palu_func_max_lds(reinterpret_cast<const void*>(kern), smem);
   if (rca) return rca;
   dim3 grid(p.head_major == 2 ? p.H * p.nqt : (p.head_major ? p.H : p.nqt), p.head_major == 2 ? 1 : (p.head_major ? p.nqt : p.H), 1);
   hipLaunchKernelGGL(kern, grid, dim3(PL_THREADS), smem, stream, p);
   PALU_LAUNCH_CHECK();
   return PALU_OK;
+}
+
+template <int QB>
+int dispatch_prefill_lat(const PfLatParams& p, int Rk, int Rv, hipStream_t s) {
+#define PL_CASE(NCB)                                                             \
+  case NCB:                                                                      \
+    return Rk == 128 ? launch_prefill_lat<NCB, 8, QB>(p, s) : launch_prefill_lat<NCB, 4, QB>(p, s);
+  switch (Rv / 32) {
+    PL_CASE(4)
+    PL_CASE(6)
+    PL_CASE(8)
+    default: return Rk == 128 ? launch_prefill_lat<12, 8, QB>(p, s) : launch_prefill_lat<12, 4, QB>(p, s);
+  }
+#undef PL_CASE
 }
 
 }  // namespace
@@ -609,11 +635,11 @@ extern "C" int palu_rope_cs_table_build(const float* inv_freq, int pos0, int npo
 }
 
 extern "C" int palu_prefill_attn_lat_supported(int H, int G, int D, int Rk, int Rv) {
-  return (H > 0 && G > 0 && H % G == 0 && D == 128 && Rk == 128 && (Rv == 384 || Rv == 256 || Rv == 128)) ? 1 : 0;
+  return (H > 0 && G > 0 && H % G == 0 && D == 128 && (Rk == 128 || Rk == 64) && (Rv == 384 || Rv == 256 || Rv == 192 || Rv == 128)) ? 1 : 0;
 }
 
 // Prompt attention of Tq queries (rotated, [H][Tq][128]; the first at absolute position `past`) over the first Tk rows of the
-// latent caches xk [G][.][128], xv [G][.][Rv] (fp16, row l = position l, 16-byte aligned rows); bt = B^T [H][128][128] contiguous;
+// latent caches xk [G][.][128], xv [G][.][Rv] (fp16, row l = position l, 16-byte aligned rows); bt = B^T [H][128][Rk] contiguous;
 // cs = palu_rope_cs_table_build(inv_freq, 0, >= Tk).  out [Tq][H * Rv] fp16.  No workspace.
 extern "C" int palu_prefill_attn_lat_f16(const void* q, int64_t sq_h, int64_t sq_t, const void* xk, int64_t sxk_g, int64_t sxk_l,
                                          const void* xv, int64_t sxv_g, int64_t sxv_l, const void* bt, const void* cs, void* out,
@@ -621,7 +647,7 @@ extern "C" int palu_prefill_attn_lat_f16(const void* q, int64_t sq_h, int64_t sq
                                          float scale, palu_stream_t stream) {
   PALU_REQUIRE(q && xk && xv && bt && cs && out, PALU_ERR_ARG, "prefill_attn_lat: null pointer");
   PALU_REQUIRE(palu_prefill_attn_lat_supported(H, G, D, Rk, Rv), PALU_ERR_UNSUPPORTED,
-               "prefill_attn_lat: needs head_dim 128, rank_k / G = 128, rank_v / G in {128, 256, 384} (H=%d G=%d D=%d Rk=%d Rv=%d)", H, G, D,
+               "prefill_attn_lat: needs head_dim 128, rank_k / G in {64, 128}, rank_v / G in {128, 192, 256, 384} (H=%d G=%d D=%d Rk=%d Rv=%d)", H, G, D,
                Rk, Rv);
   PALU_REQUIRE(Tq >= 0 && Tk >= 0 && past >= 0 && (int64_t)past + Tq < (1 << 30), PALU_ERR_ARG, "prefill_attn_lat: bad lengths");
   if (Tq == 0) return PALU_OK;
@@ -646,18 +672,13 @@ extern "C" int palu_prefill_attn_lat_f16(const void* q, int64_t sq_h, int64_t sq
   if (p.head_major == 2 && H % 8 != 0) p.head_major = 0;
   p.kc = p.vc = nullptr; p.km = p.vm = nullptr;
   p.skc_g = p.skc_l = p.skm_g = p.skm_l = p.svc_g = p.svc_l = p.svm_g = p.svm_l = 0;
-  hipStream_t s = (hipStream_t)stream;
-  switch (Rv / 32) {
-    case 4: return launch_prefill_lat<4, 0>(p, s);
-    case 8: return launch_prefill_lat<8, 0>(p, s);
-    default: return launch_prefill_lat<12, 0>(p, s);
-  }
+  return dispatch_prefill_lat<0>(p, Rk, Rv, (hipStream_t)stream);
 }
 
 // The same over PACKED 4-bit caches (quant.hip's layout: codes [G][.][R / 2] bytes, meta [G][.][2] fp16 (scale, zero) per (token,
 // group) row; byte strides for the codes, element strides for the meta): the codes are de-quantised inside the kernel -- keys in the
 // rebuild's registers, values into the half-tile image -- with unpack_dequant's arithmetic; no fp16 copy of the cache exists.
-// bt = B^T [H][128][128] with the columns of every group of 8 in the order 0 4 1 5 2 6 3 7.
+// bt = B^T [H][128][Rk] with the columns of every group of 8 in the order 0 4 1 5 2 6 3 7.
 extern "C" int palu_prefill_attn_lat_q(const void* q, int64_t sq_h, int64_t sq_t, const void* k_codes, int64_t skc_g, int64_t skc_l,
                                        const void* k_meta, int64_t skm_g, int64_t skm_l, const void* v_codes, int64_t svc_g,
                                        int64_t svc_l, const void* v_meta, int64_t svm_g, int64_t svm_l, const void* bt_perm,
@@ -666,7 +687,7 @@ extern "C" int palu_prefill_attn_lat_q(const void* q, int64_t sq_h, int64_t sq_t
   PALU_REQUIRE(q && k_codes && k_meta && v_codes && v_meta && bt_perm && cs && out, PALU_ERR_ARG, "prefill_attn_lat_q: null pointer");
   PALU_REQUIRE(bits == 4, PALU_ERR_UNSUPPORTED, "prefill_attn_lat_q: 4-bit codes only (got %d)", bits);
   PALU_REQUIRE(palu_prefill_attn_lat_supported(H, G, D, Rk, Rv), PALU_ERR_UNSUPPORTED,
-               "prefill_attn_lat_q: needs head_dim 128, rank_k / G = 128, rank_v / G in {128, 256, 384} (H=%d G=%d D=%d Rk=%d Rv=%d)", H,
+               "prefill_attn_lat_q: needs head_dim 128, rank_k / G in {64, 128}, rank_v / G in {128, 192, 256, 384} (H=%d G=%d D=%d Rk=%d Rv=%d)", H,
                G, D, Rk, Rv);
   PALU_REQUIRE(Tq >= 0 && Tk >= 0 && past >= 0 && (int64_t)past + Tq < (1 << 30), PALU_ERR_ARG, "prefill_attn_lat_q: bad lengths");
   if (Tq == 0) return PALU_OK;
@@ -681,7 +702,7 @@ extern "C" int palu_prefill_attn_lat_q(const void* q, int64_t sq_h, int64_t sq_t
                PALU_ERR_UNSUPPORTED, "prefill_attn_lat_q: one group's code slab must stay below 4 GiB");
   PfLatParams p;
   p.q = (const h16*)q; p.sq_h = sq_h; p.sq_t = sq_t;
-  p.xk = (const h16*)k_codes; p.sxk_g = 0; p.sxk_l = 128;      // (fp16 staging geometry unused)
+  p.xk = (const h16*)k_codes; p.sxk_g = 0; p.sxk_l = Rk;       // (fp16 staging geometry unused)
   p.xv = (const h16*)v_codes; p.sxv_g = 0; p.sxv_l = Rv;
   p.kc = (const unsigned char*)k_codes; p.skc_g = skc_g; p.skc_l = skc_l;
   p.km = (const h16*)k_meta; p.skm_g = skm_g; p.skm_l = skm_l;
@@ -694,10 +715,5 @@ extern "C" int palu_prefill_attn_lat_q(const void* q, int64_t sq_h, int64_t sq_t
   p.nqt = (Tq + PL_BM - 1) / PL_BM;
   p.head_major = (int64_t)p.nqt * H <= 2048 ? 1 : 2;
   if (p.head_major == 2 && H % 8 != 0) p.head_major = 0;
-  hipStream_t s = (hipStream_t)stream;
-  switch (Rv / 32) {
-    case 4: return launch_prefill_lat<4, 4>(p, s);
-    case 8: return launch_prefill_lat<8, 4>(p, s);
-    default: return launch_prefill_lat<12, 4>(p, s);
-  }
+  return dispatch_prefill_lat<4>(p, Rk, Rv, (hipStream_t)stream);
 }

@@ -73,14 +73,15 @@ def _ref_f32(q, keys, xv, past, causal):
     return ctx.transpose(0, 1).reshape(Tq, H * Rv)
 
 
-@pytest.mark.parametrize("H,gs,Tq,Tk,Rv,causal", [
-    (4, 4, 128, 128, 384, True), (8, 4, 130, 130, 384, True), (8, 4, 257, 257, 128, True), (32, 4, 300, 300, 384, True),
-    (4, 1, 1, 200, 256, False), (8, 4, 129, 1000, 384, True), (4, 4, 128, 192, 384, False), (8, 4, 333, 333, 256, True),
-    (32, 4, 1100, 1100, 384, True), (8, 2, 64, 4097, 384, True), (4, 4, 200, 70, 384, False),
+@pytest.mark.parametrize("H,gs,Tq,Tk,Rk,Rv,causal", [
+    (4, 4, 128, 128, 128, 384, True), (8, 4, 130, 130, 128, 384, True), (8, 4, 257, 257, 128, 128, True), (32, 4, 300, 300, 128, 384, True),
+    (4, 1, 1, 200, 128, 256, False), (8, 4, 129, 1000, 128, 384, True), (4, 4, 128, 192, 128, 384, False), (8, 4, 333, 333, 128, 256, True),
+    (32, 4, 1100, 1100, 128, 384, True), (8, 2, 64, 4097, 128, 384, True), (4, 4, 200, 70, 128, 384, False),
+    (32, 4, 700, 700, 64, 192, True), (8, 4, 129, 1000, 64, 192, False), (8, 4, 300, 300, 64, 384, True), (8, 4, 257, 520, 128, 192, True),   # config-4 ranks
 ])
-def test_latent_prefill_kernel_vs_workspace_form_and_fp32(H, gs, Tq, Tk, Rv, causal):
+def test_latent_prefill_kernel_vs_workspace_form_and_fp32(H, gs, Tq, Tk, Rk, Rv, causal):
     _lib, ar = _mods()
-    G, Rk = H // gs, 128
+    G = H // gs
     g = torch.Generator().manual_seed(H * 1000 + Tq + Tk + Rv)
     past = Tk - Tq if causal and Tk >= Tq else 0
     q = torch.randn(H, Tq, D, generator=g).half().to(DEV)
@@ -105,11 +106,12 @@ def test_latent_prefill_rejects_unsupported_shapes():
     _lib, _ = _mods()
     lib = _lib.lib
     assert lib.palu_prefill_attn_lat_supported(32, 8, 128, 128, 384) == 1
-    assert lib.palu_prefill_attn_lat_supported(32, 8, 128, 64, 192) == 0
+    assert lib.palu_prefill_attn_lat_supported(32, 8, 128, 64, 192) == 1           # config-4 ranks
+    assert lib.palu_prefill_attn_lat_supported(32, 8, 128, 32, 96) == 0            # config-1 ranks: workspace form
     assert lib.palu_prefill_attn_lat_supported(32, 8, 64, 128, 384) == 0
     t = torch.zeros(1024, dtype=torch.float16, device=DEV)
     rc = lib.palu_prefill_attn_lat_f16(t.data_ptr(), 128, 128, t.data_ptr(), 128, 128, t.data_ptr(), 192, 192, t.data_ptr(), t.data_ptr(),
-                                       t.data_ptr(), 192, 4, 1, 128, 1, 1, 64, 192, 0, 1, 0.1, torch.cuda.current_stream().cuda_stream)
+                                       t.data_ptr(), 192, 4, 1, 128, 1, 1, 32, 96, 0, 1, 0.1, torch.cuda.current_stream().cuda_stream)
     assert rc != 0
 
 
@@ -136,14 +138,16 @@ def _module(hidden, H, gs, Rk, Rv, seed=0):
     return m.eval().prepare_decode()
 
 
+@pytest.mark.parametrize("ranks", [(128, 384), (64, 192)], ids=["config2_ranks", "config4_ranks"])
 @pytest.mark.parametrize("bits", [16, 4])
 @pytest.mark.parametrize("causal", [True, False])
-def test_prompt_pass_in_latent_form_equals_workspace_form_and_feeds_decode(causal, bits):
+def test_prompt_pass_in_latent_form_equals_workspace_form_and_feeds_decode(causal, bits, ranks):
     """LlamaPaluAttention.forward with the latent kernel forced (PREFILL_LATENT_ABOVE = 0, query chunks of 256 -- and 200, not a
     multiple of the kernel's 128-query tile) against the workspace form (None): same output, identical cache contents, a second
     prompt pass on top of the first (past > 0), and a decode step from either cache."""
     from palu_amd.kernel.palu_attention import LatentCache, QuantLatentCache
-    hidden, H, gs, Rk, Rv, T1, T2 = 1024, 8, 4, 128, 384, 700, 333
+    hidden, H, gs, T1, T2 = 1024, 8, 4, 700, 333
+    Rk, Rv = ranks
     m = _module(hidden, H, gs, Rk, Rv)
     x1 = torch.randn(1, T1, hidden, device=DEV, dtype=torch.float16)
     x2 = torch.randn(1, T2, hidden, device=DEV, dtype=torch.float16)
@@ -220,18 +224,19 @@ def bt_perm_of(b):
     return b.transpose(1, 2).reshape(H, D, R // 8, 8)[..., idx].reshape(H, D, R).contiguous()
 
 
-@pytest.mark.parametrize("H,gs,Tq,Tk,Rv,causal", [
-    (4, 4, 128, 128, 384, True), (8, 4, 257, 257, 128, True), (32, 4, 300, 300, 384, True), (8, 4, 129, 1000, 384, True),
-    (4, 4, 200, 70, 384, False), (8, 4, 333, 333, 256, True), (8, 2, 64, 4097, 384, True),
+@pytest.mark.parametrize("H,gs,Tq,Tk,Rk,Rv,causal", [
+    (4, 4, 128, 128, 128, 384, True), (8, 4, 257, 257, 128, 128, True), (32, 4, 300, 300, 128, 384, True), (8, 4, 129, 1000, 128, 384, True),
+    (4, 4, 200, 70, 128, 384, False), (8, 4, 333, 333, 128, 256, True), (8, 2, 64, 4097, 128, 384, True),
+    (32, 4, 700, 700, 64, 192, True), (8, 4, 129, 1000, 64, 192, False), (8, 4, 257, 520, 128, 192, True),                                     # config-4 ranks
 ])
-def test_latent_prefill_kernel_on_packed_4bit_caches(H, gs, Tq, Tk, Rv, causal):
+def test_latent_prefill_kernel_on_packed_4bit_caches(H, gs, Tq, Tk, Rk, Rv, causal):
     """palu_prefill_attn_lat_q de-quantises the codes inside the kernel: same result as the fp16 kernel on unpack_dequant()'s rows
     (identical fp16 values enter the MFMAs; only the rebuild's summation order differs through the permuted B^T columns), and the
     fp32 evaluation on those rows."""
     from palu_amd.kernel.quant import quantize_pack, unpack_dequant
     _lib, ar = _mods()
     lib, S = _lib.lib, torch.cuda.current_stream().cuda_stream
-    G, Rk = H // gs, 128
+    G = H // gs
     g = torch.Generator().manual_seed(7 * H + Tq + Tk + Rv)
     past = Tk - Tq if causal and Tk >= Tq else 0
     q = torch.randn(H, Tq, D, generator=g).half().to(DEV)
