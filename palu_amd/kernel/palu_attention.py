@@ -791,7 +791,7 @@ class LlamaPaluAttention(nn.Module):
     # (2 t H (D + Rv) bytes: 64 MiB at PREFILL_LATENT_QUERY_CHUNK = 2048 and the config-2 ranks), whatever the prompt length.  It costs
     # the rebuild's +25 % of matrix work (64k tokens: ~105 ms against ~82 ms for the one-launch workspace form with its 2.4 GiB of
     # transients), so it is selected when the workspace form would exceed PREFILL_LATENT_ABOVE bytes of transients; 0 = always,
-    # None = never.  fp16 caches at head_dim 128, rank_k / G = 128, rank_v / G in {128, 256, 384}.
+    # None = never.  fp16 and packed 4-bit caches at head_dim 128, rank_k / G in {64, 128}, rank_v / G in {128, 192, 256, 384}.
     PREFILL_LATENT_ABOVE = 256 << 20
     PREFILL_LATENT_QUERY_CHUNK = 2048
 
