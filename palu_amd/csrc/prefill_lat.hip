@@ -36,6 +36,7 @@
 #endif
 
 namespace {
+unsigned long long* g_pl_timeline = nullptr;
 
 constexpr int PL_THREADS = 512;
 constexpr int PL_BM = 128;   // queries per workgroup
@@ -65,7 +66,16 @@ struct PfLatParams {
   int64_t svc_g, svc_l;
   const h16* vm;
   int64_t svm_g, svm_l;
+  unsigned long long* dbg;   // -DPL_TIMELINE builds: [wave 8][64] s_memtime stamps of workgroup 0, tiles 16 .. (tools/time_prefill_lat.py)
 };
+
+template <int I, int N, class F>
+static __device__ __forceinline__ void pl_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    pl_for<I + 1, N>(f);
+  }
+}
 
 typedef __attribute__((address_space(3))) h16x8 lds_h16x8_t;
 typedef __attribute__((address_space(3))) h16x4 lds_h16x4_t;
@@ -87,8 +97,7 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
   constexpr int XS_BYTES = PL_BN * 256;             // X tile: 64 rows x 128 fp16 (16 chunks per row, XOR-swizzled by row & 15)
   constexpr int KS_BYTES = PL_BN * 256;             // K~ tile, same geometry
   constexpr int VH_BYTES = 32 * RVB;                // half a V tile: 32 rows, row-major, 32-byte granules XOR-swizzled by row & 3
-  constexpr int NVP = VH_BYTES / 1024;              // DMA pieces of half a V tile: piece w + 8 i belongs to wave w
-  constexpr int VPW = (NVP + 7) / 8;
+  constexpr int NVP = VH_BYTES / 1024;              // DMA pieces of half a V tile
   constexpr int OFF_XS = 0;
   constexpr int OFF_VS = OFF_XS + XS_BYTES;         // (the DMA targets first: LDS offsets below 128 KB)
   constexpr int OFF_KS = OFF_VS + 2 * VH_BYTES;     // two K~ tile images: tile jt in image jt & 1
@@ -106,6 +115,21 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef PL_TIMELINE
+  unsigned stamp_off = 0;
+  unsigned long long* const dbg_w = p.dbg + w * 64;
+  const bool stamp_on = p.dbg != nullptr && blockIdx.x == 0 && blockIdx.y == 0;
+  auto stamp = [&](int jt) {                          // scalar registers only (abx_rope3_kernel.h)
+    if (stamp_on && jt >= 16 && jt < 24) {
+      unsigned long long t;
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t));
+      asm volatile("s_store_dwordx2 %0, %1, %2" ::"s"(t), "s"(dbg_w), "s"(stamp_off) : "memory");
+      stamp_off = (stamp_off + 8) & (64 * 8 - 1);
+    }
+  };
+#else
+  auto stamp = [](int) {};
+#endif
   const bool swave = w < 4;
   const int qblk = w & 3;
   const int n = lane & 31, hi = lane >> 5;
@@ -158,16 +182,20 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
         : "s"(dst), "v"(voff), "s"(rs), "s"(soff)
         : "memory");
   };
-  // X tile: piece (w + 8 i) = rows (64 / CPRX) (w + 8 i) .. , CPRX chunks each (rows past Tk are outside the descriptor: their scores
-  // are masked); 8 pieces are a multiple of CPRX rows, so the swizzle key of a lane's row does not depend on i
-  const int xrow_l = (64 / CPRX) * w + lane / CPRX;
+  // ALL staging is requested by the four S-waves (piece w + 4 i belongs to S-wave w): a CU takes in ~28 B per clock, the wave that
+  // issues a request sits in it, and the S-waves have the slack (timeline: the O-wave spent 1.3 k of a 7.3 k-tick tile issuing its
+  // five pieces on the workgroup's critical path; profiles/r06_prefill_lat_timeline.txt)
+  // X tile: piece p = rows (64 / CPRX) p .. , CPRX chunks each (rows past Tk are outside the descriptor: their scores are masked);
+  // 4 pieces are a multiple of CPRX rows, so the swizzle key of a lane's row does not depend on i
+  const int xrow_l = (64 / CPRX) * (w & 3) + lane / CPRX;
   const unsigned xvo = (unsigned)((xrow_l * p.sxk_l + (((lane % CPRX) ^ (xrow_l & (CPRX - 1))) << 3)) * 2);
   const unsigned xtile_bytes = __builtin_amdgcn_readfirstlane((unsigned)(PL_BN * p.sxk_l * 2));
-  const unsigned xstep_bytes = __builtin_amdgcn_readfirstlane((unsigned)(8 * (64 / CPRX) * p.sxk_l * 2));
-  auto dma_x = [&](int jt) {
+  const unsigned xstep_bytes = __builtin_amdgcn_readfirstlane((unsigned)(4 * (64 / CPRX) * p.sxk_l * 2));
+  static_assert((4 * (64 / CPRX)) % CPRX == 0, "four pieces of the X tile are whole swizzle periods");
+  auto dma_x = [&](int jt) {                          // (xvo depends on w & 3 only: either role can issue it)
 #pragma unroll
-    for (int i = 0; i < NXP / 8; ++i)
-      dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_XS + (w + 8 * i) * 1024), xvo, xrs,
+    for (int i = 0; i < NXP / 4; ++i)
+      dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_XS + ((w & 3) + 4 * i) * 1024), xvo, xrs,
           __builtin_amdgcn_readfirstlane((unsigned)jt * xtile_bytes + i * xstep_bytes));
   };
   // packed keys: the tile's codes (64 rows x RK / 2 bytes) as CQ pieces of 64 / CQ rows, waves 0 .. CQ - 1 one each; 16-byte chunk c of
@@ -176,20 +204,27 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
   const u32x4 xqrs = QB ? make_rsrc(p.kc + (int64_t)g * p.skc_g, (int64_t)(p.Tk - 1) * p.skc_l + RQB) : xrs;
   const unsigned xqvo = QB ? (unsigned)((lane / CQ) * (int)p.skc_l + (((lane % CQ) ^ (((lane / CQ) >> 1) & (CQ - 1))) << 4)) : 0u;
   auto dma_xq = [&](int jt) {
-    if (w < CQ)
-      dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_XS + w * 1024), xqvo, xqrs,
-          __builtin_amdgcn_readfirstlane((unsigned)(jt * PL_BN + (64 / CQ) * w) * (unsigned)p.skc_l));
+    if ((w & 3) < CQ)
+      dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_XS + (w & 3) * 1024), xqvo, xqrs,
+          __builtin_amdgcn_readfirstlane((unsigned)(jt * PL_BN + (64 / CQ) * (w & 3)) * (unsigned)p.skc_l));
   };
   // packed values: the codes of half a tile, linear ([row][RV / 2 bytes] as in memory): piece w = 16-byte chunks 64 w .. 64 w + 63; the
   // lane that de-quantises chunk q = 64 w + lane (row q / NCB, columns 32 (q % NCB) ..) also fetches that row's (scale, zero)
+  constexpr int VQI = 1;                            // piece w belongs to wave w (NVC <= 6: the S-waves and, at rank_v / G = 384, O-waves 4 and 5)
   const u32x4 vqrs = QB ? make_rsrc(p.vc + (int64_t)g * p.svc_g, (int64_t)(p.Tk - 1) * p.svc_l + RV / 2) : vrs;
-  const int vq_row = (64 * w + lane) / NCB, vq_c = (64 * w + lane) % NCB;
-  unsigned vmeta_next = 0, vmeta_cur = 0;
-  auto vc_issue = [&](int jt, int half) {           // codes of half tile (jt, half) into staging `half` + the row's meta
+  unsigned vmeta_next[VQI], vmeta_cur[VQI];
+#pragma unroll
+  for (int i = 0; i < VQI; ++i) vmeta_next[i] = vmeta_cur[i] = 0;
+  auto vc_issue = [&](int jt, int half) {           // codes of half tile (jt, half) into staging `half` + the rows' metas
     if (QB == 0 || w >= NVC) return;
-    const int row = min(jt * PL_BN + 32 * half + vq_row, p.Tk - 1);     // (rows past Tk re-read row Tk - 1: finite values x probability 0)
-    dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_VC + half * VC_BYTES + w * 1024), (unsigned)(row * (int)p.svc_l + vq_c * 16), vqrs, 0u);
-    vmeta_next = *reinterpret_cast<const unsigned*>(p.vm + (int64_t)g * p.svm_g + (int64_t)row * p.svm_l);
+#pragma unroll
+    for (int i = 0; i < VQI; ++i) {
+      const int q = 64 * w + lane;
+      const int row = min(jt * PL_BN + 32 * half + q / NCB, p.Tk - 1);   // (rows past Tk re-read row Tk - 1: finite values x probability 0)
+      dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_VC + half * VC_BYTES + w * 1024),
+          (unsigned)(row * (int)p.svc_l + (q % NCB) * 16), vqrs, 0u);
+      vmeta_next[i] = *reinterpret_cast<const unsigned*>(p.vm + (int64_t)g * p.svm_g + (int64_t)row * p.svm_l);
+    }
   };
   // (a + nb) * s on pairs: a = 0x6400 | code = 1024 + code exactly, nb = -(1024 + zero): the difference is exact, one rounding in the
   // product -- unpack_dequant's arithmetic (quant.hip; quantize_tensor's `(q - zero) * scale` in fp16, quant.py:37-39)
@@ -200,55 +235,75 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
   };
   auto vc_dequant = [&](int half) {                 // staging `half` -> fp16 row-major image slot `half` (granule-swizzled like the DMA form)
     if (QB == 0 || w >= NVC) return;
-    const u32x4 cd = *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)(lds0 + OFF_VC + half * VC_BYTES + (64 * w + lane) * 16);
-    const h16x2 m2 = __builtin_bit_cast(h16x2, vmeta_cur);
-    const h16x2 sc2 = h16x2{m2[0], m2[0]};
-    const h16 nb = -((h16)1024.f + m2[1]);
-    const h16x2 nb2 = h16x2{nb, nb};
-    const unsigned rowb = lds0 + OFF_VS + (unsigned)(half * VH_BYTES + vq_row * RVB);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {                   // dword j = columns 32 c + 8 j .. + 7 in natural order
-      const unsigned d = cd[j];
-      const unsigned t0 = d & 0x0F0F0F0Fu, t1 = (d >> 4) & 0x0F0F0F0Fu;    // codes 0 2 4 6 / 1 3 5 7 in bytes
-      u32x4 o;
-      o[0] = deq2(__builtin_amdgcn_perm(t1, t0, 0x0c040c00u), nb2, sc2);   // (c0, c1): byte 0 of t0, byte 0 of t1
-      o[1] = deq2(__builtin_amdgcn_perm(t1, t0, 0x0c050c01u), nb2, sc2);
-      o[2] = deq2(__builtin_amdgcn_perm(t1, t0, 0x0c060c02u), nb2, sc2);
-      o[3] = deq2(__builtin_amdgcn_perm(t1, t0, 0x0c070c03u), nb2, sc2);
-      const int gran = 2 * vq_c + (j >> 1);
-      *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(rowb + (unsigned)(((gran ^ (vq_row & 3)) << 5) + 16 * (j & 1))) = o;
+    for (int i = 0; i < VQI; ++i) {
+      const int q = 64 * w + lane;
+      const int vq_row = q / NCB, vq_c = q % NCB;
+      const u32x4 cd = *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)(lds0 + OFF_VC + half * VC_BYTES + q * 16);
+      const h16x2 m2 = __builtin_bit_cast(h16x2, vmeta_cur[i]);
+      const h16x2 sc2 = h16x2{m2[0], m2[0]};
+      const h16 nb = -((h16)1024.f + m2[1]);
+      const h16x2 nb2 = h16x2{nb, nb};
+      const unsigned rowb = lds0 + OFF_VS + (unsigned)(half * VH_BYTES + vq_row * RVB);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {                 // dword j = columns 32 c + 8 j .. + 7 in natural order
+        const unsigned d = cd[j];
+        const unsigned t0 = d & 0x0F0F0F0Fu, t1 = (d >> 4) & 0x0F0F0F0Fu;  // codes 0 2 4 6 / 1 3 5 7 in bytes
+        u32x4 o;
+        o[0] = deq2(__builtin_amdgcn_perm(t1, t0, 0x0c040c00u), nb2, sc2); // (c0, c1): byte 0 of t0, byte 0 of t1
+        o[1] = deq2(__builtin_amdgcn_perm(t1, t0, 0x0c050c01u), nb2, sc2);
+        o[2] = deq2(__builtin_amdgcn_perm(t1, t0, 0x0c060c02u), nb2, sc2);
+        o[3] = deq2(__builtin_amdgcn_perm(t1, t0, 0x0c070c03u), nb2, sc2);
+        const int gran = 2 * vq_c + (j >> 1);
+        *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(rowb + (unsigned)(((gran ^ (vq_row & 3)) << 5) + 16 * (j & 1))) = o;
+      }
     }
   };
-  // V half tile: wave w stages rows 4 w' .. of each group of 4 rows it owns: piece k = VPW w + i covers LDS slots
-  // [64 k, 64 k + 64); slot s: row s / SPR, 16-byte slot s % SPR of the row; LDS granule (32 B) gl of row r holds source granule
-  // gl ^ (r & 3).  VPW pieces = (VPW * 64 / SPR) whole rows, a multiple of 4: the pattern of a piece is a lane constant.
+  // V half tile (fp16 caches): piece p covers LDS slots [64 p, 64 p + 64); slot s: row s / SPR, 16-byte slot s % SPR of the row; LDS
+  // granule (32 B) gl of row r holds source granule gl ^ (r & 3).  The lane pattern of a piece repeats every PER pieces (= whole
+  // groups of 4 rows): a wave takes blocks of PER consecutive pieces (block 4 j + (w & 3)), so PER lane constants serve and the block
+  // is a scalar row offset
   constexpr int SPR = RVB / 16;                     // 16-byte slots per row
-  unsigned vvo[VPW];
+  constexpr int PER = (NCB == 12 || NCB == 6) ? 3 : (NCB == 8 ? 2 : (NCB == 10 ? 5 : 1));
+  static_assert((PER * 64) % (4 * SPR) == 0 && NVP % (4 * PER) == 0, "blocks of PER pieces are whole groups of 4 rows, 4 waves share them evenly");
+  constexpr int RPB = PER * 64 / SPR;               // rows per block
+  constexpr int NBW = NVP / PER / 4;                // blocks per wave
+  unsigned vvo[PER];
 #pragma unroll
-  for (int i = 0; i < VPW; ++i) {
-    const int s = (w + 8 * i) * 64 + lane;
+  for (int c = 0; c < PER; ++c) {
+    const int s = c * 64 + lane;
     const int r = s / SPR, sr = s % SPR;
-    vvo[i] = (unsigned)(r * (int)(p.sxv_l * 2) + ((((sr >> 1) ^ (r & 3)) << 1) + (sr & 1)) * 16);
+    vvo[c] = (unsigned)(r * (int)(p.sxv_l * 2) + ((((sr >> 1) ^ (r & 3)) << 1) + (sr & 1)) * 16);
   }
-  const unsigned vhalf_bytes = __builtin_amdgcn_readfirstlane((unsigned)(32 * p.sxv_l * 2));
-  auto dma_v = [&](int jt, int half) {              // half tile (jt, half) into slot `half`
+  const unsigned vrow_bytes = __builtin_amdgcn_readfirstlane((unsigned)(p.sxv_l * 2));
+  // `all8`: the blocks are dealt to all eight waves (block 8 j + w) instead of the four waves of one role (block 4 j + (w & 3))
+  auto dma_v = [&](int jt, int half, bool all8) {   // half tile (jt, half) into slot `half`
     const int row0 = jt * PL_BN + 32 * half;
+    const int nw = all8 ? 8 : 4, wi = all8 ? w : (w & 3);
     if (row0 + 32 <= p.Tk) {
 #pragma unroll
-      for (int i = 0; i < VPW; ++i)
-        if (w + 8 * i < NVP)
-          dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_VS + half * VH_BYTES + (w + 8 * i) * 1024), vvo[i], vrs,
-              __builtin_amdgcn_readfirstlane((unsigned)(2 * jt + half) * vhalf_bytes));
+      for (int j = 0; j < NBW; ++j) {
+        const int blk = nw * j + wi;
+        if (blk >= 4 * NBW) continue;
+#pragma unroll
+        for (int c = 0; c < PER; ++c)
+          dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_VS + half * VH_BYTES + (PER * blk + c) * 1024), vvo[c], vrs,
+              __builtin_amdgcn_readfirstlane((unsigned)(row0 + RPB * blk) * vrow_bytes));
+      }
     } else {
       // the cache's last rows: rows past Tk re-read row Tk - 1 (finite data; their probabilities are exactly zero)
 #pragma unroll
-      for (int i = 0; i < VPW; ++i) {
-        if (w + 8 * i >= NVP) continue;
-        const int s = (w + 8 * i) * 64 + lane;
-        const int r = s / SPR, sr = s % SPR;
-        const int row = min(row0 + r, p.Tk - 1);
-        dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_VS + half * VH_BYTES + (w + 8 * i) * 1024),
-            (unsigned)(row * (int)(p.sxv_l * 2) + ((((sr >> 1) ^ (r & 3)) << 1) + (sr & 1)) * 16), vrs, 0u);
+      for (int j = 0; j < NBW; ++j) {
+        const int blk = nw * j + wi;
+        if (blk >= 4 * NBW) continue;
+#pragma unroll
+        for (int c = 0; c < PER; ++c) {
+          const int s = (PER * blk + c) * 64 + lane;
+          const int r = s / SPR, sr = s % SPR;
+          const int row = min(row0 + r, p.Tk - 1);
+          dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_VS + half * VH_BYTES + (PER * blk + c) * 1024),
+              (unsigned)(row * (int)(p.sxv_l * 2) + ((((sr >> 1) ^ (r & 3)) << 1) + (sr & 1)) * 16), vrs, 0u);
+        }
       }
     }
   };
@@ -451,26 +506,45 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
           for (int e = 0; e < 16; ++e) acc_o[cb][e] *= al;
       }
     }
+    // software pipeline over the half's 2 NCB (k-step, column block) steps in groups of GS: the transpose reads of group g + 1 are in
+    // flight while the MFMAs of group g run (timeline of the first version: a P.V half took 1.9 - 3.2 k ticks for 768 cycles of matrix
+    // pipe -- read, wait, three MFMAs, read ...; the O-wave is alone on its SIMD's LDS latency)
+    constexpr int GS = (NCB % 3 == 0) ? 3 : 2;
+    constexpr int NG = 2 * NCB / GS;
+    const h16x8 pf0 = *(const lds_h16x8_t*)(uintptr_t)(psrc + (unsigned)((2 * half) * 1024));
+    const h16x8 pf1 = *(const lds_h16x8_t*)(uintptr_t)(psrc + (unsigned)((2 * half + 1) * 1024));
+    typedef __attribute__((address_space(3))) char lds_char;
+    auto vload = [&](h16x8 (&vf)[GS], auto g_c) {
+      constexpr int gq = decltype(g_c)::value;
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      const h16x8 pf = *(const lds_h16x8_t*)(uintptr_t)(psrc + (unsigned)((2 * half + s) * 1024));
-#pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) {
-        // (constant offsets on an LDS pointer: they ride in the instructions' offset fields instead of 24 address registers)
-        typedef __attribute__((address_space(3))) char lds_char;
-        lds_char* ap = (lds_char*)(uintptr_t)((cb & 1) ? tr_o : tr_e) + (half * VH_BYTES + s * 16 * RVB + (cb >> 1) * 128);
+      for (int e = 0; e < GS; ++e) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int t = gq * GS + e, st = t / NCB, cb = t % NCB;
+        // (constant offsets on an LDS pointer: they ride in the instructions' offset fields instead of address registers)
+        lds_char* ap = (lds_char*)(uintptr_t)((cb & 1) ? tr_o : tr_e) + (half * VH_BYTES + st * 16 * RVB + (cb >> 1) * 128);
         const h16x4 lo = __builtin_bit_cast(h16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((pvm::lds_s16x4*)ap));
         const h16x4 hh = __builtin_bit_cast(h16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((pvm::lds_s16x4*)(ap + 4 * RVB)));
-        const h16x8 vf = __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
-#if !(PL_EXP & 4)
-        acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, acc_o[cb], 0, 0, 0);
-#else
-        acc_o[cb][0] += (float)vf[0] + (float)pf[0];
-#endif
-        // (192 accumulators leave ~50 registers: keep hipcc from hoisting every fragment of the k-step in front of its MFMAs)
-        if (cb % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+        vf[e] = __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
       }
-    }
+    };
+    h16x8 vfA[GS], vfB[GS];
+    vload(vfA, std::integral_constant<int, 0>{});
+    auto pv_group = [&](auto g_c) {
+      constexpr int gq = decltype(g_c)::value;
+      if constexpr (gq + 1 < NG) vload((gq & 1) ? vfA : vfB, std::integral_constant<int, gq + 1>{});
+#pragma unroll
+      for (int e = 0; e < GS; ++e) {
+        const int t = gq * GS + e, st = t / NCB, cb = t % NCB;
+#if !(PL_EXP & 4)
+        acc_o[cb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(((gq & 1) ? vfB : vfA)[e], st ? pf1 : pf0, acc_o[cb], 0, 0, 0);
+#else
+        acc_o[cb][0] += (float)((gq & 1) ? vfB : vfA)[e][0] + (float)pf0[0];
+#endif
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    pl_for<0, NG>(pv_group);
   };
 
   // ================================================================================================ pipeline
@@ -486,12 +560,15 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
       if (QB) asm volatile("" : "+v"(kmeta));
     }
     if (QB) {
-      asm volatile("" : "+v"(vmeta_next));
-      vmeta_cur = vmeta_next;
+#pragma unroll
+      for (int i = 0; i < VQI; ++i) {
+        asm volatile("" : "+v"(vmeta_next[i]));
+        vmeta_cur[i] = vmeta_next[i];
+      }
     }
   };
   if (njt > 0) {
-    if (QB) dma_xq(0); else dma_x(0);
+    if (swave) { if (QB) dma_xq(0); else dma_x(0); }
     vc_issue(0, 0);
     if (swave) load_cs(0);
     dma_wait();
@@ -503,20 +580,27 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
   // The O-wave runs half a tile behind the S-wave: alpha(jt) = second half of P.V of tile jt - 1, beta(jt) = first half of tile jt
   // (whose probabilities the S-wave wrote in alpha(jt)) -- so one probability buffer serves, each k-step pair written in one phase
   // and read in the next.
-  // (packed values: the codes arrive one phase earlier in a staging buffer and waves 0 .. NVC - 1 write the fp16 image of the half
-  //  tile at the start of the phase in which the DMA form would have requested it)
+  // who requests what (timelines, profiles/r06_prefill_lat_timeline.txt): a CU takes in ~28 B per clock and a wave sits 100 - 250 ticks
+  // in every 1 KB piece it requests -- 64 pieces per tile.  Three assignments were measured within 2 % of each other (all staging by the
+  // S-waves 91.7 ms at 64k tokens; phase alpha by the O-waves, beta by the S-waves 92.6; X by S, V(.., 0) by O, V(.., 1) by all eight
+  // 93.5): the S-waves request everything -- the O-waves' P.V (incl. the accumulator rescale) is the longer half of both phases.
   auto stage_alpha = [&](int jt) {
-    if (jt + 1 < njt) { if (QB) dma_xq(jt + 1); else dma_x(jt + 1); }   // consumed by the rebuild in phase beta
     if (QB == 0) {
-      if (jt < njt) dma_v(jt, 0);                     // consumed in phase beta (slot 0 was read in the last phase beta)
-    } else if (jt < njt) {
-      vc_dequant(0);                                  // codes of (jt, 0): staged in the last phase beta (or the prologue)
-      vc_issue(jt, 1);
+      if (swave) {
+        if (jt + 1 < njt) dma_x(jt + 1);              // consumed by the rebuild in phase beta
+        if (jt < njt) dma_v(jt, 0, false);            // consumed in phase beta (slot 0 was read in the last phase beta)
+      }
+    } else {
+      if (!swave && jt + 1 < njt) dma_xq(jt + 1);
+      if (jt < njt) {
+        vc_dequant(0);                                // codes of (jt, 0): staged in the last phase beta (or the prologue)
+        vc_issue(jt, 1);
+      }
     }
   };
   auto stage_beta = [&](int jt) {
     if (QB == 0) {
-      if (jt < njt) dma_v(jt, 1);                     // consumed in the next phase alpha (slot 1 was read in this one)
+      if (swave && jt < njt) dma_v(jt, 1, false);     // consumed in the next phase alpha (slot 1 was read in this one)
     } else {
       if (jt < njt) vc_dequant(1);
       if (jt + 1 < njt) vc_issue(jt + 1, 0);
@@ -524,19 +608,27 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
   };
   if (swave) {
     for (int jt = 0; jt <= njt; ++jt) {               // iteration njt only drains the last tile's P.V
+      stamp(jt);                                      // 0: phase alpha starts
       stage_alpha(jt);                                // ---- phase alpha: scores of tile jt, first half of its softmax
       if (jt + 1 < njt) load_cs(jt + 1);
+      stamp(jt);                                      // 1: staging requested
       if (jt < njt) scores_part1(jt);
+      stamp(jt);                                      // 2: work done
       dma_wait();
       pin_prefetched();
+      stamp(jt);                                      // 3: staging landed
       __syncthreads();
+      stamp(jt);                                      // 4: phase beta starts
       stage_beta(jt);                                 // ---- phase beta: second half, then the rebuild of K~ tile jt + 1 (other image)
       if (jt < njt) scores_part2(jt);
+      stamp(jt);                                      // 5: softmax done
 #if !(PL_EXP & 1)
       if (jt + 1 < njt) build(jt + 1);
 #endif
+      stamp(jt);                                      // 6: rebuild done
       dma_wait();
       pin_prefetched();
+      stamp(jt);                                      // 7: staging landed
       __syncthreads();
     }
     // the row sums (both hi halves) for the O-wave
@@ -551,15 +643,23 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc_o[cb][e] = 0.f;
     for (int jt = 0; jt <= njt; ++jt) {
+      stamp(jt);                                      // 0
       stage_alpha(jt);                                // ---- phase alpha: second half of P.V of tile jt - 1
+      stamp(jt);                                      // 1
       if (jt >= 1) pv_half(std::integral_constant<int, 1>{});
+      stamp(jt);                                      // 2
       dma_wait();
       pin_prefetched();
+      stamp(jt);                                      // 3
       __syncthreads();
+      stamp(jt);                                      // 4
       stage_beta(jt);                                 // ---- phase beta: rescale, first half of tile jt
       if (jt < njt) pv_half(std::integral_constant<int, 0>{});
+      stamp(jt);                                      // 5
+      stamp(jt);                                      // 6
       dma_wait();
       pin_prefetched();
+      stamp(jt);                                      // 7
       __syncthreads();
     }
     __syncthreads();
@@ -579,6 +679,9 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
         }
     }
   }
+#ifdef PL_TIMELINE
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_dcache_wb" ::: "memory");
+#endif
 }
 
 // cos / sin of the key positions as the reference's rotary cache holds them (kernel/palu_attention.py:204: rotary_emb; HF
@@ -621,6 +724,9 @@ int dispatch_prefill_lat(const PfLatParams& p, int Rk, int Rv, hipStream_t s) {
 }
 
 }  // namespace
+
+// debug (-DPL_TIMELINE builds): device buffer [8 waves][64] of s_memtime stamps workgroup 0 of the next launches fills; 0 = off
+extern "C" void palu_prefill_lat_timeline_buffer(void* ptr) { g_pl_timeline = (unsigned long long*)ptr; }
 
 extern "C" size_t palu_rope_cs_table_bytes(int npos) { return npos > 0 ? (size_t)npos * 128 * sizeof(h16) : 0; }
 
@@ -670,6 +776,7 @@ extern "C" int palu_prefill_attn_lat_f16(const void* q, int64_t sq_h, int64_t sq
   p.nqt = (Tq + PL_BM - 1) / PL_BM;
   p.head_major = (int64_t)p.nqt * H <= 2048 ? 1 : 2;
   if (p.head_major == 2 && H % 8 != 0) p.head_major = 0;
+  p.dbg = g_pl_timeline;
   p.kc = p.vc = nullptr; p.km = p.vm = nullptr;
   p.skc_g = p.skc_l = p.skm_g = p.skm_l = p.svc_g = p.svc_l = p.svm_g = p.svm_l = 0;
   return dispatch_prefill_lat<0>(p, Rk, Rv, (hipStream_t)stream);
@@ -708,6 +815,7 @@ extern "C" int palu_prefill_attn_lat_q(const void* q, int64_t sq_h, int64_t sq_t
   p.km = (const h16*)k_meta; p.skm_g = skm_g; p.skm_l = skm_l;
   p.vc = (const unsigned char*)v_codes; p.svc_g = svc_g; p.svc_l = svc_l;
   p.vm = (const h16*)v_meta; p.svm_g = svm_g; p.svm_l = svm_l;
+  p.dbg = g_pl_timeline;
   p.bt = (const h16*)bt_perm; p.cs = (const h16*)cs;
   p.out = (h16*)out; p.so_t = so_t;
   p.H = H; p.G = G; p.gs = H / G; p.Tq = Tq; p.Tk = Tk; p.past = past; p.causal = causal ? 1 : 0;
