@@ -788,12 +788,12 @@ class LlamaPaluAttention(nn.Module):
     # The LATENT form of the prompt pass (round 6, csrc/prefill_lat.hip): the flash kernel rebuilds
     # K~ = RoPE(X_k . B_h) per 64-position kv tile itself and reads the latent values from the cache rows -- no [H, kv, D] key
     # workspace, no transposed value copy: the only transients are the rotated queries and context rows of ONE query chunk
-    # (2 t H (D + Rv) bytes: 64 MiB at PREFILL_LATENT_QUERY_CHUNK = 2048 and the config-2 ranks), whatever the prompt length.  It costs
+    # (2 t H (D + Rv) bytes: 96 MiB at PREFILL_LATENT_QUERY_CHUNK = 3072 and the config-2 ranks), whatever the prompt length.  It costs
     # the rebuild's +25 % of matrix work (64k tokens: ~105 ms against ~82 ms for the one-launch workspace form with its 2.4 GiB of
     # transients), so it is selected when the workspace form would exceed PREFILL_LATENT_ABOVE bytes of transients; 0 = always,
     # None = never.  fp16 and packed 4-bit caches at head_dim 128, rank_k / G in {64, 128}, rank_v / G in {128, 192, 256, 384}.
     PREFILL_LATENT_ABOVE = 256 << 20
-    PREFILL_LATENT_QUERY_CHUNK = 2048
+    PREFILL_LATENT_QUERY_CHUNK = 3072
 
     def _bt_fragments(self, permuted: bool = False):
         """B^T [H, D, Rk] contiguous (row d of head h = the weights that rebuild K[., d]): cached like the abx fragments.
@@ -874,15 +874,13 @@ class LlamaPaluAttention(nn.Module):
                                                             bt.data_ptr(), cs.data_ptr(), ctx.data_ptr(), ctx.stride(0), H, G, D, t, kv,
                                                             Rk, Rv, cache.n_bits, past + c0, 1 if causal else 0, 1.0 / math.sqrt(D),
                                                             stream), "palu_prefill_attn_lat_q")
-            o = self.o_proj(ctx)
-            del ctx, q
-            if c0 == 0 and c1 == q_len:
-                out = o
+            if out is None:
+                out = torch.empty((q_len, self.o_proj.weight.shape[0]), dtype=dt, device=dev)
+            if self.o_proj.bias is None:
+                torch.matmul(ctx, self.o_proj.weight.t(), out=out[c0:c1])                 # (no chunk-sized o_proj output buffer)
             else:
-                if out is None:
-                    out = torch.empty((q_len, o.shape[-1]), dtype=o.dtype, device=dev)
-                out[c0:c1].copy_(o)
-            del o
+                out[c0:c1].copy_(self.o_proj(ctx))
+            del ctx, q
         return out.view(1, q_len, -1)
 
     def _prefill_flash(self, hidden_states, pos, cache, causal: bool):
