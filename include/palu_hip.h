@@ -60,7 +60,7 @@ int palu_rope_inv_freq_host(float theta, int head_dim, float* out_host);
 size_t palu_abx_bfrag_bytes(int H, int G, int R);
 /* Numerics switch of the R in {32,64,128} fast path (process-wide, returns the previous value):
  * 1 (default) folds the query into the B fragments once per launch -- one extra fp16 operand
- * rounding, same size as the oracle's own rounding of K (abx_rope.py:164); 0 keeps q in fp32. */
+ * rounding, same size as the oracle's own rounding of K (abx_rope.py:164); 0 keeps q in fp32; a negative value only queries. */
 int palu_abx_set_fold(int enable);
 int palu_abx_prepare_b(const void* b, int64_t sb_h, int64_t sb_r, int64_t sb_d,
                        int H, int G, int R, int D, void* bfrag, palu_stream_t stream);
@@ -439,8 +439,8 @@ size_t palu_prefill_state_bytes(int H, int Tq, int Rv, int which);
  * [H, kv, D] key workspace and no transposed value copy.  q [H][Tq][128] rotated queries (first one at absolute position `past`),
  * xk [G][>= Tk][128] / xv [G][>= Tk][Rv] fp16 latent caches (row l = position l), bt = B^T [H][128 d][Rk] contiguous (the rows
  * of U_h), cs = the rotary cache of the key positions 0 .. Tk - 1, [pos][2][64] fp16 (cos row, sin row), built once by
- * palu_rope_cs_table_build (palu_rope_cs_table_bytes(npos) bytes); out [Tq][H * Rv] fp16.  Needs head_dim 128, rank_k / G in {64, 128},
- * rank_v / G in {128, 192, 256, 384} (palu_prefill_attn_lat_supported); causal as palu_prefill_attn_f16. */
+ * palu_rope_cs_table_build (palu_rope_cs_table_bytes(npos) bytes); out [Tq][H * Rv] fp16.  Needs head_dim 128, rank_k / G in {64, 128} with
+ * rank_v / G in {128, 192, 256, 384}, or 32 / 64 (palu_prefill_attn_lat_supported); causal as palu_prefill_attn_f16. */
 size_t palu_rope_cs_table_bytes(int npos);
 int palu_rope_cs_table_build(const float* inv_freq, int pos0, int npos, void* table, palu_stream_t stream);
 int palu_prefill_attn_lat_supported(int H, int G, int D, int Rk, int Rv);

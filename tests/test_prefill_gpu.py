@@ -106,8 +106,10 @@ def test_prefill_kernel_rejects_bad_args():
 
 
 @pytest.mark.parametrize("case", gi.PREFILL_CASES, ids=[c[0] for c in gi.PREFILL_CASES])
-def test_prefill_module_golden(golden_dir, case):
-    """Prompt pass through LlamaPaluAttention.forward (flash kernel) vs the reference's own outputs."""
+@pytest.mark.parametrize("form", ["default", "latent"])
+def test_prefill_module_golden(golden_dir, case, form):
+    """Prompt pass through LlamaPaluAttention.forward (flash kernel) vs the reference's own outputs.  form = "latent": the kernel that
+    rebuilds the keys per kv tile itself (csrc/prefill_lat.hip) forced onto the fixtures whose ranks it takes (32 / 64 per group)."""
     from palu_amd.kernel.palu_attention import LatentCache
     tag, seed, hidden, H, D, gs, rank_k, rank_v, T, causal = case
     g = np.load(os.path.join(golden_dir, "g7_prefill.npz"))
@@ -117,10 +119,19 @@ def test_prefill_module_golden(golden_dir, case):
     m = _module_from_palu_weights(hidden, H, D, gs, rank_k, rank_v, w)
     cache = LatentCache()
     am = None if mask is None else mask.reshape(1, 1, T, T).to(DEV)
+    calls = []
+    if form == "latent":
+        G = H // gs
+        if not _lib().lib.palu_prefill_attn_lat_supported(H, G, D, rank_k // G, rank_v // G):
+            pytest.skip("ranks the latent kernel does not take")
+        m.PREFILL_LATENT_ABOVE = 0
+        inner = m._prefill_latent
+        m._prefill_latent = lambda *a, **k: (calls.append(1), inner(*a, **k))[1]
     with torch.no_grad():
         out, probs, _ = m(prompt.reshape(1, T, hidden).to(DEV), attention_mask=am,
                           position_ids=torch.arange(T).unsqueeze(0), past_key_value=cache)
     assert probs is None and cache.get_seq_length(0) == T
+    assert (form != "latent") or calls == [1]
     torch.testing.assert_close(out[0].cpu(), torch.from_numpy(g[tag + "/attn_output"]), rtol=1e-3, atol=1e-3)
     kbuf, vbuf = cache.buffers(0)
     torch.testing.assert_close(kbuf[0, :, :T].cpu(), torch.from_numpy(g[tag + "/k_lat"]), rtol=1e-3, atol=1e-3)

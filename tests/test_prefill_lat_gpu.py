@@ -78,6 +78,7 @@ def _ref_f32(q, keys, xv, past, causal):
     (4, 1, 1, 200, 128, 256, False), (8, 4, 129, 1000, 128, 384, True), (4, 4, 128, 192, 128, 384, False), (8, 4, 333, 333, 128, 256, True),
     (32, 4, 1100, 1100, 128, 384, True), (8, 2, 64, 4097, 128, 384, True), (4, 4, 200, 70, 128, 384, False),
     (32, 4, 700, 700, 64, 192, True), (8, 4, 129, 1000, 64, 192, False), (8, 4, 300, 300, 64, 384, True), (8, 4, 257, 520, 128, 192, True),   # config-4 ranks
+    (4, 2, 48, 48, 32, 64, True), (4, 2, 70, 333, 32, 64, False),                                                                            # the golden fixtures' ranks
 ])
 def test_latent_prefill_kernel_vs_workspace_form_and_fp32(H, gs, Tq, Tk, Rk, Rv, causal):
     _lib, ar = _mods()
@@ -228,6 +229,7 @@ def bt_perm_of(b):
     (4, 4, 128, 128, 128, 384, True), (8, 4, 257, 257, 128, 128, True), (32, 4, 300, 300, 128, 384, True), (8, 4, 129, 1000, 128, 384, True),
     (4, 4, 200, 70, 128, 384, False), (8, 4, 333, 333, 128, 256, True), (8, 2, 64, 4097, 128, 384, True),
     (32, 4, 700, 700, 64, 192, True), (8, 4, 129, 1000, 64, 192, False), (8, 4, 257, 520, 128, 192, True),                                     # config-4 ranks
+    (4, 2, 130, 130, 32, 64, True),
 ])
 def test_latent_prefill_kernel_on_packed_4bit_caches(H, gs, Tq, Tk, Rk, Rv, causal):
     """palu_prefill_attn_lat_q de-quantises the codes inside the kernel: same result as the fp16 kernel on unpack_dequant()'s rows
