@@ -989,7 +989,12 @@ __global__ __launch_bounds__(64 * CB_WAVES) void pv_combine_kernel(CombineParams
   load_batch(stream * UN);
   // global max over the splits (every wave computes it: nsplit is small)
   float M = -INFINITY;
-  for (int s = lane; s < p.nsplit; s += 64) M = fmaxf(M, ml[s * ml_stride]);
+  // (four loads in flight per lane: with one latent group per launch there are ~1000 splits, 16 dependent round trips otherwise)
+  for (int s = lane; s < p.nsplit; s += 256) {
+    const float m0 = ml[s * ml_stride], m1 = ml[min(s + 64, p.nsplit - 1) * ml_stride];
+    const float m2 = ml[min(s + 128, p.nsplit - 1) * ml_stride], m3 = ml[min(s + 192, p.nsplit - 1) * ml_stride];
+    M = fmaxf(fmaxf(M, fmaxf(m0, m1)), fmaxf(m2, m3));
+  }
   M = wave_max(M);
   for (int s0 = stream * UN; s0 < p.nsplit; s0 += CB_WAVES * NS * UN) {
     if (s0 != stream * UN) load_batch(s0);

@@ -84,7 +84,7 @@ typedef __attribute__((address_space(3))) float lds_f32_t;
 template <int NCB, int KSR, int QB = 0>
 __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams p) {
   static_assert(QB == 0 || QB == 4, "fp16 or packed 4-bit latents");
-  static_assert(NCB % 2 == 0 && NCB >= 2 && NCB <= 12, "rank_v / G = 32 NCB, a multiple of 64 (whole groups of four 32-byte granules per row)");
+  static_assert(NCB >= 2 && NCB <= 12 && (NCB % 2 == 0 || QB == 0), "rank_v / G = 32 NCB (packed caches: a multiple of 64)");
   static_assert(KSR == 2 || KSR == 4 || KSR == 8, "rank_k / G = 16 KSR in {32, 64, 128}");
   constexpr int RK = 16 * KSR;
   constexpr int RKB = 2 * RK;                       // bytes of an fp16 X row
@@ -96,7 +96,9 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
   constexpr int RVB = RV * 2;                       // bytes of a V row
   constexpr int XS_BYTES = PL_BN * 256;             // X tile: 64 rows x 128 fp16 (16 chunks per row, XOR-swizzled by row & 15)
   constexpr int KS_BYTES = PL_BN * 256;             // K~ tile, same geometry
-  constexpr int VH_BYTES = 32 * RVB;                // half a V tile: 32 rows, row-major, 32-byte granules XOR-swizzled by row & 3
+  constexpr int VH_BYTES = 32 * RVB;                // half a V tile: 32 rows, row-major, 32-byte granules XOR-swizzled by row & SWZ
+  constexpr int SWZ = (NCB % 2 == 0) ? 3 : 1;       // (a row is whole groups of four granules, or -- odd NCB -- of two: the transpose reads
+                                                    //  then meet two-way bank conflicts; such ranks are the small configurations)
   constexpr int NVP = VH_BYTES / 1024;              // DMA pieces of half a V tile
   constexpr int OFF_XS = 0;
   constexpr int OFF_VS = OFF_XS + XS_BYTES;         // (the DMA targets first: LDS offsets below 128 KB)
@@ -255,25 +257,26 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
         o[2] = deq2(__builtin_amdgcn_perm(t1, t0, 0x0c060c02u), nb2, sc2);
         o[3] = deq2(__builtin_amdgcn_perm(t1, t0, 0x0c070c03u), nb2, sc2);
         const int gran = 2 * vq_c + (j >> 1);
-        *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(rowb + (unsigned)(((gran ^ (vq_row & 3)) << 5) + 16 * (j & 1))) = o;
+        *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(rowb + (unsigned)(((gran ^ (vq_row & SWZ)) << 5) + 16 * (j & 1))) = o;
       }
     }
   };
   // V half tile (fp16 caches): piece p covers LDS slots [64 p, 64 p + 64); slot s: row s / SPR, 16-byte slot s % SPR of the row; LDS
-  // granule (32 B) gl of row r holds source granule gl ^ (r & 3).  The lane pattern of a piece repeats every PER pieces (= whole
-  // groups of 4 rows): a wave takes blocks of PER consecutive pieces (block 4 j + (w & 3)), so PER lane constants serve and the block
-  // is a scalar row offset
+  // granule (32 B) gl of row r holds source granule gl ^ (r & SWZ).  The lane pattern of a piece repeats every PER pieces (= whole
+  // groups of SWZ + 1 rows): a wave takes blocks of PER consecutive pieces (block 4 j + (w & 3)), so PER lane constants serve and the
+  // block is a scalar row offset
   constexpr int SPR = RVB / 16;                     // 16-byte slots per row
-  constexpr int PER = (NCB == 12 || NCB == 6) ? 3 : (NCB == 8 ? 2 : (NCB == 10 ? 5 : 1));
-  static_assert((PER * 64) % (4 * SPR) == 0 && NVP % (4 * PER) == 0, "blocks of PER pieces are whole groups of 4 rows, 4 waves share them evenly");
+  constexpr int PER = (NCB % 3 == 0) ? 3 : (NCB == 8 ? 2 : (NCB == 10 ? 5 : 1));
+  static_assert((PER * 64) % ((SWZ + 1) * SPR) == 0 && NVP % PER == 0, "blocks of PER pieces are whole swizzle periods of rows");
   constexpr int RPB = PER * 64 / SPR;               // rows per block
-  constexpr int NBW = NVP / PER / 4;                // blocks per wave
+  constexpr int NBLK = NVP / PER;                   // blocks of a half tile
+  constexpr int NBW = (NBLK + 3) / 4;               // blocks per wave (the last round may not reach every wave)
   unsigned vvo[PER];
 #pragma unroll
   for (int c = 0; c < PER; ++c) {
     const int s = c * 64 + lane;
     const int r = s / SPR, sr = s % SPR;
-    vvo[c] = (unsigned)(r * (int)(p.sxv_l * 2) + ((((sr >> 1) ^ (r & 3)) << 1) + (sr & 1)) * 16);
+    vvo[c] = (unsigned)(r * (int)(p.sxv_l * 2) + ((((sr >> 1) ^ (r & SWZ)) << 1) + (sr & 1)) * 16);
   }
   const unsigned vrow_bytes = __builtin_amdgcn_readfirstlane((unsigned)(p.sxv_l * 2));
   // `all8`: the blocks are dealt to all eight waves (block 8 j + w) instead of the four waves of one role (block 4 j + (w & 3))
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
 #pragma unroll
       for (int j = 0; j < NBW; ++j) {
         const int blk = nw * j + wi;
-        if (blk >= 4 * NBW) continue;
+        if (blk >= NBLK) continue;
 #pragma unroll
         for (int c = 0; c < PER; ++c)
           dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_VS + half * VH_BYTES + (PER * blk + c) * 1024), vvo[c], vrs,
@@ -295,14 +298,14 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
 #pragma unroll
       for (int j = 0; j < NBW; ++j) {
         const int blk = nw * j + wi;
-        if (blk >= 4 * NBW) continue;
+        if (blk >= NBLK) continue;
 #pragma unroll
         for (int c = 0; c < PER; ++c) {
           const int s = (PER * blk + c) * 64 + lane;
           const int r = s / SPR, sr = s % SPR;
           const int row = min(row0 + r, p.Tk - 1);
           dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_VS + half * VH_BYTES + (PER * blk + c) * 1024),
-              (unsigned)(row * (int)(p.sxv_l * 2) + ((((sr >> 1) ^ (r & 3)) << 1) + (sr & 1)) * 16), vrs, 0u);
+              (unsigned)(row * (int)(p.sxv_l * 2) + ((((sr >> 1) ^ (r & SWZ)) << 1) + (sr & 1)) * 16), vrs, 0u);
         }
       }
     }
@@ -492,8 +495,9 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
   // on its low two bits (even / odd cb differ in bit 1: two lane constants), the rest rides in the instruction offsets.
   const int tj = lane >> 4, ti = lane & 15;
   const unsigned tbase = lds0 + OFF_VS + (unsigned)((8 * (tj >> 1) + (ti >> 2)) * RVB + 8 * (ti & 3));
-  const unsigned tr_e = tbase + (unsigned)((((tj & 1)) ^ (ti >> 2)) * 32);
-  const unsigned tr_o = tbase + (unsigned)((((2 + (tj & 1))) ^ (ti >> 2)) * 32);
+  // (odd NCB, key = row & 1: the key moves bit 0 only, every cb is a constant offset on tr_e)
+  const unsigned tr_e = tbase + (unsigned)((((tj & 1)) ^ ((ti >> 2) & SWZ)) * 32);
+  const unsigned tr_o = tbase + (unsigned)((((2 + (tj & 1))) ^ ((ti >> 2) & SWZ)) * 32);
   auto pv_half = [&](auto half_c) {         // O^T += V^T(jt, half) . P^T(jt, half): k-steps 2 half, 2 half + 1
     constexpr int half = decltype(half_c)::value;
     const unsigned psrc = lds0 + OFF_PS + (unsigned)((qblk * 4) * 1024 + lane * 16);
@@ -522,7 +526,8 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
         (void)dummy;
         const int t = gq * GS + e, st = t / NCB, cb = t % NCB;
         // (constant offsets on an LDS pointer: they ride in the instructions' offset fields instead of address registers)
-        lds_char* ap = (lds_char*)(uintptr_t)((cb & 1) ? tr_o : tr_e) + (half * VH_BYTES + st * 16 * RVB + (cb >> 1) * 128);
+        lds_char* ap = SWZ == 3 ? (lds_char*)(uintptr_t)((cb & 1) ? tr_o : tr_e) + (half * VH_BYTES + st * 16 * RVB + (cb >> 1) * 128)
+                                : (lds_char*)(uintptr_t)tr_e + (half * VH_BYTES + st * 16 * RVB + cb * 64);
         const h16x4 lo = __builtin_bit_cast(h16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((pvm::lds_s16x4*)ap));
         const h16x4 hh = __builtin_bit_cast(h16x4, __builtin_amdgcn_ds_read_tr16_b64_v4i16((pvm::lds_s16x4*)(ap + 4 * RVB)));
         vf[e] = __builtin_shufflevector(lo, hh, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -714,7 +719,12 @@ int dispatch_prefill_lat(const PfLatParams& p, int Rk, int Rv, hipStream_t s) {
 #define PL_CASE(NCB)                                                             \
   case NCB:                                                                      \
     return Rk == 128 ? launch_prefill_lat<NCB, 8, QB>(p, s) : launch_prefill_lat<NCB, 4, QB>(p, s);
-  if (Rk == 32) return launch_prefill_lat<2, 2, QB>(p, s);       // (the small golden-fixture shape: rank_k / G = 32, rank_v / G = 64)
+  if (Rk == 32) {                                                // BASELINE config 1 and the small golden-fixture shape
+    if constexpr (QB == 0) {
+      if (Rv == 96) return launch_prefill_lat<3, 2, QB>(p, s);
+    }
+    return launch_prefill_lat<2, 2, QB>(p, s);
+  }
   switch (Rv / 32) {
     PL_CASE(4)
     PL_CASE(6)
@@ -743,7 +753,8 @@ extern "C" int palu_rope_cs_table_build(const float* inv_freq, int pos0, int npo
 
 extern "C" int palu_prefill_attn_lat_supported(int H, int G, int D, int Rk, int Rv) {
   if (!(H > 0 && G > 0 && H % G == 0 && D == 128)) return 0;
-  if (Rk == 32 && Rv == 64) return 1;                // what the reference-generated prefill fixtures use (tests/golden/g7_prefill.npz)
+  if (Rk == 32 && (Rv == 64 || Rv == 96)) return 1;  // BASELINE config 1 (32 / 96, fp16 rows only) and what the reference-generated
+                                                     // prefill fixtures use (tests/golden/g7_prefill.npz)
   return ((Rk == 128 || Rk == 64) && (Rv == 384 || Rv == 256 || Rv == 192 || Rv == 128)) ? 1 : 0;
 }
 
@@ -796,6 +807,7 @@ extern "C" int palu_prefill_attn_lat_q(const void* q, int64_t sq_h, int64_t sq_t
                                        int bits, int past, int causal, float scale, palu_stream_t stream) {
   PALU_REQUIRE(q && k_codes && k_meta && v_codes && v_meta && bt_perm && cs && out, PALU_ERR_ARG, "prefill_attn_lat_q: null pointer");
   PALU_REQUIRE(bits == 4, PALU_ERR_UNSUPPORTED, "prefill_attn_lat_q: 4-bit codes only (got %d)", bits);
+  PALU_REQUIRE(Rv % 64 == 0, PALU_ERR_UNSUPPORTED, "prefill_attn_lat_q: rank_v / G = %d is taken for fp16 rows only", Rv);
   PALU_REQUIRE(palu_prefill_attn_lat_supported(H, G, D, Rk, Rv), PALU_ERR_UNSUPPORTED,
                "prefill_attn_lat_q: needs head_dim 128, rank_k / G in {64, 128} with rank_v / G in {128, 192, 256, 384}, or 32 / 64 (H=%d G=%d D=%d Rk=%d Rv=%d)", H,
                G, D, Rk, Rv);

@@ -28,6 +28,11 @@ def _workspace_form(q, xk, xv, b, past, causal, inv):
     Rv = xv.shape[2]
     gs = H // G
     keys = torch.empty(H, Tk, D, dtype=torch.float16, device=DEV)
+    if Rk % 64:                                                  # the GEMM takes K in whole 64s: zero columns change nothing
+        pad_k = 64 - Rk % 64
+        xk = torch.nn.functional.pad(xk, (0, pad_k))
+        b = torch.nn.functional.pad(b, (0, 0, 0, pad_k))
+        Rk += pad_k
     for g in range(G):
         u = b[g * gs:(g + 1) * gs].transpose(1, 2).reshape(gs * D, Rk).contiguous()           # U_g [gs*D, Rk]
         _lib.check(lib.palu_lowrank_project_gemm(xk[g].data_ptr(), xk.stride(1), u.data_ptr(), u.stride(0), keys[g * gs].data_ptr(),
@@ -78,7 +83,7 @@ def _ref_f32(q, keys, xv, past, causal):
     (4, 1, 1, 200, 128, 256, False), (8, 4, 129, 1000, 128, 384, True), (4, 4, 128, 192, 128, 384, False), (8, 4, 333, 333, 128, 256, True),
     (32, 4, 1100, 1100, 128, 384, True), (8, 2, 64, 4097, 128, 384, True), (4, 4, 200, 70, 128, 384, False),
     (32, 4, 700, 700, 64, 192, True), (8, 4, 129, 1000, 64, 192, False), (8, 4, 300, 300, 64, 384, True), (8, 4, 257, 520, 128, 192, True),   # config-4 ranks
-    (4, 2, 48, 48, 32, 64, True), (4, 2, 70, 333, 32, 64, False),                                                                            # the golden fixtures' ranks
+    (4, 2, 48, 48, 32, 64, True), (4, 2, 70, 333, 32, 64, False), (8, 4, 130, 130, 32, 96, True), (8, 2, 77, 400, 32, 96, False),   # config-1 and the golden fixtures' ranks
 ])
 def test_latent_prefill_kernel_vs_workspace_form_and_fp32(H, gs, Tq, Tk, Rk, Rv, causal):
     _lib, ar = _mods()
@@ -108,11 +113,12 @@ def test_latent_prefill_rejects_unsupported_shapes():
     lib = _lib.lib
     assert lib.palu_prefill_attn_lat_supported(32, 8, 128, 128, 384) == 1
     assert lib.palu_prefill_attn_lat_supported(32, 8, 128, 64, 192) == 1           # config-4 ranks
-    assert lib.palu_prefill_attn_lat_supported(32, 8, 128, 32, 96) == 0            # config-1 ranks: workspace form
+    assert lib.palu_prefill_attn_lat_supported(32, 8, 128, 32, 96) == 1            # config-1 ranks (fp16 rows)
+    assert lib.palu_prefill_attn_lat_supported(32, 8, 128, 32, 128) == 0
     assert lib.palu_prefill_attn_lat_supported(32, 8, 64, 128, 384) == 0
     t = torch.zeros(1024, dtype=torch.float16, device=DEV)
     rc = lib.palu_prefill_attn_lat_f16(t.data_ptr(), 128, 128, t.data_ptr(), 128, 128, t.data_ptr(), 192, 192, t.data_ptr(), t.data_ptr(),
-                                       t.data_ptr(), 192, 4, 1, 128, 1, 1, 32, 96, 0, 1, 0.1, torch.cuda.current_stream().cuda_stream)
+                                       t.data_ptr(), 192, 4, 1, 128, 1, 1, 32, 160, 0, 1, 0.1, torch.cuda.current_stream().cuda_stream)
     assert rc != 0
 
 
