@@ -1179,6 +1179,7 @@ extern "C" size_t palu_pv_stats_offset(int H, int G, int L, int Rv) {
 // whole 32-code (8-column) chunks, dword (16-byte) aligned rows, a group's rows within 2 GiB, and a divisor whose fast
 // quotient is exact.  Returns PV_QR_NOT_TAKEN when the shape is left to the older kernels.
 constexpr int PV_QR_NOT_TAKEN = 1;
+#define PV_DIRECT_AUTO(G, L) ((G) == 1)
 // geometry of a register-direct launch: column slices of <= 16 chunks (cw columns each), S row sets per unit, and one
 // round of 8-wave workgroups (256 VGPRs per wave: one workgroup per CU): CUs / G ranges per group, each cut into
 // nws = 8 / slices wave ranges of whole units (32 S rows); the statistics are computed online, so a wave range may have
@@ -1227,7 +1228,7 @@ static int pv_qr_launch(const void* scores, int64_t ss_h, const void* mask, cons
     // 182.6 vs 177.4 us per step) -- both kernels stream at the ~6.3 TB/s this part sustains, the VALU kernel's four
     // small workgroups per CU ramp up and drain better.  Opt-in: PALU_PV_DIRECT=1.
     const char* e16 = getenv("PALU_PV_DIRECT");
-    qr16_enabled = e16 ? atoi(e16) : 0;
+    qr16_enabled = e16 ? atoi(e16) : 2;                 // 2 = by shape (below)
   }
   const int gs = H / G;
   int cw = pv_qr_chunk_width(Rv, bits);
@@ -1235,7 +1236,11 @@ static int pv_qr_launch(const void* scores, int64_t ss_h, const void* mask, cons
   if (cw == 32 && bits == 4 && !al16) cw = 0;                          // 16-byte chunks are loaded as aligned dwordx4
   const long long row_bytes = (long long)Rv * bits / 8;
   const long long span = (long long)(L - 1) * sc_l + row_bytes;
-  bool ok = (bits == 16 ? qr16_enabled : qr_enabled) && (gs == 1 || gs == 2 || gs == 4) && cw != 0 &&
+  // fp16 rows, no setting: ONE latent group per launch (a rank of the head-group sharding, BASELINE config 5) takes this kernel --
+  // 40.4 vs 49.6 us at 256 k positions (profiles/r06_pv_forms.txt): the VALU kernel's ~1000 workgroups then all walk one group's rows
+  // in 264-row ranges, this one runs a single round of 256 workgroups with 8 wave ranges each
+  const bool on16 = qr16_enabled == 2 ? PV_DIRECT_AUTO(G, L) : qr16_enabled != 0;
+  bool ok = (bits == 16 ? on16 : qr_enabled != 0) && (gs == 1 || gs == 2 || gs == 4) && cw != 0 &&
             span + 4096ll * sc_l < 0x7FFFFFFFll && ((uintptr_t)rows & 3) == 0 && sc_g % 4 == 0 && sc_l % 4 == 0 &&
             (bits != 16 || al16) && pv_exact_rcp(sqrt_d) != 0.f;
   if (!ok) return PV_QR_NOT_TAKEN;
