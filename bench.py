@@ -396,7 +396,7 @@ def bench_prefill(rank_k, rank_v, T, dev):
     # rebuilt per kv tile inside the flash kernel, V from the cache rows; transients = one 2048-query chunk); "..._workspace_form" =
     # the one-launch form with its [H, kv, D] key workspace and transposed value copy (PREFILL_LATENT_ABOVE = None)
     for tag, bits, budget in (("fp16_cache", 16, None), ("fp16_cache_workspace_form", 16, "ws"), ("fp16_cache_bounded_workspace", 16, 0),
-                              ("packed_4bit_cache", 4, None), ("packed_4bit_cache_bounded_workspace", 4, 0),
+                              ("packed_4bit_cache", 4, None), ("packed_3bit_cache", 3, None), ("packed_4bit_cache_bounded_workspace", 4, 0),
                               ("packed_4bit_cache_kv_panels", 4, "panels")):
         mk = (lambda: LatentCache(capacity=T + 512)) if bits >= 16 else (lambda: QuantLatentCache(bits, capacity=T + 512))
         panels = budget == "panels"         # kv panels with carried softmax state: transients independent of T (<= 64 MiB)

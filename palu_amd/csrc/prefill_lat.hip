@@ -83,15 +83,17 @@ typedef __attribute__((address_space(3))) float lds_f32_t;
 
 template <int NCB, int KSR, int QB = 0>
 __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams p) {
-  static_assert(QB == 0 || QB == 4, "fp16 or packed 4-bit latents");
+  static_assert(QB == 0 || QB == 3 || QB == 4, "fp16 or packed 3- / 4-bit latents");
   static_assert(NCB >= 2 && NCB <= 12 && (NCB % 2 == 0 || QB == 0), "rank_v / G = 32 NCB (packed caches: a multiple of 64)");
+  static_assert(QB != 3 || (KSR == 8 && NCB % 4 == 0), "3-bit rows are whole 16-byte chunks at multiples of 128 codes");
   static_assert(KSR == 2 || KSR == 4 || KSR == 8, "rank_k / G = 16 KSR in {32, 64, 128}");
   constexpr int RK = 16 * KSR;
   constexpr int RKB = 2 * RK;                       // bytes of an fp16 X row
   constexpr int CPRX = 2 * KSR;                     // its 16-byte chunks (XOR-swizzled by row & (CPRX - 1))
   constexpr int NXP = PL_BN * RKB / 1024;           // DMA pieces of an fp16 X tile (8 or 16)
-  constexpr int RQB = RK / 2;                       // bytes of a packed X row
-  constexpr int CQ = RQB / 16;                      // its 16-byte chunks (2 or 4)
+  constexpr int QBE = QB ? QB : 4;
+  constexpr int RQB = RK * QBE / 8;                 // bytes of a packed X row
+  constexpr int CQ = RQB / 16;                      // its 16-byte chunks (2 or 4; 3-bit: 3) = the DMA pieces of a tile's codes
   constexpr int RV = 32 * NCB;
   constexpr int RVB = RV * 2;                       // bytes of a V row
   constexpr int XS_BYTES = PL_BN * 256;             // X tile: 64 rows x 128 fp16 (16 chunks per row, XOR-swizzled by row & 15)
@@ -108,8 +110,11 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
   constexpr int OFF_AL = OFF_PS + 4 * 4096;         // [qblk 4][32] floats: rescale factor of the tile (at the end: the row sums)
   constexpr int OFF_QF = OFF_AL + 4 * 32 * 4;       // [qblk 4][ks 8][lane 64] x 16 B: the Q~ fragments (B operand of the scores) -- the S-wave's
                                                     // registers hold the rebuild's 64 B^T fragments instead
-  constexpr int VC_BYTES = 16 * RV;                 // packed caches: the codes of half a V tile (32 rows x RV / 2 bytes), two of them
-  constexpr int NVC = VC_BYTES / 1024;              // = DMA pieces = waves that de-quantise a half tile (16-byte chunk 64 w + lane)
+  constexpr int VRB = RV * QBE / 8;                 // bytes of a packed V row
+  constexpr int CPV = VRB / 16;                     // its 16-byte chunks
+  constexpr int NVCP = (32 * VRB + 1023) / 1024;    // DMA pieces of the codes of half a V tile (32 rows, linear as in memory)
+  constexpr int VC_BYTES = NVCP * 1024;             // staging for them, two of them
+  constexpr int NVC = NCB / 2;                      // waves that de-quantise a half tile: unit 64 w + lane = 32 codes of one row
   constexpr int OFF_VC = OFF_QF + 32 * 1024;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)reinterpret_cast<uintptr_t>(smem);
@@ -204,28 +209,37 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
   // row r lands at chunk position c ^ ((r >> 1) & (CQ - 1)) (the rebuild reads 4 bytes per lane and k-step: rows two apart would
   // share a bank)
   const u32x4 xqrs = QB ? make_rsrc(p.kc + (int64_t)g * p.skc_g, (int64_t)(p.Tk - 1) * p.skc_l + RQB) : xrs;
-  const unsigned xqvo = QB ? (unsigned)((lane / CQ) * (int)p.skc_l + (((lane % CQ) ^ (((lane / CQ) >> 1) & (CQ - 1))) << 4)) : 0u;
+  // (3-bit rows, 3 chunks each: plain row-major -- the rebuild's two dwords per lane and k-step then meet two-way conflicts)
+  const int xqc = 64 * (w & 3) + lane;
+  const unsigned xqvo = QB == 4 ? (unsigned)((lane / CQ) * (int)p.skc_l + (((lane % CQ) ^ (((lane / CQ) >> 1) & (CQ - 1))) << 4))
+                                : (QB == 3 ? (unsigned)((xqc / CQ) * (int)p.skc_l + ((xqc % CQ) << 4)) : 0u);
   auto dma_xq = [&](int jt) {
     if ((w & 3) < CQ)
       dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_XS + (w & 3) * 1024), xqvo, xqrs,
-          __builtin_amdgcn_readfirstlane((unsigned)(jt * PL_BN + (64 / CQ) * (w & 3)) * (unsigned)p.skc_l));
+          __builtin_amdgcn_readfirstlane((unsigned)(jt * PL_BN + (QB == 4 ? (64 / CQ) * (w & 3) : 0)) * (unsigned)p.skc_l));
   };
   // packed values: the codes of half a tile, linear ([row][RV / 2 bytes] as in memory): piece w = 16-byte chunks 64 w .. 64 w + 63; the
   // lane that de-quantises chunk q = 64 w + lane (row q / NCB, columns 32 (q % NCB) ..) also fetches that row's (scale, zero)
   constexpr int VQI = 1;                            // piece w belongs to wave w (NVC <= 6: the S-waves and, at rank_v / G = 384, O-waves 4 and 5)
-  const u32x4 vqrs = QB ? make_rsrc(p.vc + (int64_t)g * p.svc_g, (int64_t)(p.Tk - 1) * p.svc_l + RV / 2) : vrs;
+  const u32x4 vqrs = QB ? make_rsrc(p.vc + (int64_t)g * p.svc_g, (int64_t)(p.Tk - 1) * p.svc_l + VRB) : vrs;
   unsigned vmeta_next[VQI], vmeta_cur[VQI];
 #pragma unroll
   for (int i = 0; i < VQI; ++i) vmeta_next[i] = vmeta_cur[i] = 0;
   auto vc_issue = [&](int jt, int half) {           // codes of half tile (jt, half) into staging `half` + the rows' metas
-    if (QB == 0 || w >= NVC) return;
+    if (QB == 0) return;
 #pragma unroll
     for (int i = 0; i < VQI; ++i) {
       const int q = 64 * w + lane;
-      const int row = min(jt * PL_BN + 32 * half + q / NCB, p.Tk - 1);   // (rows past Tk re-read row Tk - 1: finite values x probability 0)
-      dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_VC + half * VC_BYTES + w * 1024),
-          (unsigned)(row * (int)p.svc_l + (q % NCB) * 16), vqrs, 0u);
-      vmeta_next[i] = *reinterpret_cast<const unsigned*>(p.vm + (int64_t)g * p.svm_g + (int64_t)row * p.svm_l);
+      if (w < NVCP) {                                 // 16-byte chunk q of the half tile's codes (the last piece may reach past them: its
+        const int qc = min(q, 32 * CPV - 1);          //  spare lanes re-read the last chunk into the staging's padding)
+        const int crow = min(jt * PL_BN + 32 * half + qc / CPV, p.Tk - 1);   // (rows past Tk re-read row Tk - 1: finite values x probability 0)
+        dma(__builtin_amdgcn_readfirstlane(lds0 + OFF_VC + half * VC_BYTES + w * 1024),
+            (unsigned)(crow * (int)p.svc_l + (qc % CPV) * 16), vqrs, 0u);
+      }
+      if (w < NVC) {                                  // (scale, zero) of the row whose unit q this lane de-quantises
+        const int row = min(jt * PL_BN + 32 * half + q / NCB, p.Tk - 1);
+        vmeta_next[i] = *reinterpret_cast<const unsigned*>(p.vm + (int64_t)g * p.svm_g + (int64_t)row * p.svm_l);
+      }
     }
   };
   // (a + nb) * s on pairs: a = 0x6400 | code = 1024 + code exactly, nb = -(1024 + zero): the difference is exact, one rounding in the
@@ -235,18 +249,43 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
     v = (v + nb2) * sc2;
     return __builtin_bit_cast(unsigned, v);
   };
+  // 3-bit codes: the pair (code at bit lo, code at bit hi) of a 24-bit group as two fp16 1024 + code, de-quantised like deq2
+  auto deq3 = [](unsigned v, int lo, int hi, h16x2 nb2, h16x2 sc2) {
+    const unsigned a = ((v >> lo) & 7u) | 0x64006400u;
+    const unsigned b = (v >> hi) & 7u;
+    h16x2 x = __builtin_bit_cast(h16x2, a | (b << 16));
+    x = (x + nb2) * sc2;
+    return __builtin_bit_cast(unsigned, x);
+  };
   auto vc_dequant = [&](int half) {                 // staging `half` -> fp16 row-major image slot `half` (granule-swizzled like the DMA form)
     if (QB == 0 || w >= NVC) return;
 #pragma unroll
     for (int i = 0; i < VQI; ++i) {
       const int q = 64 * w + lane;
       const int vq_row = q / NCB, vq_c = q % NCB;
-      const u32x4 cd = *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)(lds0 + OFF_VC + half * VC_BYTES + q * 16);
       const h16x2 m2 = __builtin_bit_cast(h16x2, vmeta_cur[i]);
       const h16x2 sc2 = h16x2{m2[0], m2[0]};
       const h16 nb = -((h16)1024.f + m2[1]);
       const h16x2 nb2 = h16x2{nb, nb};
       const unsigned rowb = lds0 + OFF_VS + (unsigned)(half * VH_BYTES + vq_row * RVB);
+      if constexpr (QB == 3) {
+        // 32 codes = 3 dwords (quant.hip: code j of a row at bits [3 j, 3 j + 3) of its little-endian stream); 8-code group j = 24 bits
+        const unsigned src = lds0 + OFF_VC + (unsigned)(half * VC_BYTES + vq_row * VRB + vq_c * 12);
+        const unsigned d0 = *(const __attribute__((address_space(3))) unsigned*)(uintptr_t)src;
+        const unsigned d1 = *(const __attribute__((address_space(3))) unsigned*)(uintptr_t)(src + 4);
+        const unsigned d2 = *(const __attribute__((address_space(3))) unsigned*)(uintptr_t)(src + 8);
+        const unsigned v24[4] = {d0, __builtin_amdgcn_alignbit(d1, d0, 24), __builtin_amdgcn_alignbit(d2, d1, 16), d2 >> 8};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          u32x4 o;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) o[m] = deq3(v24[j], 6 * m, 6 * m + 3, nb2, sc2);
+          const int gran = 2 * vq_c + (j >> 1);
+          *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(rowb + (unsigned)(((gran ^ (vq_row & SWZ)) << 5) + 16 * (j & 1))) = o;
+        }
+        continue;
+      }
+      const u32x4 cd = *(const __attribute__((address_space(3))) u32x4*)(uintptr_t)(lds0 + OFF_VC + half * VC_BYTES + q * 16);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {                 // dword j = columns 32 c + 8 j .. + 7 in natural order
         const unsigned d = cd[j];
@@ -374,6 +413,21 @@ __global__ __launch_bounds__(PL_THREADS, 1) void prefill_lat_kernel(PfLatParams 
       h16x8 xf;
       if constexpr (QB == 0) {
         xf = *(const lds_h16x8_t*)(uintptr_t)(xbase ^ (unsigned)(ks << 5));               // chunk (2 ks + hi) ^ (row & (CPRX - 1))
+      } else if constexpr (QB == 3) {
+        // 8 codes = 24 bits at byte 6 ks + 3 hi of the row's 48: two aligned dwords and a funnel shift -- even ks: byte 6 ks, shift 24 hi;
+        // odd ks: byte 6 ks - 2 + 4 hi, shift 16 - 8 hi.  Pairs (e, e + 4) like the 4-bit form (the same permuted B^T).
+        const unsigned xa = lds0 + OFF_XS + (unsigned)(row * RQB + ((ks & 1) ? 6 * ks - 2 + 4 * hi : 6 * ks));
+        const unsigned d0 = *(const __attribute__((address_space(3))) unsigned*)(uintptr_t)xa;
+        const unsigned d1 = *(const __attribute__((address_space(3))) unsigned*)(uintptr_t)(xa + 4);
+        const unsigned v24 = __builtin_amdgcn_alignbit(d1, d0, (unsigned)((ks & 1) ? 16 - 8 * hi : 24 * hi));
+        const h16x2 m2 = __builtin_bit_cast(h16x2, kmeta);
+        const h16x2 sc2 = h16x2{m2[0], m2[0]};
+        const h16 nb = -((h16)1024.f + m2[1]);
+        const h16x2 nb2 = h16x2{nb, nb};
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = deq3(v24, 3 * e, 3 * e + 12, nb2, sc2);
+        xf = __builtin_bit_cast(h16x8, o);
       } else {
         // 8 codes = 4 bytes at byte 8 ks + 4 hi of the row's 64: chunk ks >> 1 (at position ^ ((row >> 1) & 3)), nibble e of the dword =
         // column 16 ks + 8 hi + e; the pairs come out as (0, 4) (1, 5) (2, 6) (3, 7): bt carries its columns in that order
@@ -704,7 +758,7 @@ __global__ void rope_cs_table_kernel(const float* __restrict__ inv_freq, int pos
 
 template <int NCB, int KSR, int QB>
 int launch_prefill_lat(const PfLatParams& p, hipStream_t stream) {
-  constexpr int smem = 3 * PL_BN * 256 + 2 * 32 * 64 * NCB + 4 * 4096 + 4 * 32 * 4 + 32 * 1024 + (QB ? 2 * 16 * 32 * NCB : 0);
+  constexpr int smem = 3 * PL_BN * 256 + 2 * 32 * 64 * NCB + 4 * 4096 + 4 * 32 * 4 + 32 * 1024 + (QB ? 2 * 1024 * ((32 * 32 * NCB * QB / 8 + 1023) / 1024) : 0);
   auto kern = prefill_lat_kernel<NCB, KSR, QB>;
   const int rca = palu_func_max_lds(reinterpret_cast<const void*>(kern), smem);
   if (rca) return rca;
@@ -716,6 +770,11 @@ int launch_prefill_lat(const PfLatParams& p, hipStream_t stream) {
 
 template <int QB>
 int dispatch_prefill_lat(const PfLatParams& p, int Rk, int Rv, hipStream_t s) {
+  if constexpr (QB == 3) {                                        // 3-bit rows: rank_k / G = 128, rank_v / G a multiple of 128
+    if (Rv == 128) return launch_prefill_lat<4, 8, 3>(p, s);
+    if (Rv == 256) return launch_prefill_lat<8, 8, 3>(p, s);
+    return launch_prefill_lat<12, 8, 3>(p, s);
+  } else {
 #define PL_CASE(NCB)                                                             \
   case NCB:                                                                      \
     return Rk == 128 ? launch_prefill_lat<NCB, 8, QB>(p, s) : launch_prefill_lat<NCB, 4, QB>(p, s);
@@ -732,6 +791,7 @@ int dispatch_prefill_lat(const PfLatParams& p, int Rk, int Rv, hipStream_t s) {
     default: return Rk == 128 ? launch_prefill_lat<12, 8, QB>(p, s) : launch_prefill_lat<12, 4, QB>(p, s);
   }
 #undef PL_CASE
+  }
 }
 
 }  // namespace
@@ -796,8 +856,8 @@ extern "C" int palu_prefill_attn_lat_f16(const void* q, int64_t sq_h, int64_t sq
   return dispatch_prefill_lat<0>(p, Rk, Rv, (hipStream_t)stream);
 }
 
-// The same over PACKED 4-bit caches (quant.hip's layout: codes [G][.][R / 2] bytes, meta [G][.][2] fp16 (scale, zero) per (token,
-// group) row; byte strides for the codes, element strides for the meta): the codes are de-quantised inside the kernel -- keys in the
+// The same over PACKED 4-bit or 3-bit caches (quant.hip's layout: codes [G][.][R bits / 8] bytes, meta [G][.][2] fp16 (scale, zero) per
+// (token, group) row; byte strides for the codes, element strides for the meta; 3-bit: rank_k / G = 128 and rank_v / G in {128, 256, 384}): the codes are de-quantised inside the kernel -- keys in the
 // rebuild's registers, values into the half-tile image -- with unpack_dequant's arithmetic; no fp16 copy of the cache exists.
 // bt = B^T [H][128][Rk] with the columns of every group of 8 in the order 0 4 1 5 2 6 3 7.
 extern "C" int palu_prefill_attn_lat_q(const void* q, int64_t sq_h, int64_t sq_t, const void* k_codes, int64_t skc_g, int64_t skc_l,
@@ -806,8 +866,10 @@ extern "C" int palu_prefill_attn_lat_q(const void* q, int64_t sq_h, int64_t sq_t
                                        const void* cs, void* out, int64_t so_t, int H, int G, int D, int Tq, int Tk, int Rk, int Rv,
                                        int bits, int past, int causal, float scale, palu_stream_t stream) {
   PALU_REQUIRE(q && k_codes && k_meta && v_codes && v_meta && bt_perm && cs && out, PALU_ERR_ARG, "prefill_attn_lat_q: null pointer");
-  PALU_REQUIRE(bits == 4, PALU_ERR_UNSUPPORTED, "prefill_attn_lat_q: 4-bit codes only (got %d)", bits);
+  PALU_REQUIRE(bits == 4 || bits == 3, PALU_ERR_UNSUPPORTED, "prefill_attn_lat_q: 3- or 4-bit codes (got %d)", bits);
   PALU_REQUIRE(Rv % 64 == 0, PALU_ERR_UNSUPPORTED, "prefill_attn_lat_q: rank_v / G = %d is taken for fp16 rows only", Rv);
+  PALU_REQUIRE(bits == 4 || (Rk == 128 && Rv % 128 == 0), PALU_ERR_UNSUPPORTED,
+               "prefill_attn_lat_q: 3-bit rows need rank_k / G = 128 and rank_v / G in {128, 256, 384} (got %d, %d)", Rk, Rv);
   PALU_REQUIRE(palu_prefill_attn_lat_supported(H, G, D, Rk, Rv), PALU_ERR_UNSUPPORTED,
                "prefill_attn_lat_q: needs head_dim 128, rank_k / G in {64, 128} with rank_v / G in {128, 192, 256, 384}, or 32 / 64 (H=%d G=%d D=%d Rk=%d Rv=%d)", H,
                G, D, Rk, Rv);
@@ -818,7 +880,7 @@ extern "C" int palu_prefill_attn_lat_q(const void* q, int64_t sq_h, int64_t sq_t
   PALU_REQUIRE((((uintptr_t)q | (uintptr_t)k_codes | (uintptr_t)v_codes | (uintptr_t)bt_perm | (uintptr_t)cs) & 15) == 0 &&
                    (((uintptr_t)k_meta | (uintptr_t)v_meta) & 3) == 0 && sq_h % 8 == 0 && sq_t % 8 == 0 && skc_g % 16 == 0 &&
                    skc_l % 16 == 0 && svc_g % 16 == 0 && svc_l % 16 == 0 && skm_g % 2 == 0 && skm_l % 2 == 0 && svm_g % 2 == 0 &&
-                   svm_l % 2 == 0 && skc_l >= Rk / 2 && svc_l >= Rv / 2 && ((uintptr_t)out & 7) == 0 && so_t % 4 == 0,
+                   svm_l % 2 == 0 && skc_l >= Rk * bits / 8 && svc_l >= Rv * bits / 8 && ((uintptr_t)out & 7) == 0 && so_t % 4 == 0,
                PALU_ERR_ARG, "prefill_attn_lat_q: code rows must be 16-byte aligned, meta pairs 4-byte aligned (out 8-byte)");
   PALU_REQUIRE(((int64_t)Tk + PL_BN) * skc_l < ((int64_t)1 << 32) && ((int64_t)Tk + PL_BN) * svc_l < ((int64_t)1 << 32),
                PALU_ERR_UNSUPPORTED, "prefill_attn_lat_q: one group's code slab must stay below 4 GiB");
@@ -838,5 +900,6 @@ extern "C" int palu_prefill_attn_lat_q(const void* q, int64_t sq_h, int64_t sq_t
   p.nqt = (Tq + PL_BM - 1) / PL_BM;
   p.head_major = (int64_t)p.nqt * H <= 2048 ? 1 : 2;
   if (p.head_major == 2 && H % 8 != 0) p.head_major = 0;
+  if (bits == 3) return dispatch_prefill_lat<3>(p, Rk, Rv, (hipStream_t)stream);
   return dispatch_prefill_lat<4>(p, Rk, Rv, (hipStream_t)stream);
 }

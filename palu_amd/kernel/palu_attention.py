@@ -907,7 +907,9 @@ class LlamaPaluAttention(nn.Module):
             one_launch_bytes += 2 * kv_all * G * (Rk + Rv)          # the dequantised rows
         lat_above = self.PREFILL_LATENT_ABOVE
         pos_flat = pos.reshape(-1)
-        lat_packed_ok = packed and getattr(cache, "n_bits", 0) == 4 and not getattr(cache, "group_size", 0) and Rv % 64 == 0
+        nb = getattr(cache, "n_bits", 0) if packed else 0
+        lat_packed_ok = (packed and not getattr(cache, "group_size", 0)
+                         and ((nb == 4 and Rv % 64 == 0) or (nb == 3 and Rk == 128 and Rv % 128 == 0)))
         if (lat_above is not None and (not packed or lat_packed_ok) and panel_rows == 0 and one_launch_bytes > lat_above and dt == torch.float16
                 and self.n_rep == 1 and _lib.lib.palu_prefill_attn_lat_supported(H, G, D, Rk, Rv)
                 and bool((pos_flat == torch.arange(int(pos_flat[0]), int(pos_flat[0]) + q_len, device=pos_flat.device)).all())

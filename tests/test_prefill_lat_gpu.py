@@ -146,7 +146,7 @@ def _module(hidden, H, gs, Rk, Rv, seed=0):
 
 
 @pytest.mark.parametrize("ranks", [(128, 384), (64, 192)], ids=["config2_ranks", "config4_ranks"])
-@pytest.mark.parametrize("bits", [16, 4])
+@pytest.mark.parametrize("bits", [16, 4, 3])
 @pytest.mark.parametrize("causal", [True, False])
 def test_prompt_pass_in_latent_form_equals_workspace_form_and_feeds_decode(causal, bits, ranks):
     """LlamaPaluAttention.forward with the latent kernel forced (PREFILL_LATENT_ABOVE = 0, query chunks of 256 -- and 200, not a
@@ -155,6 +155,8 @@ def test_prompt_pass_in_latent_form_equals_workspace_form_and_feeds_decode(causa
     from palu_amd.kernel.palu_attention import LatentCache, QuantLatentCache
     hidden, H, gs, T1, T2 = 1024, 8, 4, 700, 333
     Rk, Rv = ranks
+    if bits == 3 and Rk != 128:
+        pytest.skip("3-bit rows in the latent kernel: rank_k / G = 128")
     m = _module(hidden, H, gs, Rk, Rv)
     x1 = torch.randn(1, T1, hidden, device=DEV, dtype=torch.float16)
     x2 = torch.randn(1, T2, hidden, device=DEV, dtype=torch.float16)
@@ -181,7 +183,7 @@ def test_prompt_pass_in_latent_form_equals_workspace_form_and_feeds_decode(causa
             assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("bits", [16, 4])
+@pytest.mark.parametrize("bits", [16, 4, 3])
 def test_latent_prompt_pass_needs_128_mib_of_transients_at_32k_tokens(bits):
     """the prompt pass without the [H, kv, D] key workspace and the transposed value copy.  32k tokens at the
     config-2 ranks into an fp16 cache: the latent form's transients (rotated queries + context rows of one 2048-query chunk, the
@@ -231,17 +233,22 @@ def bt_perm_of(b):
     return b.transpose(1, 2).reshape(H, D, R // 8, 8)[..., idx].reshape(H, D, R).contiguous()
 
 
-@pytest.mark.parametrize("H,gs,Tq,Tk,Rk,Rv,causal", [
+@pytest.mark.parametrize("shape", [
     (4, 4, 128, 128, 128, 384, True), (8, 4, 257, 257, 128, 128, True), (32, 4, 300, 300, 128, 384, True), (8, 4, 129, 1000, 128, 384, True),
     (4, 4, 200, 70, 128, 384, False), (8, 4, 333, 333, 128, 256, True), (8, 2, 64, 4097, 128, 384, True),
     (32, 4, 700, 700, 64, 192, True), (8, 4, 129, 1000, 64, 192, False), (8, 4, 257, 520, 128, 192, True),                                     # config-4 ranks
     (4, 2, 130, 130, 32, 64, True),
+    # 3-bit rows (config 3: 3-bit latents + Hadamard -- the rotation lives in the weights): rank_k / G = 128, rank_v / G in {128, 256, 384}
+    (4, 4, 128, 128, 128, 384, True, 3), (8, 4, 257, 257, 128, 128, True, 3), (32, 4, 300, 300, 128, 384, True, 3), (8, 4, 129, 1000, 128, 384, True, 3),
+    (4, 4, 200, 70, 128, 384, False, 3), (8, 4, 333, 333, 128, 256, True, 3), (8, 2, 64, 4097, 128, 384, True, 3), (4, 1, 1, 200, 128, 256, False, 3),
 ])
-def test_latent_prefill_kernel_on_packed_4bit_caches(H, gs, Tq, Tk, Rk, Rv, causal):
+def test_latent_prefill_kernel_on_packed_caches(shape):
     """palu_prefill_attn_lat_q de-quantises the codes inside the kernel: same result as the fp16 kernel on unpack_dequant()'s rows
     (identical fp16 values enter the MFMAs; only the rebuild's summation order differs through the permuted B^T columns), and the
     fp32 evaluation on those rows."""
     from palu_amd.kernel.quant import quantize_pack, unpack_dequant
+    H, gs, Tq, Tk, Rk, Rv, causal = shape[:7]
+    bits = shape[7] if len(shape) > 7 else 4
     _lib, ar = _mods()
     lib, S = _lib.lib, torch.cuda.current_stream().cuda_stream
     G = H // gs
@@ -252,11 +259,12 @@ def test_latent_prefill_kernel_on_packed_4bit_caches(H, gs, Tq, Tk, Rk, Rv, caus
     xk = torch.randn(G, cap, Rk, generator=g).half().to(DEV)
     xv = torch.randn(G, cap, Rv, generator=g).half().to(DEV)
     b = (torch.randn(H, Rk, D, generator=g) * Rk ** -0.5).half().to(DEV)
-    kc, km = quantize_pack(xk, 4)
-    vc, vm = quantize_pack(xv, 4)
+    kc, km = quantize_pack(xk, bits)
+    vc, vm = quantize_pack(xv, bits)
     kc[:, Tk:], vc[:, Tk:] = 0xFF, 0xFF                                      # rows beyond Tk hold garbage
     km[:, Tk:], vm[:, Tk:] = float("nan"), float("nan")
-    xkd, xvd = unpack_dequant(kc[:, :Tk].contiguous(), km[:, :Tk].contiguous(), 4, Rk), unpack_dequant(vc[:, :Tk].contiguous(), vm[:, :Tk].contiguous(), 4, Rv)
+    xkd = unpack_dequant(kc[:, :Tk].contiguous(), km[:, :Tk].contiguous(), bits, Rk)
+    xvd = unpack_dequant(vc[:, :Tk].contiguous(), vm[:, :Tk].contiguous(), bits, Rv)
     inv = ar.rope_inv_freq(torch.device(DEV))
     ref16 = _lat_form(q, xkd, xvd, b, past, causal, inv, Tk)
     cs = torch.empty(lib.palu_rope_cs_table_bytes(Tk), dtype=torch.uint8, device=DEV)
@@ -266,7 +274,7 @@ def test_latent_prefill_kernel_on_packed_4bit_caches(H, gs, Tq, Tk, Rk, Rv, caus
     _lib.check(lib.palu_prefill_attn_lat_q(q.data_ptr(), q.stride(0), q.stride(1), kc.data_ptr(), kc.stride(0), kc.stride(1),
                                            km.data_ptr(), km.stride(0), km.stride(1), vc.data_ptr(), vc.stride(0), vc.stride(1),
                                            vm.data_ptr(), vm.stride(0), vm.stride(1), btp.data_ptr(), cs.data_ptr(), out.data_ptr(),
-                                           out.stride(0), H, G, D, Tq, Tk, Rk, Rv, 4, past, 1 if causal else 0, 1.0 / math.sqrt(D), S),
+                                           out.stride(0), H, G, D, Tq, Tk, Rk, Rv, bits, past, 1 if causal else 0, 1.0 / math.sqrt(D), S),
                "prefill_attn_lat_q")
     assert torch.isfinite(out).all()
     scale = ref16.float().abs().max().item()
