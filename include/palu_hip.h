@@ -440,7 +440,7 @@ size_t palu_prefill_state_bytes(int H, int Tq, int Rv, int which);
  * xk [G][>= Tk][128] / xv [G][>= Tk][Rv] fp16 latent caches (row l = position l), bt = B^T [H][128 d][Rk] contiguous (the rows
  * of U_h), cs = the rotary cache of the key positions 0 .. Tk - 1, [pos][2][64] fp16 (cos row, sin row), built once by
  * palu_rope_cs_table_build (palu_rope_cs_table_bytes(npos) bytes); out [Tq][H * Rv] fp16.  Needs head_dim 128, rank_k / G in {64, 128} with
- * rank_v / G in {128, 192, 256, 384}, or 32 / 64 (palu_prefill_attn_lat_supported); causal as palu_prefill_attn_f16. */
+ * rank_v / G in {128, 192, 256, 384}, or 32 with 64 / 96 (palu_prefill_attn_lat_supported); causal as palu_prefill_attn_f16. */
 size_t palu_rope_cs_table_bytes(int npos);
 int palu_rope_cs_table_build(const float* inv_freq, int pos0, int npos, void* table, palu_stream_t stream);
 int palu_prefill_attn_lat_supported(int H, int G, int D, int Rk, int Rv);
@@ -448,11 +448,12 @@ int palu_prefill_attn_lat_f16(const void* q, int64_t sq_h, int64_t sq_t, const v
                               const void* xv, int64_t sxv_g, int64_t sxv_l, const void* bt, const void* cs, void* out,
                               int64_t so_t, int H, int G, int D, int Tq, int Tk, int Rk, int Rv, int past, int causal,
                               float scale, palu_stream_t stream);
-/* The same over PACKED 4-bit latent caches (the reference's README.md:24 TODO; values defined by palu/model/modules/quant.py:37-39):
- * codes [G][>= Tk][R / 2] bytes (byte strides s*c_g, s*c_l), meta [G][>= Tk][2] fp16 (scale, zero) per (token, group) row (element
+/* The same over PACKED 4-bit or 3-bit latent caches (the reference's README.md:24 TODO; values defined by
+ * palu/model/modules/quant.py:37-39): codes [G][>= Tk][R bits / 8] bytes (byte strides s*c_g, s*c_l), meta [G][>= Tk][2] fp16 (scale, zero) per (token, group) row (element
  * strides) -- palu_quantize_pack's layout.  The codes are de-quantised inside the kernel with palu_unpack_dequant's arithmetic (keys
  * in the rebuild's registers, values into the kernel's half-tile image): no fp16 copy of the cache exists.  bt_perm = B^T
- * [H][128][Rk] with the columns of every group of 8 in the order 0 4 1 5 2 6 3 7 (the order the nibbles leave a dword).  bits = 4. */
+ * [H][128][Rk] with the columns of every group of 8 in the order 0 4 1 5 2 6 3 7 (the order the nibbles leave a dword; the 3-bit form extracts its pairs in the same
+ * order).  bits = 4: rank_v / G a multiple of 64; bits = 3: rank_k / G = 128 and rank_v / G in {128, 256, 384}. */
 int palu_prefill_attn_lat_q(const void* q, int64_t sq_h, int64_t sq_t, const void* k_codes, int64_t skc_g, int64_t skc_l,
                             const void* k_meta, int64_t skm_g, int64_t skm_l, const void* v_codes, int64_t svc_g,
                             int64_t svc_l, const void* v_meta, int64_t svm_g, int64_t svm_l, const void* bt_perm,

@@ -109,7 +109,7 @@ def test_prefill_kernel_rejects_bad_args():
 @pytest.mark.parametrize("form", ["default", "latent"])
 def test_prefill_module_golden(golden_dir, case, form):
     """Prompt pass through LlamaPaluAttention.forward (flash kernel) vs the reference's own outputs.  form = "latent": the kernel that
-    rebuilds the keys per kv tile itself (csrc/prefill_lat.hip) forced onto the fixtures whose ranks it takes (32 / 64 per group)."""
+    rebuilds the keys per kv tile itself (csrc/prefill_lat.hip) forced onto the fixtures whose ranks it takes (32 / 64 and 32 / 96 per group: all three)."""
     from palu_amd.kernel.palu_attention import LatentCache
     tag, seed, hidden, H, D, gs, rank_k, rank_v, T, causal = case
     g = np.load(os.path.join(golden_dir, "g7_prefill.npz"))
