@@ -444,6 +444,8 @@ size_t palu_prefill_state_bytes(int H, int Tq, int Rv, int which);
 size_t palu_rope_cs_table_bytes(int npos);
 int palu_rope_cs_table_build(const float* inv_freq, int pos0, int npos, void* table, palu_stream_t stream);
 int palu_prefill_attn_lat_supported(int H, int G, int D, int Rk, int Rv);
+/* the same per row format: bits = 16 (fp16 rows, palu_prefill_attn_lat_f16), 4 or 3 (packed rows, palu_prefill_attn_lat_q) */
+int palu_prefill_attn_lat_supported_bits(int H, int G, int D, int Rk, int Rv, int bits);
 int palu_prefill_attn_lat_f16(const void* q, int64_t sq_h, int64_t sq_t, const void* xk, int64_t sxk_g, int64_t sxk_l,
                               const void* xv, int64_t sxv_g, int64_t sxv_l, const void* bt, const void* cs, void* out,
                               int64_t so_t, int H, int G, int D, int Tq, int Tk, int Rk, int Rv, int past, int causal,

@@ -101,6 +101,7 @@ SIGNATURES = {
     "palu_rope_cs_table_bytes": (sz, [i32]),
     "palu_rope_cs_table_build": (i32, [vp, i32, i32, vp, vp]),
     "palu_prefill_attn_lat_supported": (i32, [i32, i32, i32, i32, i32]),
+    "palu_prefill_attn_lat_supported_bits": (i32, [i32, i32, i32, i32, i32, i32]),
     "palu_prefill_attn_lat_q": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, vp, i64,
                                       i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, f32, vp]),
     "palu_prefill_attn_lat_f16": (i32, [vp, i64, i64, vp, i64, i64, vp, i64, i64, vp, vp, vp, i64, i32, i32, i32, i32, i32, i32,

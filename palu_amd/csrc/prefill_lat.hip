@@ -818,6 +818,15 @@ extern "C" int palu_prefill_attn_lat_supported(int H, int G, int D, int Rk, int 
   return ((Rk == 128 || Rk == 64) && (Rv == 384 || Rv == 256 || Rv == 192 || Rv == 128)) ? 1 : 0;
 }
 
+// bits = 16 (fp16 rows), 4 or 3 (packed rows with whole-row (scale, zero) pairs): which entry takes the shape
+extern "C" int palu_prefill_attn_lat_supported_bits(int H, int G, int D, int Rk, int Rv, int bits) {
+  if (!palu_prefill_attn_lat_supported(H, G, D, Rk, Rv)) return 0;
+  if (bits == 16) return 1;
+  if (bits == 4) return Rv % 64 == 0 ? 1 : 0;
+  if (bits == 3) return (Rk == 128 && Rv % 128 == 0) ? 1 : 0;
+  return 0;
+}
+
 // Prompt attention of Tq queries (rotated, [H][Tq][128]; the first at absolute position `past`) over the first Tk rows of the
 // latent caches xk [G][.][128], xv [G][.][Rv] (fp16, row l = position l, 16-byte aligned rows); bt = B^T [H][128][Rk] contiguous;
 // cs = palu_rope_cs_table_build(inv_freq, 0, >= Tk).  out [Tq][H * Rv] fp16.  No workspace.
@@ -867,12 +876,9 @@ extern "C" int palu_prefill_attn_lat_q(const void* q, int64_t sq_h, int64_t sq_t
                                        int bits, int past, int causal, float scale, palu_stream_t stream) {
   PALU_REQUIRE(q && k_codes && k_meta && v_codes && v_meta && bt_perm && cs && out, PALU_ERR_ARG, "prefill_attn_lat_q: null pointer");
   PALU_REQUIRE(bits == 4 || bits == 3, PALU_ERR_UNSUPPORTED, "prefill_attn_lat_q: 3- or 4-bit codes (got %d)", bits);
-  PALU_REQUIRE(Rv % 64 == 0, PALU_ERR_UNSUPPORTED, "prefill_attn_lat_q: rank_v / G = %d is taken for fp16 rows only", Rv);
-  PALU_REQUIRE(bits == 4 || (Rk == 128 && Rv % 128 == 0), PALU_ERR_UNSUPPORTED,
-               "prefill_attn_lat_q: 3-bit rows need rank_k / G = 128 and rank_v / G in {128, 256, 384} (got %d, %d)", Rk, Rv);
-  PALU_REQUIRE(palu_prefill_attn_lat_supported(H, G, D, Rk, Rv), PALU_ERR_UNSUPPORTED,
-               "prefill_attn_lat_q: needs head_dim 128, rank_k / G in {64, 128} with rank_v / G in {128, 192, 256, 384}, or 32 / 64 (H=%d G=%d D=%d Rk=%d Rv=%d)", H,
-               G, D, Rk, Rv);
+  PALU_REQUIRE(palu_prefill_attn_lat_supported_bits(H, G, D, Rk, Rv, bits), PALU_ERR_UNSUPPORTED,
+               "prefill_attn_lat_q: needs head_dim 128 and, at 4 bit, rank_k / G in {64, 128} with rank_v / G in {128, 192, 256, 384} or 32 / 64; at 3 "
+               "bit rank_k / G = 128 with rank_v / G in {128, 256, 384} (H=%d G=%d D=%d Rk=%d Rv=%d bits=%d)", H, G, D, Rk, Rv, bits);
   PALU_REQUIRE(Tq >= 0 && Tk >= 0 && past >= 0 && (int64_t)past + Tq < (1 << 30), PALU_ERR_ARG, "prefill_attn_lat_q: bad lengths");
   if (Tq == 0) return PALU_OK;
   PALU_REQUIRE(Tk > 0, PALU_ERR_ARG, "prefill_attn_lat_q: no keys");

@@ -791,9 +791,12 @@ class LlamaPaluAttention(nn.Module):
     # (2 t H (D + Rv) bytes: 96 MiB at PREFILL_LATENT_QUERY_CHUNK = 3072 and the config-2 ranks), whatever the prompt length.  It costs
     # the rebuild's +25 % of matrix work (64k tokens: ~105 ms against ~82 ms for the one-launch workspace form with its 2.4 GiB of
     # transients), so it is selected when the workspace form would exceed PREFILL_LATENT_ABOVE bytes of transients; 0 = always,
-    # None = never.  fp16 and packed 4-bit caches at head_dim 128, rank_k / G in {64, 128}, rank_v / G in {128, 192, 256, 384}.
+    # None = never.  fp16, packed 4-bit and (rank_k / G = 128) packed 3-bit caches at head_dim 128 -- the shapes
+    # palu_prefill_attn_lat_supported_bits lists.  PREFILL_LATENT_PROJECT_ROWS: the latent projections (straight into cache rows:
+    # no transient) run ahead of the attention in blocks of that many rows.
     PREFILL_LATENT_ABOVE = 256 << 20
     PREFILL_LATENT_QUERY_CHUNK = 3072
+    PREFILL_LATENT_PROJECT_ROWS = 16384
 
     def _bt_fragments(self, permuted: bool = False):
         """B^T [H, D, Rk] contiguous (row d of head h = the weights that rebuild K[., d]): cached like the abx fragments.
@@ -834,27 +837,36 @@ class LlamaPaluAttention(nn.Module):
         stream = _lib.current_stream()
         p0 = int(pos.reshape(-1)[0])
 
-        def project(hs):
-            t_ = hs.shape[1]
+        def project(r0, r1):
+            """Latent rows r0 .. r1 - 1 of this pass into the cache; False if that block size would need a temporary (retry smaller)."""
+            hs = hidden_states[:, r0:r1]
             if not packed:
                 self._project_into_cache(hs, cache)                                       # latents straight into the rows
             elif not self._project_into_packed_cache(hs, cache):
-                kh = self.k_proj.project_to_latent(hs).view(1, t_, G, Rk).transpose(1, 2)
-                vh = self.v_proj.project_to_latent(hs).view(1, t_, G, Rv).transpose(1, 2)
+                if r1 - r0 > qc:
+                    return False
+                kh = self.k_proj.project_to_latent(hs).view(1, r1 - r0, G, Rk).transpose(1, 2)
+                vh = self.v_proj.project_to_latent(hs).view(1, r1 - r0, G, Rv).transpose(1, 2)
                 cache.append_rows(kh, vh, li)                                             # quantise + pack this chunk's rows
-        all_first = (not causal) and q_len > qc        # no mask: every query attends every key of the pass (see _prefill_flash)
-        if all_first:
-            for c0 in range(0, q_len, qc):
-                project(hidden_states[:, c0:min(q_len, c0 + qc)])
+            return True
+        # The projections write straight into cache rows and need no transient, so they run AHEAD of the attention in blocks of
+        # PREFILL_LATENT_PROJECT_ROWS rows (a 3072-row block of the rank-128 projection is 96 workgroups on 256 CUs; cache rows
+        # beyond a chunk's kv are never read).  No mask: every query attends every key of the pass -- all rows first.
+        pb = q_len if not causal else max(qc, int(self.PREFILL_LATENT_PROJECT_ROWS))
+        done = 0
         out = None
         for c0 in range(0, q_len, qc):
             c1 = min(q_len, c0 + qc)
             t = c1 - c0
             hs = hidden_states[:, c0:c1]
             q = self.q_proj(hs).view(t, H, D).transpose(0, 1)                             # [H,t,D] view of [t, H*D]
-            if not all_first:
-                project(hs)
-            kv = kv_all if all_first else past + c1
+            while done < (c1 if causal else q_len):
+                blk = min(q_len, done + pb)
+                if not project(done, blk):
+                    pb = qc                                                               # (no fused quantise tile: chunk by chunk)
+                    continue
+                done = blk
+            kv = past + c1 if causal else kv_all
             _lib.check(_lib.lib.palu_rope_f16(q.data_ptr(), q.stride(0), q.stride(1), H, t, D, p0 + c0, inv.data_ptr(), stream),
                        "palu_rope_f16")
             ctx = torch.empty((t, H * Rv), dtype=dt, device=dev)
@@ -907,11 +919,10 @@ class LlamaPaluAttention(nn.Module):
             one_launch_bytes += 2 * kv_all * G * (Rk + Rv)          # the dequantised rows
         lat_above = self.PREFILL_LATENT_ABOVE
         pos_flat = pos.reshape(-1)
-        nb = getattr(cache, "n_bits", 0) if packed else 0
-        lat_packed_ok = (packed and not getattr(cache, "group_size", 0)
-                         and ((nb == 4 and Rv % 64 == 0) or (nb == 3 and Rk == 128 and Rv % 128 == 0)))
+        nb = int(getattr(cache, "n_bits", 0)) if packed else 16
+        lat_packed_ok = packed and not getattr(cache, "group_size", 0)
         if (lat_above is not None and (not packed or lat_packed_ok) and panel_rows == 0 and one_launch_bytes > lat_above and dt == torch.float16
-                and self.n_rep == 1 and _lib.lib.palu_prefill_attn_lat_supported(H, G, D, Rk, Rv)
+                and self.n_rep == 1 and _lib.lib.palu_prefill_attn_lat_supported_bits(H, G, D, Rk, Rv, nb)
                 and bool((pos_flat == torch.arange(int(pos_flat[0]), int(pos_flat[0]) + q_len, device=pos_flat.device)).all())
                 and self.q_proj.weight.dtype == dt):
             return self._prefill_latent(hidden_states, pos, cache, causal)
@@ -955,7 +966,7 @@ class LlamaPaluAttention(nn.Module):
             q = self.q_proj(hs).view(t, H, D).transpose(0, 1)                             # [H,t,D] view of [t, H*D]
             if not all_first:
                 project_latents(hs)
-            kv = kv_all if all_first else past + c1
+            kv = past + c1 if causal else kv_all
             if contiguous_pos and q.stride(2) == 1:
                 _lib.check(_lib.lib.palu_rope_f16(q.data_ptr(), q.stride(0), q.stride(1), H, t, D, p0 + c0, inv.data_ptr(),
                                                   stream), "palu_rope_f16")

@@ -116,6 +116,9 @@ def test_latent_prefill_rejects_unsupported_shapes():
     assert lib.palu_prefill_attn_lat_supported(32, 8, 128, 32, 96) == 1            # config-1 ranks (fp16 rows)
     assert lib.palu_prefill_attn_lat_supported(32, 8, 128, 32, 128) == 0
     assert lib.palu_prefill_attn_lat_supported(32, 8, 64, 128, 384) == 0
+    for shape, want in (((128, 384), (1, 1, 1)), ((64, 192), (1, 1, 0)), ((32, 96), (1, 0, 0)), ((128, 192), (1, 1, 0)), ((128, 256), (1, 1, 1))):
+        assert tuple(lib.palu_prefill_attn_lat_supported_bits(32, 8, 128, *shape, b) for b in (16, 4, 3)) == want
+    assert lib.palu_prefill_attn_lat_supported_bits(32, 8, 128, 128, 384, 8) == 0
     t = torch.zeros(1024, dtype=torch.float16, device=DEV)
     rc = lib.palu_prefill_attn_lat_f16(t.data_ptr(), 128, 128, t.data_ptr(), 128, 128, t.data_ptr(), 192, 192, t.data_ptr(), t.data_ptr(),
                                        t.data_ptr(), 192, 4, 1, 128, 1, 1, 32, 160, 0, 1, 0.1, torch.cuda.current_stream().cuda_stream)
@@ -165,13 +168,14 @@ def test_prompt_pass_in_latent_form_equals_workspace_form_and_feeds_decode(causa
     for mode, above, chunk in (("workspace", None, 2048), ("latent", 0, 256), ("latent200", 0, 200)):
         cache = LatentCache() if bits == 16 else QuantLatentCache(bits)
         m.PREFILL_LATENT_ABOVE, m.PREFILL_LATENT_QUERY_CHUNK = above, chunk
+        m.PREFILL_LATENT_PROJECT_ROWS = 500 if mode == "latent200" else 16384    # projections ahead of the attention: 500-row blocks / all at once
         try:
             with torch.no_grad():
                 o1, _, _ = m(x1, past_key_value=cache, is_causal=causal)
                 o2, _, _ = m(x2, past_key_value=cache, is_causal=causal, position_ids=torch.arange(T1, T1 + T2).unsqueeze(0))
                 od, _, _ = m(xd, past_key_value=cache, position_ids=torch.tensor([[T1 + T2]]))
         finally:
-            del m.PREFILL_LATENT_ABOVE, m.PREFILL_LATENT_QUERY_CHUNK
+            del m.PREFILL_LATENT_ABOVE, m.PREFILL_LATENT_QUERY_CHUNK, m.PREFILL_LATENT_PROJECT_ROWS
         bufs = cache.buffers(0) if bits == 16 else [cache.buffers(0)[k] for k in ("kc", "km", "vc", "vm")]
         outs[mode] = (o1, o2, od, [b[:, :, :T1 + T2 + 1].clone() for b in bufs])
     ref = outs["workspace"]
