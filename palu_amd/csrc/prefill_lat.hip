@@ -768,6 +768,20 @@ int launch_prefill_lat(const PfLatParams& p, hipStream_t stream) {
   return PALU_OK;
 }
 
+// workgroup order: 2 = eight heads at a time, one per XCD (a head's query tiles share its group's rows in that XCD's L2), heavy
+// tiles first; 1 = head-major.  (The query chunks of the module's prompt pass -- 24 tiles x 32 heads -- ran 5 % slower in order 1:
+// 99.0 vs 94.0 ms for 64k tokens, tools/time_prefill_lat_chunks.py.)  PALU_PL_ORDER=0/1/2 forces one (experiments builds).
+int pl_head_major(int nqt, int H) {
+  static int force = -2;
+  if (force == -2) {
+    const char* e = palu_exp_env("PALU_PL_ORDER");
+    force = e ? atoi(e) : -1;
+  }
+  int hm = force >= 0 ? force : ((int64_t)nqt * H <= 256 ? 1 : 2);
+  if (hm == 2 && H % 8 != 0) hm = 0;
+  return hm;
+}
+
 template <int QB>
 int dispatch_prefill_lat(const PfLatParams& p, int Rk, int Rv, hipStream_t s) {
   if constexpr (QB == 3) {                                        // 3-bit rows: rank_k / G = 128, rank_v / G a multiple of 128
@@ -857,8 +871,7 @@ extern "C" int palu_prefill_attn_lat_f16(const void* q, int64_t sq_h, int64_t sq
   p.H = H; p.G = G; p.gs = H / G; p.Tq = Tq; p.Tk = Tk; p.past = past; p.causal = causal ? 1 : 0;
   p.scale_log2 = scale * 1.4426950408889634f;
   p.nqt = (Tq + PL_BM - 1) / PL_BM;
-  p.head_major = (int64_t)p.nqt * H <= 2048 ? 1 : 2;
-  if (p.head_major == 2 && H % 8 != 0) p.head_major = 0;
+  p.head_major = pl_head_major(p.nqt, H);
   p.dbg = g_pl_timeline;
   p.kc = p.vc = nullptr; p.km = p.vm = nullptr;
   p.skc_g = p.skc_l = p.skm_g = p.skm_l = p.svc_g = p.svc_l = p.svm_g = p.svm_l = 0;
@@ -904,8 +917,7 @@ extern "C" int palu_prefill_attn_lat_q(const void* q, int64_t sq_h, int64_t sq_t
   p.H = H; p.G = G; p.gs = H / G; p.Tq = Tq; p.Tk = Tk; p.past = past; p.causal = causal ? 1 : 0;
   p.scale_log2 = scale * 1.4426950408889634f;
   p.nqt = (Tq + PL_BM - 1) / PL_BM;
-  p.head_major = (int64_t)p.nqt * H <= 2048 ? 1 : 2;
-  if (p.head_major == 2 && H % 8 != 0) p.head_major = 0;
+  p.head_major = pl_head_major(p.nqt, H);
   if (bits == 3) return dispatch_prefill_lat<3>(p, Rk, Rv, (hipStream_t)stream);
   return dispatch_prefill_lat<4>(p, Rk, Rv, (hipStream_t)stream);
 }
