@@ -922,7 +922,7 @@ class LlamaPaluAttention(nn.Module):
         nb = int(getattr(cache, "n_bits", 0)) if packed else 16
         lat_packed_ok = packed and not getattr(cache, "group_size", 0)
         if (lat_above is not None and (not packed or lat_packed_ok) and panel_rows == 0 and one_launch_bytes > lat_above and dt == torch.float16
-                and self.n_rep == 1 and _lib.lib.palu_prefill_attn_lat_supported_bits(H, G, D, Rk, Rv, nb)
+                and _lib.lib.palu_prefill_attn_lat_supported_bits(H, G, D, Rk, Rv, nb)
                 and bool((pos_flat == torch.arange(int(pos_flat[0]), int(pos_flat[0]) + q_len, device=pos_flat.device)).all())
                 and self.q_proj.weight.dtype == dt):
             return self._prefill_latent(hidden_states, pos, cache, causal)

@@ -126,15 +126,18 @@ def test_latent_prefill_rejects_unsupported_shapes():
 
 
 # ------------------------------------------------------------------------------------------------- module level
-def _module(hidden, H, gs, Rk, Rv, seed=0):
+def _module(hidden, H, gs, Rk, Rv, seed=0, n_rep=1):
+    """n_rep > 1: grouped-query attention -- H query heads over H / n_rep KV heads, gs KV heads per latent group."""
     from torch import nn
     from palu_amd.kernel.palu_attention import LlamaPaluAttention, build_b
 
     class Cfg:
         pass
     cfg = Cfg()
-    G = H // gs
+    kv = H // n_rep
+    G = kv // gs
     cfg.hidden_size, cfg.num_attention_heads, cfg.attention_bias = hidden, H, False
+    cfg.num_key_value_heads = kv
     cfg.group_size, cfg.num_groups, cfg.total_rank_k, cfg.total_rank_v = gs, G, Rk * G, Rv * G
     torch.manual_seed(seed)
     with torch.device(DEV):
@@ -144,8 +147,37 @@ def _module(hidden, H, gs, Rk, Rv, seed=0):
                 lin.weight.normal_(0.0, 0.03)
             for u in m.k_proj.U_list:
                 u.weight.normal_(0.0, Rk ** -0.5)
-        m.k_proj.B = nn.Parameter(build_b([u.weight for u in m.k_proj.U_list], gs, D))
+        m.k_proj.B = nn.Parameter(build_b([u.weight for u in m.k_proj.U_list], gs, D, n_rep))
     return m.eval().prepare_decode()
+
+
+@pytest.mark.parametrize("bits", [16, 4])
+def test_gqa_prompt_pass_in_latent_form(bits):
+    """Grouped-query attention (the Mistral shape of BASELINE config 4: 4 query heads per KV head, one KV head per latent group, ranks
+    64 / 192): a latent group serves n_rep query heads with one B per KV head -- latent form against workspace form, then a decode step."""
+    from palu_amd.kernel.palu_attention import LatentCache, QuantLatentCache
+    hidden, H, T = 1024, 8, 600
+    m = _module(hidden, H, 1, 64, 192, n_rep=4)
+    assert m.n_rep == 4 and m.num_groups == 2 and m.group_size == 4
+    x = torch.randn(1, T, hidden, device=DEV, dtype=torch.float16)
+    xd = torch.randn(1, 1, hidden, device=DEV, dtype=torch.float16)
+    outs = {}
+    for mode, above in (("workspace", None), ("latent", 0)):
+        cache = LatentCache() if bits == 16 else QuantLatentCache(bits)
+        m.PREFILL_LATENT_ABOVE, m.PREFILL_LATENT_QUERY_CHUNK = above, 256
+        calls = []
+        inner = m._prefill_latent
+        m._prefill_latent = lambda *a, **k: (calls.append(1), inner(*a, **k))[1]
+        try:
+            with torch.no_grad():
+                o, _, _ = m(x, past_key_value=cache, is_causal=True)
+                od, _, _ = m(xd, past_key_value=cache, position_ids=torch.tensor([[T]]))
+        finally:
+            del m.PREFILL_LATENT_ABOVE, m.PREFILL_LATENT_QUERY_CHUNK, m._prefill_latent
+        assert bool(calls) == (mode == "latent")
+        outs[mode] = (o, od)
+    for a, b in zip(outs["latent"], outs["workspace"]):
+        torch.testing.assert_close(a.float(), b.float(), rtol=2e-3, atol=2e-3)
 
 
 @pytest.mark.parametrize("ranks", [(128, 384), (64, 192)], ids=["config2_ranks", "config4_ranks"])
