@@ -123,6 +123,13 @@ def test_latent_prefill_rejects_unsupported_shapes():
     rc = lib.palu_prefill_attn_lat_f16(t.data_ptr(), 128, 128, t.data_ptr(), 128, 128, t.data_ptr(), 192, 192, t.data_ptr(), t.data_ptr(),
                                        t.data_ptr(), 192, 4, 1, 128, 1, 1, 32, 160, 0, 1, 0.1, torch.cuda.current_stream().cuda_stream)
     assert rc != 0
+    # the packed entry refuses what the query says it does not take: 3-bit rows at rank_k / G = 64, 4-bit rows at rank_v / G = 96
+    u8 = torch.zeros(4096, dtype=torch.uint8, device=DEV)
+    for Rk, Rv, bits in ((64, 192, 3), (32, 96, 4), (128, 384, 5)):
+        rc = lib.palu_prefill_attn_lat_q(t.data_ptr(), 128, 128, u8.data_ptr(), 4096, 64, t.data_ptr(), 64, 2, u8.data_ptr(), 4096, 192,
+                                         t.data_ptr(), 64, 2, t.data_ptr(), t.data_ptr(), t.data_ptr(), 4 * Rv, 4, 1, 128, 1, 1, Rk, Rv, bits,
+                                         0, 1, 0.1, torch.cuda.current_stream().cuda_stream)
+        assert rc != 0, (Rk, Rv, bits)
 
 
 # ------------------------------------------------------------------------------------------------- module level
